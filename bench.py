@@ -1,0 +1,181 @@
+"""bench.py — headline benchmark: MojoPagedDecodeGQA, Llama-3-8B shape, on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path over one batch: paged decode attention for B=64 sequences
+(32 q heads / 8 kv heads, head_dim 128, page 16, bf16, ctx 4096 each, block tables a random
+permutation) with all inputs resident in HBM.  ``value`` = tokens/s = B * steps / time, whole job.
+With N > 1 every rank runs its own batch (the op has no exchange step: replicas, weak scaling).
+
+Extra objects on the JSON line:
+  roofline     — HBM roofline of the decode op from HIP-event time of the timed region.
+  cpu_baseline — the torch-native oracle (a port of the reference's golden backend) timed on the
+                 host cores on a bounded sample of the same workload.
+  extras       — other hot-path ops measured in the same run (absolute rate + roofline fraction).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+B, HQ, HKV, D, PAGE, CTX = 64, 32, 8, 128, 16, 4096
+
+
+def build_decode_inputs(device, ctx=CTX, batch=B, seed=20260716, sets=2):
+    g = torch.Generator().manual_seed(seed)
+    pages_per_seq = ctx // PAGE
+    n_pages = batch * pages_per_seq + 10
+    out = []
+    for s in range(sets):
+        q = torch.randn(batch, HQ, D, generator=g).to(torch.bfloat16).to(device)
+        k = torch.randn(n_pages, HKV, PAGE, D, device=device, dtype=torch.bfloat16)
+        v = torch.randn(n_pages, HKV, PAGE, D, device=device, dtype=torch.bfloat16)
+        table = torch.randperm(n_pages, generator=g, dtype=torch.int32)[: batch * pages_per_seq].view(batch, -1)
+        lens = torch.full((batch,), ctx, dtype=torch.int32)
+        out.append((q, k, v, lens.to(device), table.to(device)))
+    return out
+
+
+def decode_algorithmic_bytes(lens, max_blocks):
+    kv = int(lens.sum()) * HKV * D * 2 * 2
+    qo = 2 * lens.numel() * HQ * D * 2
+    idx = 4 * lens.numel() * (max_blocks + 1)
+    return kv + qo + idx
+
+
+def cpu_baseline(budget_s=12.0):
+    """Oracle (port of the reference's torch golden) on the host cores: 4 sequences of the same shape."""
+    import mojo_opset_amd as mo
+    import oracle  # noqa: F401
+
+    sample_b = 4
+    (q, k, v, lens, table), = build_decode_inputs("cpu", batch=sample_b, sets=1)
+    ref = mo.MojoPagedDecodeGQA.get_backend_impl("torch", strict=True)()
+    ref(q, k, v, lens, table)  # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref(q, k, v, lens, table)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return {"value": sample_b * n / el, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} passes of B={sample_b} sequences at ctx={CTX} (same head/page shape), oracle.TorchPagedDecodeGQA"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ns = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import mojo_opset_amd as mo
+
+    op = mo.MojoPagedDecodeGQA.get_backend_impl("hip", strict=True)(is_causal=True, gqa_layout="AABB")
+    sets = build_decode_inputs(device)
+    scale = 1.0 / math.sqrt(D)
+
+    def step(i):
+        q, k, v, lens, table = sets[i % len(sets)]
+        return op(q, k, v, lens, table, softmax_scale=scale, max_total_seq_len=CTX)
+
+    for i in range(ns.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(ns.steps):
+        step(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if dist_on:
+        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    lens_cpu = sets[0][3].cpu()
+    alg_bytes = decode_algorithmic_bytes(lens_cpu, sets[0][4].shape[1])
+    kernel_s = dev_ms / 1e3 / ns.steps
+    achieved = alg_bytes / kernel_s / 1e9
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "decode_gqa_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "MojoPagedDecodeGQA tokens/s (Llama-3-8B shape, bf16, 1/8 MI355X)",
+        "value": world * B * ns.steps / wall,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": ns.steps,
+        "warmup": ns.warmup,
+        "ms_per_step": wall * 1e3 / ns.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": "MojoPagedDecodeGQA bf16, B=64, 32q/8kv, head_dim=128, page=16, ctx=4096 uniform, "
+                               "AABB, random block tables (BASELINE configs[1])",
+                   "per_gpu_batch": B, "parallelism": f"replicas x{world} (no collective on this path)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
+                     "kernel": "mojo::decode_split_kernel<bf16,4> + decode_merge_kernel (one op call)"},
+    }
+    if rank == 0:
+        if not ns.no_extras:
+            try:
+                from benchmarks.extras import run_extras
+
+                line["extras"] = run_extras(device, world)
+            except Exception as e:  # extras must never break the headline line
+                line["extras"] = {"error": repr(e)}
+        if world == 1 and not ns.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/* mojo_hip.h — C ABI of libmojo_hip.so, the MI355X (gfx950) kernel library behind the
+ * `HIP<Op>` backend classes of mojo_opset_amd.
+ *
+ * The reference (XPU-Forces/mojo_opset) has no native code: each accelerated backend class
+ * (e.g. `TTXPagedDecodeGQA.forward`, mojo_opset/backends/ttx/operators/attention.py:143-176)
+ * calls a Python kernel launcher.  Every entry point below replaces one such launcher call; the
+ * comment above it names the reference operator (golden `forward`) whose semantics it implements
+ * and the accelerated call site it stands in for.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - shapes/strides are int64 in ELEMENTS; the innermost dimension is always contiguous;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - no allocation, no host sync, re-entrant; scratch comes from the caller (`workspace`);
+ *   - return 0 on success, a negative MOJO_E* code otherwise; `mojo_hip_last_error()` returns a
+ *     thread-local message for the last failure on the calling thread.
+ */
+#ifndef MOJO_HIP_H
+#define MOJO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mojo_stream_t;
+
+enum mojo_dtype { MOJO_F32 = 0, MOJO_F16 = 1, MOJO_BF16 = 2, MOJO_I8 = 3, MOJO_F8E4M3 = 4 };
+
+enum mojo_status {
+  MOJO_OK = 0,
+  MOJO_EINVAL = -1,        /* malformed arguments (-> AssertionError / ValueError in the shim) */
+  MOJO_EUNSUPPORTED = -2,  /* legal but not implemented for this shape/dtype (-> NotImplementedError) */
+  MOJO_ELAUNCH = -3,       /* HIP launch failure (-> RuntimeError) */
+  MOJO_EWORKSPACE = -4     /* workspace too small (-> RuntimeError) */
+};
+
+const char* mojo_hip_version(void);
+const char* mojo_hip_last_error(void);
+
+/* ---- MojoStorePagedKVCache (core/operators/kv_cache.py:104-171; replaces store_paged_kv(),
+ *      backends/ttx/operators/kv_cache.py:40-46).  Bit-exact copy, token-major -> head-major.
+ *      plan rows = (src_token_start, dst_block_id, dst_block_offset, chunk_len) int32.          */
+int mojo_hip_store_paged_kv_plan(const void* key_states, const void* value_states,
+                                 void* key_cache, void* value_cache,
+                                 const int32_t* plan, int64_t num_chunks,
+                                 int64_t num_tokens, int64_t num_kv_heads, int64_t head_dim,
+                                 int64_t num_blocks, int64_t block_size, int64_t elt_bytes,
+                                 int64_t src_token_stride, int64_t src_head_stride,
+                                 int64_t cache_block_stride, int64_t cache_head_stride,
+                                 int64_t cache_token_stride, mojo_stream_t stream);
+
+/*      Same op, legacy arguments (block_table, cu_q_lens|NULL, context_kv_lens): the plan of
+ *      build_paged_kv_chunk_metadata (kv_cache.py:33-101) is evaluated per token on the device, so
+ *      there is no host sync.  cu_q_lens == NULL selects decode mode (one token per sequence).  */
+int mojo_hip_store_paged_kv_layout(const void* key_states, const void* value_states,
+                                   void* key_cache, void* value_cache,
+                                   const int32_t* block_table, int64_t block_table_stride,
+                                   int64_t max_blocks_per_seq,
+                                   const int32_t* cu_q_lens, const int32_t* context_kv_lens,
+                                   int64_t batch, int64_t num_tokens, int64_t num_kv_heads,
+                                   int64_t head_dim, int64_t num_blocks, int64_t block_size,
+                                   int64_t elt_bytes, int64_t src_token_stride,
+                                   int64_t src_head_stride, int64_t cache_block_stride,
+                                   int64_t cache_head_stride, int64_t cache_token_stride,
+                                   mojo_stream_t stream);
+
+/* ---- MojoSwiGLU (core/operators/activation.py:38-66; replaces swiglu_fwd,
+ *      backends/ttx/operators/activation.py).  Flat contiguous tensors of n elements.           */
+int mojo_hip_swiglu(const void* gate, const void* up, void* out, int64_t n, int dtype,
+                    float swiglu_limit, mojo_stream_t stream);
+
+/* ---- MojoResidualAddRMSNorm / MojoRMSNorm (core/operators/normalization.py:308-362, :71-111;
+ *      replaces fused_add_rmsnorm / rmsnorm launchers, backends/ttx/operators/normalization.py:35-47).
+ *      residual == NULL: plain RMSNorm.  sum_out may be NULL (norm_pos="post").
+ *      sum = round_dtype(hidden + residual); normed = round_dtype(sum * rsqrt(mean(sum^2)+eps) * w). */
+int mojo_hip_residual_add_rmsnorm(const void* hidden, const void* residual, const void* weight,
+                                  void* normed_out, void* sum_out, int64_t rows, int64_t dim,
+                                  int dtype, float eps, mojo_stream_t stream);
+
+/* ---- MojoApplyRoPE (core/operators/position_embedding.py:98-175; replaces rope_fwd,
+ *      backends/ttx/operators/position_embedding.py).  q/k are addressed as [B][T][N][D] through
+ *      explicit strides (so head-first and token-first layouts are read in place); cos/sin are
+ *      fp32 [.., rope_dim] addressed as [B][T] with strides (cos_b_stride may be 0).             */
+int mojo_hip_apply_rope(const void* q, const void* k, void* q_out, void* k_out,
+                        const float* cos, const float* sin,
+                        int64_t batch, int64_t tokens, int64_t q_heads, int64_t k_heads,
+                        int64_t head_dim, int64_t rope_dim,
+                        const int64_t q_strides[3], const int64_t k_strides[3],
+                        const int64_t qo_strides[3], const int64_t ko_strides[3],
+                        int64_t cos_b_stride, int64_t cos_t_stride, int dtype,
+                        mojo_stream_t stream);
+
+/* ---- MojoRotaryEmbedding (core/operators/position_embedding.py:9-95; replaces rot_pos_embed,
+ *      backends/ttx/kernels/ilu/rope.py:634-675 — a host loop with .item() per sequence).
+ *      mode 0: positions = position_ids[i];  mode 1: positions = i (padded prefill);
+ *      mode 2: positions from cu_q_lens (+ total_seq_lens or NULL), tokens outside every
+ *              sequence get position -1 (python-style: last table row / angle -inv_freq).
+ *      cos_table/sin_table == NULL: compute cos/sin(pos * inv_freq) * scaling on the fly.        */
+int mojo_hip_rotary_embedding(float* cos_out, float* sin_out, int64_t n_pos, int64_t rope_dim,
+                              int mode, const int32_t* position_ids, const int32_t* cu_q_lens,
+                              const int32_t* total_seq_lens, int64_t batch,
+                              const float* cos_table, const float* sin_table, int64_t table_len,
+                              const float* inv_freq, float attention_scaling,
+                              mojo_stream_t stream);
+
+/* ---- MojoPagedDecodeGQA (core/operators/attention.py:113-232; replaces paged_attention_decode,
+ *      backends/ttx/operators/attention.py:166-174).  Split-KV flash decoding; the q-heads of one
+ *      kv-head share every K/V load.  layout_abab: 0 = "AABB", 1 = "ABAB".
+ *      max_seq_len_hint <= 0: derive the split count from max_blocks_per_seq * block_size.       */
+int64_t mojo_hip_paged_decode_gqa_workspace_bytes(int64_t batch, int64_t q_heads, int64_t kv_heads,
+                                                  int64_t head_dim, int64_t block_size,
+                                                  int64_t max_blocks_per_seq,
+                                                  int64_t max_seq_len_hint);
+int mojo_hip_paged_decode_gqa(const void* query, const void* key_cache, const void* value_cache,
+                              const int32_t* total_seq_lens, const int32_t* block_tables,
+                              void* out, void* workspace, int64_t workspace_bytes,
+                              int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t head_dim,
+                              int64_t block_size, int64_t max_blocks_per_seq,
+                              int64_t block_table_stride, int64_t cache_block_stride,
+                              int64_t cache_head_stride, int64_t cache_token_stride,
+                              int64_t max_seq_len_hint, float softmax_scale, int layout_abab,
+                              int dtype, mojo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOJO_HIP_H */

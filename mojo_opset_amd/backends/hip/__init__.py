@@ -1,0 +1,7 @@
+"""The ``hip`` backend: `HIP<Op>` classes (one per `Mojo<Op>`), registered by definition.
+
+On a host without a ROCm GPU the classes still import (so their signatures can be inspected) but
+the registry ignores them; on a ROCm host they are the first-priority backend.
+"""
+from .operators.attention import *  # noqa: F401,F403
+from .operators.streaming import *  # noqa: F401,F403

@@ -1,0 +1,124 @@
+"""ctypes binding of libmojo_hip.so (the C ABI declared in include/mojo_hip.h).
+
+The library is located in-tree (``mojo_opset_amd/lib/libmojo_hip.so``) or through
+``MOJO_HIP_LIB``.  There is no fallback of any kind: if it is missing, or a call returns a
+non-zero status, the caller gets an exception.
+"""
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DEFAULT_LIB = os.path.join(_PKG, "lib", "libmojo_hip.so")
+
+MOJO_F32, MOJO_F16, MOJO_BF16, MOJO_I8, MOJO_F8E4M3 = 0, 1, 2, 3, 4
+_DTYPE_CODE = {
+    torch.float32: MOJO_F32, torch.float16: MOJO_F16, torch.bfloat16: MOJO_BF16,
+    torch.int8: MOJO_I8, torch.float8_e4m3fn: MOJO_F8E4M3,
+}
+
+MOJO_EINVAL, MOJO_EUNSUPPORTED, MOJO_ELAUNCH, MOJO_EWORKSPACE = -1, -2, -3, -4
+
+_P = c_void_p
+_I = c_int64
+_I64x3 = c_int64 * 3
+
+# name -> (restype, argtypes); must mirror include/mojo_hip.h exactly (tests/test_c_abi.py checks
+# that every declared symbol is exported and listed here).
+SIGNATURES = {
+    "mojo_hip_version": (c_char_p, []),
+    "mojo_hip_last_error": (c_char_p, []),
+    "mojo_hip_store_paged_kv_plan": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mojo_hip_store_paged_kv_layout": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                               _I, _I, _I, _P]),
+    "mojo_hip_swiglu": (c_int, [_P, _P, _P, _I, c_int, c_float, _P]),
+    "mojo_hip_residual_add_rmsnorm": (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, c_float, _P]),
+    "mojo_hip_apply_rope": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I64x3, _I64x3, _I64x3, _I64x3,
+                                    _I, _I, c_int, _P]),
+    "mojo_hip_rotary_embedding": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _I, _P, _P, _I, _P, c_float, _P]),
+    "mojo_hip_paged_decode_gqa_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I, _I, _I]),
+    "mojo_hip_paged_decode_gqa": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                          c_float, c_int, c_int, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class MojoHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return os.environ.get("MOJO_HIP_LIB", DEFAULT_LIB)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise MojoHipError(
+                f"libmojo_hip.so not found at {path}. Build it with `python -m mojo_opset_amd.csrc.build` "
+                f"(or __graft_entry__.build()). The hip backend has no CPU fallback."
+            )
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise MojoHipError(f"{path} does not export {name}; rebuild the library") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    try:
+        return _DTYPE_CODE[dtype]
+    except KeyError:
+        raise NotImplementedError(f"hip backend: dtype {dtype} is not supported") from None
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def strides3(*vals):
+    return _I64x3(*vals)
+
+
+def check(status: int, what: str):
+    """Map a C status to the exception type the reference's operators raise."""
+    if status == 0:
+        return
+    msg = load().mojo_hip_last_error().decode("utf-8", "replace")
+    text = f"{what}: {msg}"
+    if status == MOJO_EINVAL:
+        raise ValueError(text)
+    if status == MOJO_EUNSUPPORTED:
+        raise NotImplementedError(text)
+    raise MojoHipError(f"{text} (status {status})")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MojoHipError(
+                "hip backend called with a CPU tensor; it has no CPU path (select MOJO_BACKEND=torch from the "
+                "oracle package for host-side reference runs)."
+            )

@@ -1,0 +1,15 @@
+from .activation import MojoSwiGLU
+from .attention import MojoPagedDecodeGQA, MojoPagedPrefillGQA
+from .compute_with_comm import MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllReduce, MojoGemmReduceScatter
+from .gemm import MojoGroupGemm, MojoQuantGemm
+from .kv_cache import MojoStorePagedKVCache, build_paged_kv_chunk_metadata
+from .mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
+from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm
+from .position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
+
+__all__ = [
+    "MojoSwiGLU", "MojoPagedDecodeGQA", "MojoPagedPrefillGQA", "MojoAllGatherGemm", "MojoGemmAll2All",
+    "MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoGroupGemm", "MojoQuantGemm", "MojoStorePagedKVCache",
+    "build_paged_kv_chunk_metadata", "MojoPagedDecodeMLA", "MojoPagedPrefillMLA", "MojoResidualAddRMSNorm",
+    "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding",
+]

@@ -1,0 +1,136 @@
+// Shared device/host helpers for libmojo_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mojo_hip.h"
+
+namespace mojo {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// thread-local error text ------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define MOJO_REQUIRE(cond, code, ...)                                                   \
+  do {                                                                                  \
+    if (!(cond)) {                                                                      \
+      ::mojo::set_error(__VA_ARGS__);                                                   \
+      return (code);                                                                    \
+    }                                                                                   \
+  } while (0)
+
+#define MOJO_CHECK_LAUNCH(what)                                                         \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      ::mojo::set_error("%s: launch failed: %s", (what), hipGetErrorString(e__));       \
+      return MOJO_ELAUNCH;                                                              \
+    }                                                                                   \
+  } while (0)
+
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// DPP lane exchange (one VALU instruction, no LDS) --------------------------------------------
+constexpr int DPP_QUAD_XOR1 = 0xB1;          // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;          // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane i <-> 7-i inside each 8
+constexpr int DPP_ROW_MIRROR = 0x140;        // lane i <-> 15-i inside each 16
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+
+// all-reduce over the 16 lanes of a DPP row; every lane ends with the row's sum
+__device__ __forceinline__ float row16_sum(float x) {
+  x += dpp_mov<DPP_QUAD_XOR1>(x);
+  x += dpp_mov<DPP_QUAD_XOR2>(x);
+  x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+  x += dpp_mov<DPP_ROW_MIRROR>(x);
+  return x;
+}
+__device__ __forceinline__ float row8_sum(float x) {
+  x += dpp_mov<DPP_QUAD_XOR1>(x);
+  x += dpp_mov<DPP_QUAD_XOR2>(x);
+  x += dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+  return x;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+  x = row16_sum(x);
+  x += __shfl_xor(x, 16);
+  x += __shfl_xor(x, 32);
+  return x;
+}
+
+// block-wide sum for blockDim.x == 64 * NWAVES; result valid in every thread
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float x, float* smem /* >= NWAVES floats */) {
+  x = wave_sum(x);
+  if constexpr (NWAVES == 1) return x;
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem[wave] = x;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NWAVES; ++i) t += smem[i];
+  return t;
+}
+
+// element traits ----------------------------------------------------------------------------
+template <typename T> struct elt;
+template <> struct elt<float> {
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct elt<bf16_t> {
+  static __device__ __forceinline__ float to_f(bf16_t v) { return static_cast<float>(v); }
+  static __device__ __forceinline__ bf16_t from_f(float v) { return static_cast<bf16_t>(v); }
+};
+template <> struct elt<f16_t> {
+  static __device__ __forceinline__ float to_f(f16_t v) { return static_cast<float>(v); }
+  static __device__ __forceinline__ f16_t from_f(float v) { return static_cast<f16_t>(v); }
+};
+
+template <typename T, int N> struct vec_of { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T> struct vec_of<T, 1> { typedef T type; };
+
+template <typename T, int N>
+__device__ __forceinline__ typename vec_of<T, N>::type load_vec(const T* p) {
+  return *reinterpret_cast<const typename vec_of<T, N>::type*>(p);
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_vec(T* p, typename vec_of<T, N>::type v) {
+  *reinterpret_cast<typename vec_of<T, N>::type*>(p) = v;
+}
+template <typename T, int N>
+__device__ __forceinline__ T vget(const typename vec_of<T, N>::type& v, int i) {
+  if constexpr (N == 1) return v; else return v[i];
+}
+template <typename T, int N>
+__device__ __forceinline__ void vset(typename vec_of<T, N>::type& v, int i, T x) {
+  if constexpr (N == 1) v = x; else v[i] = x;
+}
+
+}  // namespace mojo

@@ -1,0 +1,358 @@
+// MojoPagedDecodeGQA — split-KV flash decoding for gfx950.
+//
+// Work decomposition
+//   grid = (chunks, B * Hkv); one 64-lane wave per (sequence, kv-head, chunk of the KV range).
+//   The G = Hq/Hkv query heads that share a kv-head are processed together, so every K/V byte is
+//   read from HBM exactly once (the reference's Triton kernel launches (B, Hq) and re-reads the
+//   cache G times: backends/ttx/kernels/ilu/flash_attention.py:818).
+//
+// Data layout in the wave
+//   A (page, head) slab of the cache is [page tokens][D] contiguous.  LPT = 16 lanes cover one token
+//   row with 16 B (8 elements) each, so one wave-wide load instruction moves 64/LPT = 4 consecutive
+//   tokens = up to 1 KiB fully coalesced.  A tile is 4 such loads of K and 4 of V (16 tokens);
+//   two tiles are kept in flight (register double buffer) — K/V go straight to VGPRs, there is no
+//   reuse to stage through LDS.
+//   lane = r * LPT + j :  r = token slot inside a load (0..3), j = 8-element slice of the head dim.
+//   Each lane row r runs its own online softmax over tokens {4i + r}; the 4 partial states are merged
+//   once at the end.  Scores: v_dot2c_f32_bf16 partial dots + a 4-step DPP butterfly inside the row.
+//
+// Numerics: fp32 scores/softmax/accumulators; the golden rounds scores and probabilities to the
+// storage dtype, so parity is by tolerance (atol = rtol = 2e-2 in the reference test).
+//
+// Algorithmic bytes per launch: sum_b len_b * Hkv * D * 2(K,V) * elt  +  2 * B * Hq * D * elt
+//                               + 4 * B * (max_blocks + 1).
+#include <math.h>
+
+#include "common.h"
+
+namespace mojo {
+
+constexpr int DEC_LPT = 16;               // lanes per token row
+constexpr int DEC_TPL = 64 / DEC_LPT;     // tokens per wave-wide load
+constexpr int DEC_LOADS = 4;              // loads per tile
+constexpr int DEC_TILE = DEC_TPL * DEC_LOADS;   // 16 tokens
+
+template <typename T> struct pack8;
+template <> struct pack8<bf16_t> {
+  typedef bf16x8 vec;
+  typedef bf16x2 pair;
+  static __device__ __forceinline__ float dot2(pair a, pair b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+  }
+};
+template <> struct pack8<f16_t> {
+  typedef f16x8 vec;
+  typedef f16x2 pair;
+  static __device__ __forceinline__ float dot2(pair a, pair b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+};
+
+struct DecodeArgs {
+  const void* q;
+  const void* kc;
+  const void* vc;
+  const int32_t* seq_lens;
+  const int32_t* tables;
+  void* out;
+  float* ws_acc;     // [B*Hkv][chunks][G][D] fp32, un-normalised
+  float* ws_ml;      // [B*Hkv][chunks][G][2]  (running max in log2 units, running sum)
+  int hq, hkv, dim, page, max_pages;
+  int64_t table_stride, c_blk, c_head, c_tok;
+  int chunk_tokens, n_chunks;
+  float scale_log2;
+  int abab;
+};
+
+template <typename T, int G>
+__global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
+  typedef typename pack8<T>::vec V8;
+  typedef typename pack8<T>::pair V2;
+  const int lane = threadIdx.x;
+  const int r = lane / DEC_LPT;
+  const int j = lane % DEC_LPT;
+  const int chunk = blockIdx.x;
+  const int b = blockIdx.y / a.hkv;
+  const int kvh = blockIdx.y % a.hkv;
+
+  const int seq_len = a.seq_lens[b];
+  const int tok_begin = chunk * a.chunk_tokens;
+  if (seq_len <= 0 || tok_begin >= seq_len) return;
+  const int tok_end = min(seq_len, tok_begin + a.chunk_tokens);
+  const bool dim_ok = j * 8 < a.dim;
+
+  // query slices for the G heads of this kv-head (AABB: h = kvh*G + g, ABAB: h = g*Hkv + kvh)
+  V8 qv[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+    V8 z = {};
+    qv[g] = dim_ok ? *reinterpret_cast<const V8*>(static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + j * 8) : z;
+  }
+
+  float m[G], l[G], acc[G][8];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    m[g] = -INFINITY;
+    l[g] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+  }
+
+  const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
+  const T* kbase = static_cast<const T*>(a.kc) + kvh * a.c_head + j * 8;
+  const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head + j * 8;
+
+  struct Tile { V8 k[DEC_LOADS]; V8 v[DEC_LOADS]; };
+
+  auto load_tile = [&](Tile& t, int t0) {
+#pragma unroll
+    for (int u = 0; u < DEC_LOADS; ++u) {
+      const int tu = t0 + u * DEC_TPL;                 // wave-uniform first token of this load
+      V8 z = {};
+      t.k[u] = z;
+      t.v[u] = z;
+      if (tu < tok_end) {
+        const int lp = tu / a.page;                    // TPL | page, so the 4 tokens share a page
+        const int phys = lp < a.max_pages ? table[lp] : -1;
+        if (phys >= 0 && dim_ok) {                     // phys < 0: K = V = 0 (reference `break`)
+          const int64_t off = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - lp * a.page + r) * a.c_tok;
+          t.k[u] = *reinterpret_cast<const V8*>(kbase + off);
+          t.v[u] = *reinterpret_cast<const V8*>(vbase + off);
+        }
+      }
+    }
+  };
+
+  auto process = [&](const Tile& t, int t0) {
+    float s[DEC_LOADS][G];
+#pragma unroll
+    for (int u = 0; u < DEC_LOADS; ++u) {
+      const bool valid = (t0 + u * DEC_TPL + r) < tok_end;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          V2 qa = {qv[g][2 * e], qv[g][2 * e + 1]};
+          V2 ka = {t.k[u][2 * e], t.k[u][2 * e + 1]};
+          d = pack8<T>::dot2(qa, ka, d);
+        }
+        d = row16_sum(d);
+        s[u][g] = valid ? d * a.scale_log2 : -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float mx = m[g];
+#pragma unroll
+      for (int u = 0; u < DEC_LOADS; ++u) mx = fmaxf(mx, s[u][g]);
+      const float ms = mx == -INFINITY ? 0.f : mx;       // row r may not have seen a valid token yet
+      const float alpha = exp2f(m[g] - ms);
+      m[g] = mx;
+      float p[DEC_LOADS];
+      float ps = 0.f;
+#pragma unroll
+      for (int u = 0; u < DEC_LOADS; ++u) {
+        p[u] = exp2f(s[u][g] - ms);
+        ps += p[u];
+      }
+      l[g] = l[g] * alpha + ps;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = acc[g][e] * alpha;
+#pragma unroll
+        for (int u = 0; u < DEC_LOADS; ++u) x = fmaf(p[u], static_cast<float>(t.v[u][e]), x);
+        acc[g][e] = x;
+      }
+    }
+  };
+
+  // register double buffer: tile A / tile B, no copies
+  Tile ta, tb;
+  load_tile(ta, tok_begin);
+  for (int t0 = tok_begin; t0 < tok_end; t0 += 2 * DEC_TILE) {
+    const bool has_b = t0 + DEC_TILE < tok_end;
+    if (has_b) load_tile(tb, t0 + DEC_TILE);
+    process(ta, t0);
+    if (has_b) {
+      if (t0 + 2 * DEC_TILE < tok_end) load_tile(ta, t0 + 2 * DEC_TILE);
+      process(tb, t0 + DEC_TILE);
+    }
+  }
+
+  // merge the DEC_TPL lane rows (lanes j, j+16, j+32, j+48 hold the same head-dim slice)
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float mx = m[g];
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float ms = mx == -INFINITY ? 0.f : mx;
+    const float w = exp2f(m[g] - ms);
+    float lw = l[g] * w;
+    lw += __shfl_xor(lw, 16);
+    lw += __shfl_xor(lw, 32);
+    l[g] = lw;
+    m[g] = mx;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = acc[g][e] * w;
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      acc[g][e] = x;
+    }
+  }
+
+  if (r != 0 || !dim_ok) return;
+  const int n_chunks_seq = (seq_len + a.chunk_tokens - 1) / a.chunk_tokens;
+  if (n_chunks_seq == 1) {
+    // single chunk: finish here, the merge kernel skips this row
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+      const float inv = 1.0f / l[g];
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = static_cast<T>(acc[g][e] * inv);
+      *reinterpret_cast<V8*>(static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + j * 8) = o;
+    }
+    return;
+  }
+  const int64_t slot = (static_cast<int64_t>(blockIdx.y) * a.n_chunks + chunk) * G;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    float* dst = a.ws_acc + (slot + g) * a.dim + j * 8;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
+    if (j == 0) {
+      a.ws_ml[(slot + g) * 2 + 0] = m[g];
+      a.ws_ml[(slot + g) * 2 + 1] = l[g];
+    }
+  }
+}
+
+// Merge the chunk partials of one (sequence, kv-head): grid = B*Hkv, block = G rows x (D/4 lanes... )
+template <typename T>
+__global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a, int G) {
+  const int b = blockIdx.x / a.hkv;
+  const int kvh = blockIdx.x % a.hkv;
+  const int seq_len = a.seq_lens[b];
+  const int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + a.chunk_tokens - 1) / a.chunk_tokens;
+  if (n_chunks_seq == 1) return;                       // written by the split kernel
+  const int per_head = a.dim;                          // one thread per output element
+  for (int idx = threadIdx.x; idx < G * per_head; idx += blockDim.x) {
+    const int g = idx / per_head, d = idx - g * per_head;
+    const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+    T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + d;
+    if (n_chunks_seq == 0) {                           // seq_len <= 0: the golden returns zeros
+      *dst = static_cast<T>(0.f);
+      continue;
+    }
+    const int64_t base = static_cast<int64_t>(blockIdx.x) * a.n_chunks * G;
+    float mx = -INFINITY;
+    for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, a.ws_ml[((base + static_cast<int64_t>(c) * G) + g) * 2]);
+    float num = 0.f, den = 0.f;
+    for (int c = 0; c < n_chunks_seq; ++c) {
+      const int64_t slot = base + static_cast<int64_t>(c) * G + g;
+      const float w = exp2f(a.ws_ml[slot * 2] - mx);
+      den = fmaf(w, a.ws_ml[slot * 2 + 1], den);
+      num = fmaf(w, a.ws_acc[slot * a.dim + d], num);
+    }
+    *dst = static_cast<T>(num / den);
+  }
+}
+
+static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len) {
+  // aim at ~4 waves per SIMD slot across the chip (256 CUs x 12 resident waves), never below 64 tokens
+  const int64_t units = batch * kv_heads;
+  const int64_t target_waves = 256 * 12 * 2;
+  int64_t chunks = ceil_div(target_waves, units > 0 ? units : 1);
+  if (chunks < 1) chunks = 1;
+  int64_t chunk = ceil_div(max_len > 0 ? max_len : 1, chunks);
+  if (chunk < 64) chunk = 64;
+  chunk = ceil_div(chunk, 2 * DEC_TILE) * (2 * DEC_TILE);
+  return static_cast<int>(chunk);
+}
+
+static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
+  const int64_t cap = page * max_pages;
+  return (hint > 0 && hint < cap) ? hint : cap;
+}
+
+template <typename T>
+static int launch_decode(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
+  dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv));
+  switch (G) {
+    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2>), grid, dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4>), grid, dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8>), grid, dim3(64), 0, s, a); break;
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
+  }
+  MOJO_CHECK_LAUNCH("paged_decode_gqa(split)");
+  hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv)), dim3(256), 0, s, a, G);
+  MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
+  return MOJO_OK;
+}
+
+}  // namespace mojo
+
+using namespace mojo;
+
+extern "C" int64_t mojo_hip_paged_decode_gqa_workspace_bytes(int64_t batch, int64_t q_heads, int64_t kv_heads,
+                                                             int64_t head_dim, int64_t block_size,
+                                                             int64_t max_blocks_per_seq, int64_t max_seq_len_hint) {
+  if (batch <= 0 || kv_heads <= 0 || q_heads <= 0) return 0;
+  const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
+  const int chunk = decode_chunk_tokens(batch, kv_heads, max_len);
+  const int64_t n_chunks = ceil_div(max_len > 0 ? max_len : 1, chunk);
+  const int64_t slots = batch * kv_heads * n_chunks * (q_heads / kv_heads);
+  return slots * (head_dim + 2) * static_cast<int64_t>(sizeof(float)) + 256;
+}
+
+extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cache, const void* value_cache,
+                                         const int32_t* total_seq_lens, const int32_t* block_tables, void* out,
+                                         void* workspace, int64_t workspace_bytes, int64_t batch, int64_t q_heads,
+                                         int64_t kv_heads, int64_t head_dim, int64_t block_size,
+                                         int64_t max_blocks_per_seq, int64_t block_table_stride,
+                                         int64_t cache_block_stride, int64_t cache_head_stride,
+                                         int64_t cache_token_stride, int64_t max_seq_len_hint, float softmax_scale,
+                                         int layout_abab, int dtype, mojo_stream_t stream) {
+  if (batch == 0) return MOJO_OK;
+  MOJO_REQUIRE(query && key_cache && value_cache && total_seq_lens && block_tables && out, MOJO_EINVAL,
+               "paged_decode_gqa: null pointer");
+  MOJO_REQUIRE(batch > 0 && q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0, MOJO_EINVAL,
+               "paged_decode_gqa: bad head counts Hq=%lld Hkv=%lld", (long long)q_heads, (long long)kv_heads);
+  MOJO_REQUIRE(dtype == MOJO_BF16 || dtype == MOJO_F16, MOJO_EUNSUPPORTED,
+               "paged_decode_gqa: dtype %d (bf16/fp16 only)", dtype);
+  MOJO_REQUIRE(head_dim % 8 == 0 && head_dim <= 8 * DEC_LPT, MOJO_EUNSUPPORTED,
+               "paged_decode_gqa: head_dim %lld (multiple of 8, <= %d)", (long long)head_dim, 8 * DEC_LPT);
+  MOJO_REQUIRE(block_size % DEC_TPL == 0, MOJO_EUNSUPPORTED, "paged_decode_gqa: block_size %lld must be a multiple of %d",
+               (long long)block_size, DEC_TPL);
+  MOJO_REQUIRE(cache_token_stride % 8 == 0 && cache_head_stride % 8 == 0 && cache_block_stride % 8 == 0 &&
+                   aligned_to(key_cache, 16) && aligned_to(value_cache, 16) && aligned_to(query, 16) &&
+                   aligned_to(out, 16),
+               MOJO_EUNSUPPORTED, "paged_decode_gqa: tensors must be 16-byte aligned with 16-byte row strides");
+  MOJO_REQUIRE(max_blocks_per_seq >= 0 && batch * kv_heads <= 65535, MOJO_EUNSUPPORTED,
+               "paged_decode_gqa: batch*kv_heads %lld exceeds the grid limit", (long long)(batch * kv_heads));
+
+  DecodeArgs a;
+  a.q = query; a.kc = key_cache; a.vc = value_cache; a.seq_lens = total_seq_lens; a.tables = block_tables; a.out = out;
+  a.hq = static_cast<int>(q_heads); a.hkv = static_cast<int>(kv_heads); a.dim = static_cast<int>(head_dim);
+  a.page = static_cast<int>(block_size); a.max_pages = static_cast<int>(max_blocks_per_seq);
+  a.table_stride = block_table_stride; a.c_blk = cache_block_stride; a.c_head = cache_head_stride;
+  a.c_tok = cache_token_stride;
+  const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
+  a.chunk_tokens = decode_chunk_tokens(batch, kv_heads, max_len);
+  a.n_chunks = static_cast<int>(ceil_div(max_len > 0 ? max_len : 1, a.chunk_tokens));
+  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.abab = layout_abab ? 1 : 0;
+  const int G = static_cast<int>(q_heads / kv_heads);
+  const int64_t slots = batch * kv_heads * a.n_chunks * G;
+  const int64_t need = slots * (head_dim + 2) * static_cast<int64_t>(sizeof(float));
+  MOJO_REQUIRE(workspace && workspace_bytes >= need, MOJO_EWORKSPACE,
+               "paged_decode_gqa: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);
+  MOJO_REQUIRE(aligned_to(workspace, 16), MOJO_EINVAL, "paged_decode_gqa: workspace must be 16-byte aligned");
+  a.ws_acc = static_cast<float*>(workspace);
+  a.ws_ml = a.ws_acc + slots * head_dim;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == MOJO_BF16 ? launch_decode<bf16_t>(a, batch, G, s) : launch_decode<f16_t>(a, batch, G, s);
+}

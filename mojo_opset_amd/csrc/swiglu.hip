@@ -1,0 +1,68 @@
+// MojoSwiGLU: out = silu(gate) * up, optional clamp.  Pure HBM streaming: 3 tensors, 16 B per lane.
+// Rounding mirrors the torch golden: for 16-bit types silu(gate) is rounded to the storage type
+// BEFORE the multiply (the golden runs two elementwise ops), for fp32 there is nothing to mirror.
+//
+// Algorithmic bytes per element: 3 x elt.
+#include "common.h"
+
+namespace mojo {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gate, const T* __restrict__ up,
+                                                     T* __restrict__ out, int64_t n_vec, float limit) {
+  typedef typename vec_of<T, VEC>::type V;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const V g = load_vec<T, VEC>(gate + i * VEC);
+    const V u = load_vec<T, VEC>(up + i * VEC);
+    V o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float gf = elt<T>::to_f(vget<T, VEC>(g, j));
+      float uf = elt<T>::to_f(vget<T, VEC>(u, j));
+      if (limit > 0.f) {
+        uf = fminf(fmaxf(uf, -limit), limit);
+        gf = fminf(gf, limit);
+      }
+      const float s = elt<T>::to_f(elt<T>::from_f(silu_f(gf)));   // round like the golden's F.silu
+      vset<T, VEC>(o, j, elt<T>::from_f(s * uf));
+    }
+    store_vec<T, VEC>(out + i * VEC, o);
+  }
+}
+
+template <typename T>
+static int launch_swiglu(const void* gate, const void* up, void* out, int64_t n, float limit, hipStream_t s) {
+  constexpr int WIDE = 16 / sizeof(T);
+  const bool wide = n % WIDE == 0 && aligned_to(gate, 16) && aligned_to(up, 16) && aligned_to(out, 16);
+  const int64_t n_vec = wide ? n / WIDE : n;
+  int64_t blocks = ceil_div(n_vec, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (wide)
+    hipLaunchKernelGGL((swiglu_kernel<T, WIDE>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+                       static_cast<const T*>(up), static_cast<T*>(out), n_vec, limit);
+  else
+    hipLaunchKernelGGL((swiglu_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+                       static_cast<const T*>(up), static_cast<T*>(out), n_vec, limit);
+  MOJO_CHECK_LAUNCH("swiglu");
+  return MOJO_OK;
+}
+
+}  // namespace mojo
+
+using namespace mojo;
+
+extern "C" int mojo_hip_swiglu(const void* gate, const void* up, void* out, int64_t n, int dtype, float swiglu_limit,
+                               mojo_stream_t stream) {
+  if (n == 0) return MOJO_OK;
+  MOJO_REQUIRE(gate && up && out && n > 0, MOJO_EINVAL, "swiglu: null pointer or negative size");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case MOJO_F32: return launch_swiglu<float>(gate, up, out, n, swiglu_limit, s);
+    case MOJO_F16: return launch_swiglu<f16_t>(gate, up, out, n, swiglu_limit, s);
+    case MOJO_BF16: return launch_swiglu<bf16_t>(gate, up, out, n, swiglu_limit, s);
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "swiglu: dtype %d not supported", dtype);
+  }
+}

@@ -1,0 +1,491 @@
+"""Torch-native golden backend ("torch") — the parity oracle.  See the package docstring.
+
+Each class cites the reference lines it restates.  The rounding points are the reference's:
+they are what the fixtures in tests/golden pin bit-for-bit.
+"""
+import math
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.distributed._functional_collectives as fc
+import torch.nn.functional as F
+
+from mojo_opset_amd.core.operators import activation as _act
+from mojo_opset_amd.core.operators import attention as _attn
+from mojo_opset_amd.core.operators import compute_with_comm as _cc
+from mojo_opset_amd.core.operators import gemm as _gemm_api
+from mojo_opset_amd.core.operators import kv_cache as _kv
+from mojo_opset_amd.core.operators import mla as _mla
+from mojo_opset_amd.core.operators import normalization as _norm
+from mojo_opset_amd.core.operators import position_embedding as _pe
+
+_CPU = ["rocm", "cpu"]
+
+__all__ = [
+    "TorchPagedDecodeGQA", "TorchPagedPrefillGQA", "TorchPagedDecodeMLA", "TorchPagedPrefillMLA",
+    "TorchRMSNorm", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
+    "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
+    "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
+    "gather_pages", "quant_gemm_formula",
+]
+
+
+# ----------------------------------------------------------------------------------------------
+# paged-cache helpers
+# ----------------------------------------------------------------------------------------------
+def gather_pages(cache: torch.Tensor, table_row: torch.Tensor, length: int) -> torch.Tensor:
+    """``[length, heads, D]`` rows of one sequence pulled out of ``cache [N, heads, page, D]``.
+
+    Pages are walked in logical order; the walk stops at the first negative id and the remaining
+    rows stay zero — the behaviour of the reference's ``break`` inside a zero-initialised buffer
+    (`core/operators/attention.py:190-207`, :405-419).
+    """
+    page = cache.shape[2]
+    heads, dim = cache.shape[1], cache.shape[3]
+    out = torch.zeros(length, heads, dim, dtype=cache.dtype, device=cache.device)
+    n_pages = (length + page - 1) // page
+    ids = table_row[:n_pages].to(torch.int64)
+    bad = (ids < 0).nonzero()
+    if bad.numel():
+        n_pages = int(bad[0])
+        ids = ids[:n_pages]
+    if n_pages == 0:
+        return out
+    rows = cache[ids].permute(0, 2, 1, 3).reshape(n_pages * page, heads, dim)   # token-major
+    take = min(length, n_pages * page)
+    out[:take] = rows[:take]
+    return out
+
+
+def _expand_kv_heads(x: torch.Tensor, group: int, layout: str) -> torch.Tensor:
+    """``[S, Hkv, D] -> [S, Hq, D]``: AABB = repeat_interleave, ABAB = tile (:209-214)."""
+    if group == 1:
+        return x
+    if layout == "AABB":
+        return x.repeat_interleave(group, dim=1)
+    return x.repeat((1, group, 1))
+
+
+def _first_page_must_exist(table_row: torch.Tensor, what: str) -> None:
+    if int(table_row[0]) < 0:
+        raise ValueError(f"Paged {what} requires a valid block table for rows with kv lens > 0.")
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+class TorchPagedDecodeGQA(_attn.MojoPagedDecodeGQA):
+    """`core/operators/attention.py:141-232`: scores are a q-dtype einsum scaled in q dtype,
+    softmax in fp32 rounded to q dtype, PV a q-dtype einsum."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, query, key_cache, value_cache, total_seq_lens, block_tables,
+                softmax_scale: Optional[float] = None, mask: Optional[torch.Tensor] = None, *,
+                max_total_seq_len: Optional[int] = None):
+        _attn.assert_paged_decode_contract(block_tables, total_seq_lens)
+        batch, hq, dim = query.shape
+        hkv = key_cache.shape[1]
+        group = hq // hkv
+        scale = 1.0 / math.sqrt(dim) if softmax_scale is None else softmax_scale
+        out = torch.zeros(batch, hq, dim, dtype=query.dtype, device=query.device)
+        lens = total_seq_lens.tolist()
+        for b, n in enumerate(lens):
+            if n <= 0:
+                continue
+            _first_page_must_exist(block_tables[b], "decode")
+            k = _expand_kv_heads(gather_pages(key_cache, block_tables[b], n), group, self.gqa_layout)
+            v = _expand_kv_heads(gather_pages(value_cache, block_tables[b], n), group, self.gqa_layout)
+            scores = torch.einsum("hd,khd->hk", query[b], k) * scale
+            if not self.is_causal and mask is not None:
+                m = mask if mask.dim() == 2 else mask[b]
+                scores.masked_fill_(m[n, :n].unsqueeze(0), -torch.inf)
+            probs = torch.softmax(scores, dim=-1, dtype=torch.float32).to(query.dtype)
+            out[b] = torch.einsum("hk,khd->hd", probs, v)
+        return out
+
+
+class TorchPagedPrefillGQA(_attn.MojoPagedPrefillGQA):
+    """`core/operators/attention.py:345-451`: as decode but the q-dtype score einsum is upcast
+    to fp32 *before* scaling, with the causal band ``tril(kv_len - q_len)``."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, query, key_cache, value_cache, cu_q_lens, block_tables,
+                softmax_scale: Optional[float] = None, cu_total_seq_lens: Optional[torch.Tensor] = None,
+                mask: Optional[torch.Tensor] = None, max_q_len: Optional[int] = None,
+                max_total_seq_len: Optional[int] = None):
+        _attn.assert_paged_prefill_contract(cu_q_lens, block_tables, cu_total_seq_lens)
+        tokens, hq, dim = query.shape
+        hkv = key_cache.shape[1]
+        group = hq // hkv
+        scale = 1.0 / math.sqrt(dim) if softmax_scale is None else softmax_scale
+        out = torch.zeros(tokens, hq, dim, dtype=query.dtype, device=query.device)
+        q_off = cu_q_lens.tolist()
+        kv_off = q_off if cu_total_seq_lens is None else cu_total_seq_lens.tolist()
+        for b in range(len(q_off) - 1):
+            lo, hi = q_off[b], q_off[b + 1]
+            q_len, kv_len = hi - lo, kv_off[b + 1] - kv_off[b]
+            if q_len == 0 or kv_len <= 0:
+                continue
+            _first_page_must_exist(block_tables[b], "prefill")
+            k = _expand_kv_heads(gather_pages(key_cache, block_tables[b], kv_len), group, self.gqa_layout)
+            v = _expand_kv_heads(gather_pages(value_cache, block_tables[b], kv_len), group, self.gqa_layout)
+            scores = torch.einsum("thd,khd->thk", query[lo:hi], k).float() * scale
+            if self.is_causal:
+                band = torch.ones(q_len, kv_len, dtype=torch.bool, device=query.device).tril(kv_len - q_len)
+                scores.masked_fill_(~band.unsqueeze(1), -torch.inf)
+            elif mask is not None:
+                m = mask if mask.dim() == 2 else mask[b]
+                scores.masked_fill_(~m[kv_len - q_len: kv_len, :kv_len].unsqueeze(1), -torch.inf)
+            probs = torch.softmax(scores, dim=-1, dtype=torch.float32).to(query.dtype)
+            out[lo:hi] = torch.einsum("thk,khd->thd", probs, v)
+        return out
+
+
+def _sink_softmax(scores: torch.Tensor, out_dtype, sink: Optional[torch.Tensor]) -> torch.Tensor:
+    """fp32 softmax with an optional per-head sink logit that takes probability mass and is then
+    dropped; NaN rows (all -inf) become zeros (`experimental/operators/attention.py:20-42`)."""
+    if sink is None:
+        p = torch.softmax(scores, dim=-1, dtype=torch.float32)
+        return torch.nan_to_num(p, nan=0.0).to(out_dtype)
+    if scores.dim() < 2:
+        raise ValueError(f"scores must have at least 2 dimensions, but got {scores.dim()}")
+    if sink.dim() != 1 or sink.numel() != scores.shape[-2]:
+        raise ValueError(
+            f"attn_sink must be 1D with length equal to num_heads {scores.shape[-2]}, "
+            f"but got shape {tuple(sink.shape)}"
+        )
+    shape = [1] * scores.dim()
+    shape[-2] = sink.numel()
+    extra = sink.float().view(shape).expand(*scores.shape[:-1], 1)
+    p = torch.softmax(torch.cat([scores.float(), extra], dim=-1), dim=-1, dtype=torch.float32)[..., :-1]
+    return torch.nan_to_num(p, nan=0.0).to(out_dtype)
+
+
+class _TorchMLAMixin:
+    def _decompress(self, c_kv: torch.Tensor, k_pe: torch.Tensor):
+        """``kv = c_kv @ kv_b_proj.T`` split into ``k_nope | v``; ``k = cat(k_nope, k_pe)`` (:210-213)."""
+        n = c_kv.shape[0]
+        kv = (c_kv @ self.kv_b_proj.T).view(n, self.num_heads, self.qk_nope_head_dim + self.v_head_dim)
+        k_nope, v = kv[..., : self.qk_nope_head_dim], kv[..., self.qk_nope_head_dim:]
+        k = torch.cat([k_nope, k_pe.unsqueeze(1).expand(-1, self.num_heads, -1)], dim=-1)
+        return k, v
+
+
+class TorchPagedDecodeMLA(_TorchMLAMixin, _mla.MojoPagedDecodeMLA):
+    """`experimental/operators/attention.py:159-220`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables,
+                softmax_scale: Optional[float] = None):
+        _attn.assert_paged_decode_contract(block_tables, total_seq_lens)
+        batch, heads, _ = query.shape
+        page = compressed_kv_cache.shape[2]
+        scale = 1.0 / math.sqrt(self.qk_head_dim) if softmax_scale is None else softmax_scale
+        out = torch.zeros(batch, heads, self.v_head_dim, dtype=query.dtype, device=query.device)
+        for b, n in enumerate(total_seq_lens.tolist()):
+            if n <= 0:
+                continue
+            _first_page_must_exist(block_tables[b], "decode")
+            c_kv, k_pe = _mla_unpage(compressed_kv_cache, k_pe_cache, block_tables[b], n, page)
+            if c_kv is None:
+                continue
+            k, v = self._decompress(c_kv, k_pe)
+            scores = torch.einsum("hd,shd->hs", query[b], k) * scale
+            probs = _sink_softmax(scores, query.dtype, getattr(self, "attn_sink", None))
+            out[b] = torch.einsum("hs,shd->hd", probs, v)
+        return out
+
+
+def _mla_unpage(c_cache, pe_cache, table_row, length, page):
+    """Concatenate the valid prefix of pages; unlike GQA the tail after a negative id is *dropped*,
+    not zero-filled (`experimental/operators/attention.py:196-209`, :355-369)."""
+    n_pages = (length + page - 1) // page
+    ids = table_row[:n_pages].tolist()
+    c_parts, pe_parts = [], []
+    for j, pid in enumerate(ids):
+        if pid < 0:
+            break
+        take = min(page, length - j * page)
+        c_parts.append(c_cache[pid, 0, :take])
+        pe_parts.append(pe_cache[pid, 0, :take])
+    if not c_parts:
+        return None, None
+    return torch.cat(c_parts, dim=0), torch.cat(pe_parts, dim=0)
+
+
+class TorchPagedPrefillMLA(_TorchMLAMixin, _mla.MojoPagedPrefillMLA):
+    """`experimental/operators/attention.py:371-439` (scores upcast to fp32 before scaling :425)."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables,
+                softmax_scale: Optional[float] = None, cu_total_seq_lens: Optional[torch.Tensor] = None):
+        _attn.assert_paged_prefill_contract(cu_q_lens, block_tables, cu_total_seq_lens)
+        tokens, heads, _ = query.shape
+        page = compressed_kv_cache.shape[2]
+        scale = 1.0 / math.sqrt(self.qk_head_dim) if softmax_scale is None else softmax_scale
+        out = torch.zeros(tokens, heads, self.v_head_dim, dtype=query.dtype, device=query.device)
+        q_off = cu_q_lens.tolist()
+        kv_off = q_off if cu_total_seq_lens is None else cu_total_seq_lens.tolist()
+        for b in range(len(q_off) - 1):
+            lo, hi = q_off[b], q_off[b + 1]
+            q_len, kv_len = hi - lo, kv_off[b + 1] - kv_off[b]
+            if q_len == 0 or kv_len <= 0:
+                continue
+            _first_page_must_exist(block_tables[b], "prefill")
+            c_kv, k_pe = _mla_unpage(compressed_kv_cache, k_pe_cache, block_tables[b], kv_len, page)
+            if c_kv is None:
+                continue
+            # NB the reference views the decompressed kv with kv_len rows, so a truncated page walk
+            # would raise there; only complete tables are meaningful (and tested).
+            k, v = self._decompress(c_kv, k_pe)
+            scores = torch.einsum("thd,shd->ths", query[lo:hi], k).float() * scale
+            if self.is_causal:
+                band = torch.ones(q_len, kv_len, dtype=torch.bool, device=query.device).tril(kv_len - q_len)
+                scores.masked_fill_(~band.unsqueeze(1), float("-inf"))
+            probs = _sink_softmax(scores, query.dtype, getattr(self, "attn_sink", None))
+            out[lo:hi] = torch.einsum("ths,shd->thd", probs, v)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------
+# norm / activation / rope
+# ----------------------------------------------------------------------------------------------
+class TorchRMSNorm(_norm.MojoRMSNorm):
+    """`core/operators/normalization.py:91-111`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_state):
+        return F.rms_norm(hidden_state, [hidden_state.shape[-1]], weight=self.weight, eps=self.variance_epsilon)
+
+
+class TorchResidualAddRMSNorm(_norm.MojoResidualAddRMSNorm):
+    """`core/operators/normalization.py:340-359`: the sum is rounded to the input dtype, then
+    `F.rms_norm` (fp32 math, one final rounding)."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_state, residual):
+        summed = hidden_state + residual
+        normed = F.rms_norm(summed, (summed.size(-1),), weight=self.weight, eps=self.variance_epsilon)
+        return (normed, summed) if self.norm_pos == "pre" else (normed, normed)
+
+
+class TorchSwiGLU(_act.MojoSwiGLU):
+    """`core/operators/activation.py:43-63`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, gate_out, up_out):
+        lim = self.swiglu_limit
+        if lim > 0:
+            up_out = up_out.clamp(min=-lim, max=lim)
+            gate_out = gate_out.clamp(max=lim)
+        return F.silu(gate_out) * up_out
+
+
+class TorchRotaryEmbedding(_pe.MojoRotaryEmbedding):
+    """`core/operators/position_embedding.py:44-95`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, x, cu_q_lens=None, total_seq_lens=None, position_ids=None):
+        self.check_index_contract(x, cu_q_lens, total_seq_lens, position_ids)
+        if cu_q_lens is not None:
+            position_ids = torch.full((x.shape[0],), -1, device=x.device, dtype=torch.int32)
+            off = cu_q_lens.tolist()
+            tot = None if total_seq_lens is None else total_seq_lens.tolist()
+            for b in range(len(off) - 1):
+                n = off[b + 1] - off[b]
+                start = 0 if tot is None else tot[b] - n
+                position_ids[off[b]: off[b + 1]] = torch.arange(start, start + n, dtype=torch.int32, device=x.device)
+        elif position_ids is None:
+            position_ids = torch.arange(x.shape[1], device=x.device, dtype=torch.int32)
+
+        if self.init_max_length is None:
+            freqs = position_ids[..., None] * self.inv_freq[None, :]
+            emb = torch.cat((freqs, freqs), dim=-1)
+            return emb.cos() * self.attention_scaling, emb.sin() * self.attention_scaling
+        return self.cos[position_ids], self.sin[position_ids]
+
+
+class TorchApplyRoPE(_pe.MojoApplyRoPE):
+    """`core/operators/position_embedding.py:109-175`: fp32 promote, one rounding per output."""
+
+    supported_platforms_list = _CPU
+
+    @staticmethod
+    def _rot(x, cos, sin):
+        d = cos.shape[-1]
+        keep, r = x[..., : x.shape[-1] - d], x[..., x.shape[-1] - d:]
+        half = d // 2
+        turned = torch.cat((-r[..., half:], r[..., :half]), dim=-1)
+        r = (r * cos + turned * sin).to(x.dtype)
+        return torch.cat([keep, r], dim=-1) if keep.shape[-1] > 0 else r
+
+    def forward(self, q, k, cos, sin, head_first: bool = True):
+        self.check_shape_contract(q, k, cos, sin)
+        axis = -3 if head_first else -2
+        cos, sin = cos.unsqueeze(axis), sin.unsqueeze(axis)
+        return self._rot(q, cos, sin), self._rot(k, cos, sin)
+
+
+# ----------------------------------------------------------------------------------------------
+# kv cache store
+# ----------------------------------------------------------------------------------------------
+class TorchStorePagedKVCache(_kv.MojoStorePagedKVCache):
+    """`core/operators/kv_cache.py:118-171`: per plan row, a token-major -> head-major copy."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, key_states, value_states, key_cache, value_cache, block_table=None, cu_q_lens=None,
+                context_kv_lens=None, *, chunk_metadata=None):
+        self.check_call_contract(key_states, value_states, block_table, cu_q_lens, context_kv_lens, chunk_metadata)
+        if chunk_metadata is None:
+            chunk_metadata = _kv.build_paged_kv_chunk_metadata(block_table, cu_q_lens, context_kv_lens,
+                                                               key_cache.shape[2])
+        _kv.assert_paged_kv_store_contract(chunk_metadata)
+        for src, blk, off, n in chunk_metadata.tolist():
+            key_cache[blk, :, off: off + n, :] = key_states[src: src + n].transpose(0, 1)
+            value_cache[blk, :, off: off + n, :] = value_states[src: src + n].transpose(0, 1)
+        return key_cache, value_cache
+
+
+# ----------------------------------------------------------------------------------------------
+# gemm
+# ----------------------------------------------------------------------------------------------
+class TorchGroupGemm(_gemm_api.MojoGroupGemm):
+    """`core/operators/gemm.py:69-117`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input, group_list):
+        counts = group_list.to("cpu")
+        self.check_call_contract(input, counts)
+        w = self.weight.transpose(1, 2).contiguous() if self.trans_weight else self.weight
+        pieces, start = [], 0
+        for g, rows in enumerate(counts.tolist()):
+            pieces.append(input[start: start + rows, :] @ w[g])
+            start += rows
+        return torch.cat(pieces, dim=0)
+
+
+def quant_gemm_formula(x_q: torch.Tensor, w_kn: torch.Tensor, input_scale, weight_scale, out_dtype):
+    """``(x_q @ w) * s_in[m] * s_w[n]`` with the products accumulated in float64 — exact for int8
+    (|sum| < 2**53) and the definition used for the fp8 extension (parity unpinned)."""
+    acc = x_q.to(torch.float64) @ w_kn.to(torch.float64)
+    s_in = input_scale.float().reshape(-1, 1)
+    s_w = weight_scale.float().reshape(1, -1)
+    return (acc.float() * s_in * s_w).to(out_dtype)
+
+
+class TorchQuantGemm(_gemm_api.MojoQuantGemm):
+    """`core/operators/gemm.py:186-223`: int32 products summed in fp32, fp32 scaling, one cast.
+
+    The reference materialises the ``[M,N,K]`` product tensor (:213); here the same fp32 sum is
+    formed blockwise over N so that real shapes fit in memory (summation order along K unchanged).
+    fp8 inputs (extension, parity unpinned) are upcast to fp32 and multiplied with fp32 accumulate.
+    """
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input, input_scale):
+        self.check_call_contract(input, input_scale)
+        w_nk = self.weight if self.trans_weight else self.weight.mT           # [N, K] view
+        if input.dtype == torch.int8:
+            a = input.int().unsqueeze(-2)                                      # [M,1,K]
+            cols = []
+            step = max(1, (1 << 26) // max(1, input.shape[0] * input.shape[1]))
+            for n0 in range(0, w_nk.shape[0], step):
+                cols.append(torch.mul(a, w_nk[n0: n0 + step].int()).float().sum(dim=-1))
+            acc = torch.cat(cols, dim=-1)
+        else:
+            acc = input.float() @ w_nk.float().mT
+        s_in = input_scale.unsqueeze(-1) if input_scale.dim() == 1 else input_scale
+        out = acc * s_in.float() * self.weight_scale.unsqueeze(0).float()
+        return out.to(self.output_dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# gemm + collective
+# ----------------------------------------------------------------------------------------------
+def _local_gemm(x, weight, bias, trans_weight):
+    """`core/operators/compute_with_comm.py:12-24`."""
+    if trans_weight:
+        y = x @ weight
+        return y if bias is None else y + bias
+    return F.linear(x, weight, bias)
+
+
+class TorchGemmAllReduce(_cc.MojoGemmAllReduce):
+    """:96-111 — bias joins every rank's partial before the sum."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input):
+        y = _local_gemm(input, self.weight, self.bias, self.trans_weight)
+        if _cc.is_dist_initialized():
+            y = fc.all_reduce(y, reduceOp="sum", group=self._group())
+        return y
+
+
+class TorchAllGatherGemm(_cc.MojoAllGatherGemm):
+    """:160-176."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input):
+        if _cc.is_dist_initialized():
+            input = fc.all_gather_tensor(input, gather_dim=self.gather_dim, group=self._group())
+        return _local_gemm(input, self.weight, self.bias, self.trans_weight)
+
+
+class TorchGemmAll2All(_cc.MojoGemmAll2All):
+    """:234-253.  `dist.all_to_all` is not implemented by gloo; on such a backend the exchange is
+    emulated with an all_gather of every rank's chunk list (same result, more traffic)."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input):
+        y = _local_gemm(input, self.weight, self.bias, self.trans_weight)
+        if not _cc.is_dist_initialized():
+            return y
+        group = self._group()
+        ws, rank = dist.get_world_size(group), dist.get_rank(group)
+        send = [c.contiguous() for c in y.chunk(ws, dim=self.scatter_dim)]
+        try:
+            recv: List[torch.Tensor] = [torch.empty_like(c) for c in send]
+            dist.all_to_all(recv, send, group=group)
+        except RuntimeError:
+            stacked = torch.stack(send)                                  # [ws, ...]
+            everyone = [torch.empty_like(stacked) for _ in range(ws)]
+            dist.all_gather(everyone, stacked, group=group)
+            recv = [everyone[src][rank] for src in range(ws)]
+        return torch.cat(recv, dim=self.gather_dim)
+
+
+class TorchGemmReduceScatter(_cc.MojoGemmReduceScatter):
+    """:316-332.  gloo lacks reduce_scatter in some builds; fall back to all_reduce + slice."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input):
+        y = _local_gemm(input, self.weight, self.bias, self.trans_weight)
+        if not _cc.is_dist_initialized():
+            return y
+        group = self._group()
+        ws, rank = dist.get_world_size(group), dist.get_rank(group)
+        chunks = [c.contiguous() for c in y.chunk(ws, dim=self.scatter_dim)]
+        mine = torch.empty_like(chunks[rank])
+        try:
+            dist.reduce_scatter(mine, chunks, op=dist.ReduceOp.SUM, group=group)
+        except RuntimeError:
+            total = y.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+            mine = total.chunk(ws, dim=self.scatter_dim)[rank].contiguous()
+        return mine

@@ -1,0 +1,74 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    return torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)["cases"]
+
+
+def to_device(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.to(device)
+    if isinstance(x, (list, tuple)):
+        return type(x)(to_device(v, device) for v in x)
+    if isinstance(x, dict):
+        return {k: to_device(v, device) for k, v in x.items()}
+    return x
+
+
+def clone_tree(x):
+    if isinstance(x, torch.Tensor):
+        return x.clone()
+    if isinstance(x, (list, tuple)):
+        return type(x)(clone_tree(v) for v in x)
+    if isinstance(x, dict):
+        return {k: clone_tree(v) for k, v in x.items()}
+    return x
+
+
+def build_op(cls, case, device="cpu"):
+    """Instantiate ``cls`` the way the fixture generator did and load its recorded state."""
+    ctor = case["ctor"]
+    kwargs = dict(ctor.get("kwargs", {}))
+    args = to_device(clone_tree(ctor.get("args", ())), device)
+    op = cls(*args, **kwargs)
+    if case.get("cast") is not None:
+        op = op.to(case["cast"])
+    op = op.to(device)
+    with torch.no_grad():
+        for k, v in case["state"].items():
+            getattr(op, k).copy_(v.to(device))
+    return op
+
+
+def bit_equal(a, b):
+    if isinstance(a, (tuple, list)):
+        return len(a) == len(b) and all(bit_equal(x, y) for x, y in zip(a, b))
+    a, b = a.detach().cpu(), b.detach().cpu()
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    if a.is_floating_point():
+        return torch.equal(torch.nan_to_num(a.float(), nan=12345.0), torch.nan_to_num(b.float(), nan=12345.0))
+    return torch.equal(a, b)

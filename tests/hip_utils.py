@@ -1,0 +1,49 @@
+"""Helpers for the `-m gpu` parity tests: run a HIP<Op> through the C ABI on cuda:0 and compare with
+the oracle (CPU) or with the committed reference vectors."""
+import torch
+
+import mojo_opset_amd as mo
+import oracle  # noqa: F401
+from conftest import build_op, clone_tree, to_device
+
+DEV = "cuda"
+
+
+def hip_cls(op_name):
+    return getattr(mo, op_name).get_backend_impl("hip", strict=True)
+
+
+def torch_cls(op_name):
+    return getattr(mo, op_name).get_backend_impl("torch", strict=True)
+
+
+def run_hip_case(case):
+    op = build_op(hip_cls(case["op"]), case, device=DEV)
+    args = to_device(clone_tree(case["args"]), DEV)
+    kwargs = to_device(clone_tree(case["kwargs"]), DEV)
+    out = op.forward(*args, **kwargs)
+    torch.cuda.synchronize()
+    return out
+
+
+def to_cpu(x):
+    if isinstance(x, (tuple, list)):
+        return type(x)(to_cpu(v) for v in x)
+    return x.detach().cpu()
+
+
+def assert_close_tree(got, want, atol, rtol):
+    if isinstance(want, (tuple, list)):
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert_close_tree(g, w, atol, rtol)
+        return
+    assert got.dtype == want.dtype and got.shape == want.shape, (got.dtype, want.dtype, got.shape, want.shape)
+    torch.testing.assert_close(got.float(), want.float(), atol=atol, rtol=rtol)
+
+
+def max_ulp_bf16ish(got, want):
+    """Largest difference in units of the storage type's last place (16-bit float types)."""
+    gi = got.view(torch.int16).int()
+    wi = want.view(torch.int16).int()
+    return int((gi - wi).abs().max()) if got.numel() else 0

@@ -1,0 +1,127 @@
+"""GPU parity of MojoPagedDecodeGQA through the C ABI.
+
+Tolerance: atol = rtol = 2e-2, the reference's own bound for this op
+(mojo_opset/tests/accuracy/operators/test_attention.py:137-138)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+
+pytestmark = pytest.mark.gpu
+ATOL = RTOL = 2e-2
+
+
+def make_decode_inputs(batch, hq, hkv, d, max_len, page, dtype=torch.bfloat16, seed=0, lens=None):
+    """Same construction as the reference's generator (test_attention.py:33-83): random lengths,
+    pools with 10 spare pages, a shuffled table padded with -1."""
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(batch, hq, d, generator=g).to(dtype)
+    if lens is None:
+        if max_len > 0:
+            lens = torch.randint(0, max_len, (batch,), generator=g, dtype=torch.int32).clamp(min=1)
+        else:
+            lens = torch.randperm(batch, generator=g, dtype=torch.int32)
+    else:
+        lens = torch.tensor(lens, dtype=torch.int32)
+    need = (lens + page - 1) // page
+    width = max(int(need.max()), 1)
+    total = max(int(need.sum()), 1) + 10
+    k = torch.randn(total, hkv, page, d, generator=g).to(dtype)
+    v = torch.randn(total, hkv, page, d, generator=g).to(dtype)
+    table = torch.full((batch, width), -1, dtype=torch.int32)
+    free = torch.randperm(total, generator=g, dtype=torch.int32)
+    at = 0
+    for b in range(batch):
+        n = int(need[b])
+        table[b, :n] = free[at: at + n]
+        at += n
+    return q, k, v, lens, table
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"decode-{i}") for i, c in enumerate(load_golden("paged_decode_gqa"))])
+def test_decode_vectors(case):
+    assert_close_tree(to_cpu(run_hip_case(case)), case["out"], ATOL, RTOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    (8, 16, 4, 128, 1024, 32), (8, 16, 4, 96, 1024, 128), (8, 8, 1, 128, 8192, 1024),
+    (8, 8, 1, 128, 2048, 1024), (8, 8, 1, 128, 0, 1024),
+    (64, 32, 8, 128, 1024, 16),                     # BASELINE shape at a length the CPU oracle handles
+], ids=["M_BF16", "M_BF16_PADDIM", "M_BF16_LONG", "M_BF16_BIGPAGE", "M_BF16_PADSEQ", "LLAMA3_8B_ctx1k"])
+@pytest.mark.parametrize("layout", ["ABAB", "AABB"])
+def test_decode_reference_space(cfg, layout):
+    batch, hq, hkv, d, max_len, page = cfg
+    q, k, v, lens, table = make_decode_inputs(batch, hq, hkv, d, max_len, page, seed=hash(cfg) % 1000)
+    op = hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    ref = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    dev = [t.to(DEV) for t in (q, k, v, lens, table)]
+    op.forward_diff_with(ref, *dev, softmax_scale=1.0 / math.sqrt(d), max_total_seq_len=int(lens.max()),
+                         atol=ATOL, rtol=RTOL, ref_device="cpu")
+    # without the host hint the split count comes from the table width: same numbers
+    a = op(*dev)
+    b = op(*dev, max_total_seq_len=int(lens.max()))
+    torch.testing.assert_close(a.float(), b.float(), atol=2e-3, rtol=2e-3)
+
+
+def test_decode_zero_length_rows_are_zero_and_fp16():
+    q, k, v, lens, table = make_decode_inputs(6, 8, 2, 128, 0, 16, dtype=torch.float16, lens=[0, 5, 0, 300, 1, 0])
+    op = hip_cls("MojoPagedDecodeGQA")()
+    out = op(*[t.to(DEV) for t in (q, k, v, lens, table)])
+    assert torch.count_nonzero(out[[0, 2, 5]]) == 0
+    want = torch_cls("MojoPagedDecodeGQA")()(q, k, v, lens, table)
+    assert_close_tree(to_cpu(out), want, ATOL, RTOL)
+
+
+def test_decode_contract_errors():
+    q, k, v, lens, table = [t.to(DEV) for t in make_decode_inputs(2, 8, 2, 128, 64, 16)]
+    op = hip_cls("MojoPagedDecodeGQA")()
+    with pytest.raises(AssertionError):
+        op(q, k, v, lens.long(), table)
+    with pytest.raises(AssertionError):
+        op(q, k, v, lens, table.long())
+    with pytest.raises(NotImplementedError):
+        hip_cls("MojoPagedDecodeGQA")(is_causal=False)(q, k, v, lens, table, mask=torch.ones(8, 8, dtype=torch.bool, device=DEV))
+    with pytest.raises(ValueError):
+        hip_cls("MojoPagedDecodeGQA")(gqa_layout="BBAA")
+
+
+def test_decode_invalid_first_page_raises_when_validation_is_on(monkeypatch):
+    q, k, v, lens, table = [t.to(DEV) for t in make_decode_inputs(2, 8, 2, 128, 64, 16)]
+    table[1, 0] = -1
+    monkeypatch.setenv("MOJO_HIP_VALIDATE", "1")
+    with pytest.raises(ValueError):
+        hip_cls("MojoPagedDecodeGQA")()(q, k, v, lens, table)
+
+
+def test_decode_full_size_properties():
+    """BASELINE config 2 at full size (B=64, 32q/8kv, D=128, page=16, ctx=4096): size-independent
+    properties + the oracle on a sample of sequences."""
+    B, hq, hkv, d, page, ctx = 64, 32, 8, 128, 16, 4096
+    g = torch.Generator().manual_seed(20260716)
+    lens = torch.randint(ctx // 2, ctx + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = ctx
+    q, k, v, lens, table = make_decode_inputs(B, hq, hkv, d, 0, page, lens=lens.tolist(), seed=7)
+    dev = [t.to(DEV) for t in (q, k, v, lens, table)]
+    op = hip_cls("MojoPagedDecodeGQA")()
+    out = op(*dev, max_total_seq_len=ctx)
+    assert torch.isfinite(out.float()).all()
+    # (1) page placement must not matter: relabel the physical pages, permute the pools accordingly
+    perm = torch.randperm(k.shape[0], generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel())
+    k2, v2 = k[perm], v[perm]                                   # new page p holds old page perm[p]
+    table2 = torch.where(table >= 0, inv[table.clamp(min=0).long()].to(torch.int32), table)
+    out2 = op(q.to(DEV), k2.to(DEV), v2.to(DEV), dev[3], table2.to(DEV), max_total_seq_len=ctx)
+    assert torch.equal(out, out2)
+    # (2) softmax weights are a convex combination: constant V rows come back unchanged
+    vconst = torch.full_like(v, 0.5)
+    outc = op(dev[0], dev[1], vconst.to(DEV), dev[3], dev[4], max_total_seq_len=ctx)
+    torch.testing.assert_close(outc.float(), torch.full_like(outc, 0.5).float(), atol=4e-3, rtol=0)
+    # (3) oracle on three whole sequences (longest, a ragged one, the last)
+    ref = torch_cls("MojoPagedDecodeGQA")()
+    for b in (0, 17, B - 1):
+        want = ref(q[b: b + 1], k, v, lens[b: b + 1], table[b: b + 1])
+        assert_close_tree(to_cpu(out[b: b + 1]), want, ATOL, RTOL)
