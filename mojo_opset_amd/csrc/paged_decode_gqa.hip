@@ -22,6 +22,7 @@
 // Algorithmic bytes per launch: sum_b len_b * Hkv * D * 2(K,V) * elt  +  2 * B * Hq * D * elt
 //                               + 4 * B * (max_blocks + 1).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -55,14 +56,14 @@ struct DecodeArgs {
   void* out;
   float* ws_acc;     // [B*Hkv][chunks][G][D] fp32, un-normalised
   float* ws_ml;      // [B*Hkv][chunks][G][2]  (running max in log2 units, running sum)
-  int hq, hkv, dim, page, max_pages;
+  int hq, hkv, dim, page, page_shift, max_pages;
   int64_t table_stride, c_blk, c_head, c_tok;
   int chunk_tokens, n_chunks;
   float scale_log2;
   int abab;
 };
 
-template <typename T, int G>
+template <typename T, int G, bool NT>
 __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
   typedef typename pack8<T>::vec V8;
   typedef typename pack8<T>::pair V2;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
   if (seq_len <= 0 || tok_begin >= seq_len) return;
   const int tok_end = min(seq_len, tok_begin + a.chunk_tokens);
   const bool dim_ok = j * 8 < a.dim;
+  const int jd = dim_ok ? j * 8 : a.dim - 8;          // lanes past a short head re-read its last slice
 
   // query slices for the G heads of this kv-head (AABB: h = kvh*G + g, ABAB: h = g*Hkv + kvh)
   V8 qv[G];
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
   for (int g = 0; g < G; ++g) {
     const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
     V8 z = {};
-    qv[g] = dim_ok ? *reinterpret_cast<const V8*>(static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + j * 8) : z;
+    const V8 x = *reinterpret_cast<const V8*>(static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + jd);
+    qv[g] = dim_ok ? x : z;
   }
 
   float m[G], l[G], acc[G][8];
@@ -98,35 +101,60 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
   }
 
   const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
-  const T* kbase = static_cast<const T*>(a.kc) + kvh * a.c_head + j * 8;
-  const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head + j * 8;
+  // The golden walks the pages in order and stops at the first negative id, leaving every later
+  // row zero (core/operators/attention.py:195-198).  Find that index for the pages up to the end
+  // of this chunk: 64 table entries per step, one ballot.
+  int first_neg = 0x7fffffff;
+  {
+    int p1 = (tok_end + a.page - 1) / a.page;
+    if (p1 > a.max_pages) { first_neg = a.max_pages; p1 = a.max_pages; }
+    for (int base = 0; base < p1; base += 64) {
+      const int idx = base + lane;
+      const int v = idx < p1 ? table[idx] : 0;
+      const unsigned long long neg = __ballot(v < 0);
+      if (neg) {
+        first_neg = base + __builtin_ctzll(neg);
+        break;
+      }
+    }
+  }
+  const T* kbase = static_cast<const T*>(a.kc) + kvh * a.c_head + jd;
+  const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head + jd;
+  const int last_load = ((tok_end - 1) / DEC_TPL) * DEC_TPL;   // first token of the last non-empty load
 
-  struct Tile { V8 k[DEC_LOADS]; V8 v[DEC_LOADS]; };
+  struct Tile { V8 k[DEC_LOADS]; V8 v[DEC_LOADS]; int zero_mask; };
 
+  auto ld = [&](const T* p) -> V8 {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V8*>(p));
+    else return *reinterpret_cast<const V8*>(p);
+  };
+
+  // Branch-free: every load is issued (clamped to an address that certainly exists); which of them
+  // must read as zero (negative page id) is remembered in a wave-uniform mask.
   auto load_tile = [&](Tile& t, int t0) {
+    t.zero_mask = 0;
 #pragma unroll
     for (int u = 0; u < DEC_LOADS; ++u) {
-      const int tu = t0 + u * DEC_TPL;                 // wave-uniform first token of this load
-      V8 z = {};
-      t.k[u] = z;
-      t.v[u] = z;
-      if (tu < tok_end) {
-        const int lp = tu / a.page;                    // TPL | page, so the 4 tokens share a page
-        const int phys = lp < a.max_pages ? table[lp] : -1;
-        if (phys >= 0 && dim_ok) {                     // phys < 0: K = V = 0 (reference `break`)
-          const int64_t off = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - lp * a.page + r) * a.c_tok;
-          t.k[u] = *reinterpret_cast<const V8*>(kbase + off);
-          t.v[u] = *reinterpret_cast<const V8*>(vbase + off);
-        }
-      }
+      const int tu = min(t0 + u * DEC_TPL, last_load);    // wave-uniform; TPL | page
+      const int lp = a.page_shift >= 0 ? (tu >> a.page_shift) : tu / a.page;
+      int phys = lp < first_neg ? table[lp] : -1;
+      if (phys < 0) { t.zero_mask |= 1 << u; phys = 0; }
+      const int64_t off = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - lp * a.page + r) * a.c_tok;
+      t.k[u] = ld(kbase + off);
+      t.v[u] = ld(vbase + off);
     }
   };
 
-  auto process = [&](const Tile& t, int t0) {
+  auto process = [&](Tile& t, int t0) {
+    if (t.zero_mask) {                                   // rare: pages behind a hole read as zeros
+#pragma unroll
+      for (int u = 0; u < DEC_LOADS; ++u)
+        if (t.zero_mask & (1 << u)) { V8 z = {}; t.k[u] = z; t.v[u] = z; }
+    }
+    const bool full = t0 + DEC_TILE <= tok_end;          // wave-uniform
     float s[DEC_LOADS][G];
 #pragma unroll
     for (int u = 0; u < DEC_LOADS; ++u) {
-      const bool valid = (t0 + u * DEC_TPL + r) < tok_end;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         float d = 0.f;
@@ -136,8 +164,17 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
           V2 ka = {t.k[u][2 * e], t.k[u][2 * e + 1]};
           d = pack8<T>::dot2(qa, ka, d);
         }
-        d = row16_sum(d);
-        s[u][g] = valid ? d * a.scale_log2 : -INFINITY;
+        s[u][g] = row16_sum(d) * a.scale_log2;
+      }
+    }
+    if (!full) {                                         // last tile of the chunk: mask the tail
+#pragma unroll
+      for (int u = 0; u < DEC_LOADS; ++u) {
+        const bool valid = (t0 + u * DEC_TPL + r) < tok_end;
+        V8 z = {};
+        if (!valid) t.v[u] = z;                          // slots past the length may hold NaN/Inf
+#pragma unroll
+        for (int g = 0; g < G; ++g) s[u][g] = valid ? s[u][g] : -INFINITY;
       }
     }
 #pragma unroll
@@ -166,17 +203,19 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
     }
   };
 
-  // register double buffer: tile A / tile B, no copies
-  Tile ta, tb;
+  // three-tile register ring, prefetch distance two tiles (16 KiB in flight per wave)
+  Tile ta, tb, tc;
   load_tile(ta, tok_begin);
-  for (int t0 = tok_begin; t0 < tok_end; t0 += 2 * DEC_TILE) {
-    const bool has_b = t0 + DEC_TILE < tok_end;
-    if (has_b) load_tile(tb, t0 + DEC_TILE);
+  if (tok_begin + DEC_TILE < tok_end) load_tile(tb, tok_begin + DEC_TILE);
+  for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DEC_TILE) {
+    if (t0 + 2 * DEC_TILE < tok_end) load_tile(tc, t0 + 2 * DEC_TILE);
     process(ta, t0);
-    if (has_b) {
-      if (t0 + 2 * DEC_TILE < tok_end) load_tile(ta, t0 + 2 * DEC_TILE);
-      process(tb, t0 + DEC_TILE);
-    }
+    if (t0 + DEC_TILE >= tok_end) break;
+    if (t0 + 3 * DEC_TILE < tok_end) load_tile(ta, t0 + 3 * DEC_TILE);
+    process(tb, t0 + DEC_TILE);
+    if (t0 + 2 * DEC_TILE >= tok_end) break;
+    if (t0 + 4 * DEC_TILE < tok_end) load_tile(tb, t0 + 4 * DEC_TILE);
+    process(tc, t0 + 2 * DEC_TILE);
   }
 
   // merge the DEC_TPL lane rows (lanes j, j+16, j+32, j+48 hold the same head-dim slice)
@@ -229,46 +268,60 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
   }
 }
 
-// Merge the chunk partials of one (sequence, kv-head): grid = B*Hkv, block = G rows x (D/4 lanes... )
+// Merge the chunk partials: grid = (B*Hkv, G), one thread per 4 output elements; rows with
+// seq_len <= 0 become zeros (golden semantics), single-chunk rows were finished by the split kernel.
 template <typename T>
-__global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a, int G) {
+__global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int G) {
   const int b = blockIdx.x / a.hkv;
   const int kvh = blockIdx.x % a.hkv;
+  const int g = blockIdx.y;
   const int seq_len = a.seq_lens[b];
   const int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + a.chunk_tokens - 1) / a.chunk_tokens;
-  if (n_chunks_seq == 1) return;                       // written by the split kernel
-  const int per_head = a.dim;                          // one thread per output element
-  for (int idx = threadIdx.x; idx < G * per_head; idx += blockDim.x) {
-    const int g = idx / per_head, d = idx - g * per_head;
-    const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
-    T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + d;
-    if (n_chunks_seq == 0) {                           // seq_len <= 0: the golden returns zeros
-      *dst = static_cast<T>(0.f);
-      continue;
-    }
-    const int64_t base = static_cast<int64_t>(blockIdx.x) * a.n_chunks * G;
-    float mx = -INFINITY;
-    for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, a.ws_ml[((base + static_cast<int64_t>(c) * G) + g) * 2]);
-    float num = 0.f, den = 0.f;
-    for (int c = 0; c < n_chunks_seq; ++c) {
-      const int64_t slot = base + static_cast<int64_t>(c) * G + g;
-      const float w = exp2f(a.ws_ml[slot * 2] - mx);
-      den = fmaf(w, a.ws_ml[slot * 2 + 1], den);
-      num = fmaf(w, a.ws_acc[slot * a.dim + d], num);
-    }
-    *dst = static_cast<T>(num / den);
+  if (n_chunks_seq == 1) return;
+  const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+  const int d0 = threadIdx.x * 4;
+  if (d0 >= a.dim) return;
+  T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + d0;
+  typedef typename vec_of<T, 4>::type V4;
+  if (n_chunks_seq == 0) {
+    V4 z = {};
+    *reinterpret_cast<V4*>(dst) = z;
+    return;
   }
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * a.n_chunks * G + g;
+  float mx = -INFINITY;
+  for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, a.ws_ml[(base + static_cast<int64_t>(c) * G) * 2]);
+  f32x4 num = {0.f, 0.f, 0.f, 0.f};
+  float den = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < n_chunks_seq; ++c) {
+    const int64_t slot = base + static_cast<int64_t>(c) * G;
+    const float w = exp2f(a.ws_ml[slot * 2] - mx);
+    den = fmaf(w, a.ws_ml[slot * 2 + 1], den);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a.ws_acc + slot * a.dim + d0);
+    num += x * w;
+  }
+  const float inv = 1.0f / den;
+  V4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(num[e] * inv);
+  *reinterpret_cast<V4*>(dst) = o;
 }
 
 static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len) {
-  // aim at ~4 waves per SIMD slot across the chip (256 CUs x 12 resident waves), never below 64 tokens
-  const int64_t units = batch * kv_heads;
-  const int64_t target_waves = 256 * 12 * 2;
-  int64_t chunks = ceil_div(target_waves, units > 0 ? units : 1);
-  if (chunks < 1) chunks = 1;
-  int64_t chunk = ceil_div(max_len > 0 ? max_len : 1, chunks);
-  if (chunk < 64) chunk = 64;
-  chunk = ceil_div(chunk, 2 * DEC_TILE) * (2 * DEC_TILE);
+  if (const char* env = getenv("MOJO_HIP_DECODE_CHUNK")) {     // tuning override
+    const int v = atoi(env);
+    if (v >= DEC_TILE) return (v / DEC_TILE) * DEC_TILE;
+  }
+  // The split kernel holds 2 waves per SIMD (register-ring bound), i.e. 2048 resident waves on 256
+  // CUs.  Cut each sequence into as few chunks as still fill those slots once: long-lived waves
+  // amortise their ramp-up and leave few partials to merge.  Never below 128 tokens per chunk.
+  const int64_t units = batch * kv_heads > 0 ? batch * kv_heads : 1;
+  int64_t splits = (256 * 8) / units;
+  if (splits < 1) splits = 1;
+  int64_t chunk = ceil_div(max_len > 0 ? max_len : 1, splits);
+  if (chunk < 128) chunk = 128;
+  chunk = ceil_div(chunk, DEC_TILE) * DEC_TILE;
   return static_cast<int>(chunk);
 }
 
@@ -277,20 +330,28 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
   return (hint > 0 && hint < cap) ? hint : cap;
 }
 
-template <typename T>
-static int launch_decode(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
+template <typename T, bool NT>
+static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv));
   switch (G) {
-    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1>), grid, dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2>), grid, dim3(64), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4>), grid, dim3(64), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8>), grid, dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT>), grid, dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT>), grid, dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT>), grid, dim3(64), 0, s, a); break;
     default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
   }
   MOJO_CHECK_LAUNCH("paged_decode_gqa(split)");
-  hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv)), dim3(256), 0, s, a, G);
+  hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv), G), dim3(64), 0, s, a, G);
   MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
   return MOJO_OK;
+}
+
+template <typename T>
+static int launch_decode(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
+  // K/V are read exactly once: non-temporal loads keep them from displacing the block tables and
+  // partials in L2/MALL (measured on MI355X, B=64 ctx=4096: 204 -> 190 us).  MOJO_HIP_DECODE_NT=0 disables.
+  static const bool nt = [] { const char* e = getenv("MOJO_HIP_DECODE_NT"); return !e || atoi(e) != 0; }();
+  return nt ? launch_decode_nt<T, true>(a, batch, G, s) : launch_decode_nt<T, false>(a, batch, G, s);
 }
 
 }  // namespace mojo
@@ -323,7 +384,7 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
                "paged_decode_gqa: bad head counts Hq=%lld Hkv=%lld", (long long)q_heads, (long long)kv_heads);
   MOJO_REQUIRE(dtype == MOJO_BF16 || dtype == MOJO_F16, MOJO_EUNSUPPORTED,
                "paged_decode_gqa: dtype %d (bf16/fp16 only)", dtype);
-  MOJO_REQUIRE(head_dim % 8 == 0 && head_dim <= 8 * DEC_LPT, MOJO_EUNSUPPORTED,
+  MOJO_REQUIRE(head_dim % 8 == 0 && head_dim >= 8 && head_dim <= 8 * DEC_LPT, MOJO_EUNSUPPORTED,
                "paged_decode_gqa: head_dim %lld (multiple of 8, <= %d)", (long long)head_dim, 8 * DEC_LPT);
   MOJO_REQUIRE(block_size % DEC_TPL == 0, MOJO_EUNSUPPORTED, "paged_decode_gqa: block_size %lld must be a multiple of %d",
                (long long)block_size, DEC_TPL);
@@ -338,6 +399,7 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
   a.q = query; a.kc = key_cache; a.vc = value_cache; a.seq_lens = total_seq_lens; a.tables = block_tables; a.out = out;
   a.hq = static_cast<int>(q_heads); a.hkv = static_cast<int>(kv_heads); a.dim = static_cast<int>(head_dim);
   a.page = static_cast<int>(block_size); a.max_pages = static_cast<int>(max_blocks_per_seq);
+  a.page_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctzll(block_size) : -1;
   a.table_stride = block_table_stride; a.c_blk = cache_block_stride; a.c_head = cache_head_stride;
   a.c_tok = cache_token_stride;
   const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
