@@ -123,6 +123,28 @@ int mojo_hip_paged_decode_gqa(const void* query, const void* key_cache, const vo
                               int64_t max_seq_len_hint, float softmax_scale, int layout_abab,
                               int dtype, mojo_stream_t stream);
 
+/* ---- MojoGroupGemm (core/operators/gemm.py:59-124; replaces m_grouped_matmul,
+ *      backends/ttx/operators/gemm.py:51-92).  out[rows of g] = input[rows of g] @ W[g];
+ *      group_list = per-group ROW COUNTS on the device (int32, or int64 when group_list_is_i64);
+ *      offsets are prefix-summed on the device (no host sync, graph-capturable).
+ *      trans_weight = 0: weight [G,K,N];  1: weight [G,N,K].  bf16/fp16 with K % 64 == 0 run on the
+ *      MFMA kernel, everything else (fp32, odd K/N) on a generic kernel.                            */
+int64_t mojo_hip_group_gemm_workspace_bytes(int64_t num_groups);
+int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const void* group_list,
+                        int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
+                        int64_t num_groups, int trans_weight, int dtype, void* workspace,
+                        int64_t workspace_bytes, mojo_stream_t stream);
+
+/* ---- dense GEMM used by the GEMM+collective operators (core/operators/compute_with_comm.py:12-24,
+ *      `_gemm`): out[M,N] = input[M,K] @ W (+ bias).  W element (k,n) at weight + k*w_k_stride +
+ *      n*w_n_stride (one of the two strides is 1).  bias (optional, [N]) is added after the product
+ *      has been rounded to the storage type, as the golden's two separate ops do.                   */
+int64_t mojo_hip_gemm_workspace_bytes(void);
+int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void* out, int64_t m,
+                  int64_t k, int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride,
+                  int64_t w_n_stride, int dtype, void* workspace, int64_t workspace_bytes,
+                  mojo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,36 @@
+// Shared declarations of the grouped / dense GEMM kernels.
+#pragma once
+#include "common.h"
+
+namespace mojo {
+
+// One GEMM problem family:  C[rows of group g] = A[rows of group g] @ W[g]
+//   A  [M_total, K] row-major (lda), C [M_total, N] row-major (ldc)
+//   W  per group: element (k, n) lives at  W + g*w_group + k*w_k + n*w_n   (one of w_k / w_n is 1)
+// Row ranges come from device-side prefix arrays (built by prefix_kernel from the row counts), so no
+// host sync is needed and the launch is graph-capturable.
+struct GemmArgs {
+  const void* A;
+  const void* W;
+  void* C;
+  const void* bias;          // optional [N], same dtype as C; added after rounding (golden: two ops)
+  int64_t lda, ldc, w_group, w_k, w_n;
+  int K, N, G;
+  const int32_t* row_start;  // [G+1]
+  const int32_t* tile_start; // [G+1] prefix of ceil(rows_g / BM)
+};
+
+constexpr int GEMM_WS_INTS(int G) { return 2 * (G + 1); }
+
+// fills row_start / tile_start for tile height bm from int32 or int64 row counts
+int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
+                        int32_t* tile_start, hipStream_t s);
+
+// fast MFMA path (256x256x64 tiles); returns MOJO_EUNSUPPORTED when its preconditions do not hold
+int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
+bool gemm_mfma256_ok(const GemmArgs& a, int dtype);
+
+// generic path (any dtype in {f32,f16,bf16}, any K/N, any strides)
+int launch_gemm_generic(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
+
+}  // namespace mojo

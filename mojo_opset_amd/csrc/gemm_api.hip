@@ -1,0 +1,76 @@
+// C ABI of the grouped and dense GEMM entry points: argument checks, kernel choice, prefix launch.
+#include "gemm.h"
+
+namespace mojo {
+
+__global__ void dense_prefix_kernel(int m, int bm, int32_t* row_start, int32_t* tile_start) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    row_start[0] = 0; row_start[1] = m;
+    tile_start[0] = 0; tile_start[1] = (m + bm - 1) / bm;
+  }
+}
+
+static int run_gemm(GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
+  if (gemm_mfma256_ok(a, dtype)) return launch_gemm_mfma256(a, dtype, m_total, s);
+  return launch_gemm_generic(a, dtype, m_total, s);
+}
+
+}  // namespace mojo
+
+using namespace mojo;
+
+extern "C" int64_t mojo_hip_group_gemm_workspace_bytes(int64_t num_groups) {
+  return (2 * (num_groups + 1)) * static_cast<int64_t>(sizeof(int32_t)) + 64;
+}
+
+extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const void* group_list,
+                                   int group_list_is_i64, int64_t m_total, int64_t k, int64_t n, int64_t num_groups,
+                                   int trans_weight, int dtype, void* workspace, int64_t workspace_bytes,
+                                   mojo_stream_t stream) {
+  MOJO_REQUIRE(num_groups > 0 && k > 0 && n > 0 && m_total >= 0, MOJO_EINVAL, "group_gemm: bad shape");
+  if (m_total == 0) return MOJO_OK;
+  MOJO_REQUIRE(input && weight && out && group_list, MOJO_EINVAL, "group_gemm: null pointer");
+  MOJO_REQUIRE(dtype == MOJO_F32 || dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED,
+               "group_gemm: dtype %d not supported", dtype);
+  MOJO_REQUIRE(m_total < (1LL << 31) && k < (1LL << 31) && n < (1LL << 31) && num_groups < (1 << 20), MOJO_EUNSUPPORTED,
+               "group_gemm: dimension too large");
+  MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_group_gemm_workspace_bytes(num_groups) && aligned_to(workspace, 4),
+               MOJO_EWORKSPACE, "group_gemm: workspace too small");
+  GemmArgs a;
+  a.A = input; a.W = weight; a.C = out; a.bias = nullptr;
+  a.lda = k; a.ldc = n; a.w_group = k * n;
+  if (trans_weight) { a.w_k = 1; a.w_n = k; } else { a.w_k = n; a.w_n = 1; }
+  a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = static_cast<int>(num_groups);
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  a.row_start = ws; a.tile_start = ws + (num_groups + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
+  int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s);
+  if (rc) return rc;
+  return run_gemm(a, dtype, m_total, s);
+}
+
+extern "C" int64_t mojo_hip_gemm_workspace_bytes(void) { return 64; }
+
+extern "C" int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void* out, int64_t m, int64_t k,
+                             int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride, int64_t w_n_stride, int dtype,
+                             void* workspace, int64_t workspace_bytes, mojo_stream_t stream) {
+  MOJO_REQUIRE(k > 0 && n > 0 && m >= 0, MOJO_EINVAL, "gemm: bad shape");
+  if (m == 0) return MOJO_OK;
+  MOJO_REQUIRE(input && weight && out, MOJO_EINVAL, "gemm: null pointer");
+  MOJO_REQUIRE(dtype == MOJO_F32 || dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED,
+               "gemm: dtype %d not supported", dtype);
+  MOJO_REQUIRE(m < (1LL << 31) && k < (1LL << 31) && n < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: dimension too large");
+  MOJO_REQUIRE(workspace && workspace_bytes >= 16 && aligned_to(workspace, 4), MOJO_EWORKSPACE, "gemm: workspace too small");
+  GemmArgs a;
+  a.A = input; a.W = weight; a.C = out; a.bias = bias;
+  a.lda = lda; a.ldc = ldc; a.w_group = 0; a.w_k = w_k_stride; a.w_n = w_n_stride;
+  a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  a.row_start = ws; a.tile_start = ws + 2;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
+  hipLaunchKernelGGL(dense_prefix_kernel, dim3(1), dim3(64), 0, s, static_cast<int>(m), bm, ws, ws + 2);
+  MOJO_CHECK_LAUNCH("gemm(prefix)");
+  return run_gemm(a, dtype, m, s);
+}

@@ -1,0 +1,122 @@
+// Generic grouped GEMM: correctness path for shapes/dtypes outside the MFMA kernel's preconditions
+// (fp32 inputs, K not a multiple of 64, rows not 16-byte aligned...).  64x64 output tile per 256-thread
+// block, 16-deep K steps staged through LDS as fp32, 4x4 outputs per thread, fp32 accumulation.
+#include "gemm.h"
+
+namespace mojo {
+
+template <typename IdxT>
+__global__ void prefix_kernel(const IdxT* counts, int G, int bm, long long m_total, int32_t* row_start,
+                              int32_t* tile_start) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long r = 0, t = 0;
+  for (int g = 0; g < G; ++g) {
+    row_start[g] = static_cast<int32_t>(r);
+    tile_start[g] = static_cast<int32_t>(t);
+    long long c = static_cast<long long>(counts[g]);
+    if (c < 0) c = 0;
+    if (r + c > m_total) c = m_total - r;       // never address rows the caller did not provide
+    r += c;
+    t += (c + bm - 1) / bm;
+  }
+  row_start[G] = static_cast<int32_t>(r);
+  tile_start[G] = static_cast<int32_t>(t);
+}
+
+int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
+                        int32_t* tile_start, hipStream_t s) {
+  if (counts_are_i64)
+    hipLaunchKernelGGL(prefix_kernel<int64_t>, dim3(1), dim3(64), 0, s, static_cast<const int64_t*>(counts), G, bm,
+                       static_cast<long long>(m_total), row_start, tile_start);
+  else
+    hipLaunchKernelGGL(prefix_kernel<int32_t>, dim3(1), dim3(64), 0, s, static_cast<const int32_t*>(counts), G, bm,
+                       static_cast<long long>(m_total), row_start, tile_start);
+  MOJO_CHECK_LAUNCH("group_prefix");
+  return MOJO_OK;
+}
+
+constexpr int GT = 64;   // tile edge
+constexpr int GK = 16;   // k step
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs a) {
+  __shared__ float sa[GK][GT + 4];
+  __shared__ float sb[GK][GT + 4];
+  const int n_tiles = (a.N + GT - 1) / GT;
+  const int total = a.tile_start[a.G] * n_tiles;
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int mi = tile / n_tiles, ni = tile - mi * n_tiles;
+    int g = 0;
+    {
+      int lo = 0, hi = a.G;                      // largest g with tile_start[g] <= mi
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_start[mid] <= mi) lo = mid; else hi = mid;
+      }
+      g = lo;
+    }
+    const int m0 = a.row_start[g] + (mi - a.tile_start[g]) * GT;
+    const int m_end = a.row_start[g + 1];
+    const int n0 = ni * GT;
+    const T* A = static_cast<const T*>(a.A);
+    const T* W = static_cast<const T*>(a.W) + static_cast<int64_t>(g) * a.w_group;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < a.K; k0 += GK) {
+      for (int i = threadIdx.x; i < GT * GK; i += 256) {
+        const int r = i / GK, kk = i % GK;
+        const int m = m0 + r, k = k0 + kk;
+        sa[kk][r] = (m < m_end && k < a.K) ? elt<T>::to_f(A[static_cast<int64_t>(m) * a.lda + k]) : 0.f;
+        const int kk2 = i / GT, c = i % GT;
+        const int n = n0 + c, k2 = k0 + kk2;
+        sb[kk2][c] = (n < a.N && k2 < a.K) ? elt<T>::to_f(W[static_cast<int64_t>(k2) * a.w_k + static_cast<int64_t>(n) * a.w_n]) : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < GK; ++kk) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = sa[kk][ty * 4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = sb[kk][tx * 4 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+      }
+      __syncthreads();
+    }
+    T* C = static_cast<T*>(a.C);
+    const T* bias = static_cast<const T*>(a.bias);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + ty * 4 + i;
+      if (m >= m_end) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + tx * 4 + j;
+        if (n >= a.N) continue;
+        T o = elt<T>::from_f(acc[i][j]);
+        if (bias) o = elt<T>::from_f(elt<T>::to_f(o) + elt<T>::to_f(bias[n]));
+        C[static_cast<int64_t>(m) * a.ldc + n] = o;
+      }
+    }
+  }
+}
+
+int launch_gemm_generic(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
+  const int64_t n_tiles = ceil_div(a.N, GT);
+  int64_t blocks = (ceil_div(m_total, GT) + a.G) * n_tiles;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  switch (dtype) {
+    case MOJO_F32: hipLaunchKernelGGL(gemm_generic_kernel<float>, dim3(blocks), dim3(256), 0, s, a); break;
+    case MOJO_F16: hipLaunchKernelGGL(gemm_generic_kernel<f16_t>, dim3(blocks), dim3(256), 0, s, a); break;
+    case MOJO_BF16: hipLaunchKernelGGL(gemm_generic_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, a); break;
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "gemm: dtype %d not supported", dtype);
+  }
+  MOJO_CHECK_LAUNCH("gemm_generic");
+  return MOJO_OK;
+}
+
+}  // namespace mojo

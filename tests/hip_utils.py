@@ -42,8 +42,16 @@ def assert_close_tree(got, want, atol, rtol):
     torch.testing.assert_close(got.float(), want.float(), atol=atol, rtol=rtol)
 
 
-def max_ulp_bf16ish(got, want):
-    """Largest difference in units of the storage type's last place (16-bit float types)."""
-    gi = got.view(torch.int16).int()
-    wi = want.view(torch.int16).int()
-    return int((gi - wi).abs().max()) if got.numel() else 0
+def max_ulp_bf16ish(got, want, atol=0.0):
+    """Largest |got - want| in units of the storage type's last place at |want| (16-bit float types).
+    Differences not exceeding ``atol`` count as zero, so cancellation near zero is not mis-read as a
+    many-ulp error."""
+    if got.numel() == 0:
+        return 0
+    mant = {torch.bfloat16: 7, torch.float16: 10}[want.dtype]
+    g, w = got.double(), want.double()
+    diff = (g - w).abs()
+    expo = torch.floor(torch.log2(w.abs().clamp_min(2.0 ** -24)))
+    ulp = torch.pow(2.0, expo - mant)
+    diff = torch.where(diff <= atol, torch.zeros_like(diff), diff)
+    return float((diff / ulp).max())

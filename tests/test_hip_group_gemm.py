@@ -1,0 +1,159 @@
+"""GPU parity of MojoGroupGemm (and the dense GEMM entry point) through the C ABI.
+
+Tolerances follow the reference: large cases atol=1, rtol=2**-6, ptol=0.90
+(mojo_opset/tests/accuracy/operators/test_gemm.py:298-301); small exact-ish cases are checked
+against the oracle to within one unit in the last place of the storage type, and integer-valued
+inputs (exactly representable, fp32-exact sums) must match bit for bit."""
+import pytest
+import torch
+
+from conftest import load_golden
+from hip_utils import DEV, assert_close_tree, hip_cls, max_ulp_bf16ish, run_hip_case, to_cpu, torch_cls
+
+pytestmark = pytest.mark.gpu
+
+
+def _int_data(*shape, lo=-3, hi=4, dtype=torch.bfloat16, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(dtype)
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"gg-{i}") for i, c in enumerate(load_golden("group_gemm"))])
+def test_group_gemm_vectors(case):
+    out = to_cpu(run_hip_case(case))
+    if out.dtype == torch.float32:
+        assert_close_tree(out, case["out"], atol=1e-4, rtol=1e-4)
+    else:
+        assert max_ulp_bf16ish(out, case["out"]) <= 1
+
+
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("counts,k,n", [
+    ([256], 64, 256), ([256], 128, 256), ([512, 256], 256, 512), ([300, 0, 17, 1000, 255, 1], 512, 768),
+    ([100], 64, 96), ([700, 700], 1024, 1024 + 64), ([2560] * 3, 4096, 512),
+])
+def test_group_gemm_integer_data_is_exact(trans, dtype, counts, k, n):
+    """Asymmetric integer operands: every product and partial sum is exact in fp32, so the MFMA tiling,
+    the LDS images (both weight layouts) and the C mapping are checked element for element."""
+    g = len(counts)
+    x = _int_data(sum(counts), k, dtype=dtype, seed=1)
+    w = _int_data(g, n, k, dtype=dtype, seed=2) if trans else _int_data(g, k, n, dtype=dtype, seed=2)
+    gl = torch.tensor(counts, dtype=torch.int32)
+    want = torch_cls("MojoGroupGemm")(w.float(), trans)(x.float(), gl)
+    got = hip_cls("MojoGroupGemm")(w.to(DEV), trans)(x.to(DEV), gl.to(DEV))
+    assert torch.equal(to_cpu(got).float(), want.to(dtype).float())
+
+
+def _random_counts(groups, total, seed):
+    g = torch.Generator().manual_seed(seed)
+    raw = torch.randint(0, 2 * (total // groups) + 1, (groups,), generator=g).double()
+    c = (raw * (total / max(raw.sum().item(), 1))).long()
+    c[-1] += total - int(c.sum())
+    return c.clamp(min=0).to(torch.int32)
+
+
+@pytest.mark.parametrize("m,k,n,groups,trans", [
+    (8 * 2560, 4096, 4096, 8, False), (4 * 1024, 2048, 1024, 4, False), (6 * 512, 1024, 2048, 6, True),
+])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_group_gemm_reference_space_large(m, k, n, groups, trans, dtype):
+    torch.manual_seed(0)
+    x = torch.randn(m, k, dtype=dtype)
+    w = torch.randn(groups, n, k, dtype=dtype) if trans else torch.randn(groups, k, n, dtype=dtype)
+    counts = _random_counts(groups, m, seed=3)
+    counts[-1] = m - int(counts[:-1].sum())
+    op = hip_cls("MojoGroupGemm")(w.to(DEV), trans)
+    got = op(x.to(DEV), counts.to(DEV))
+    # oracle in fp32 on the GPU-free path would take minutes at this size on 8 cores; use per-group fp32
+    # matmul on the device as the floating-point reference of the same math (torch fp32 reference).
+    xd, wd = x.to(DEV).float(), w.to(DEV).float()
+    pieces, s = [], 0
+    for gi, c in enumerate(counts.tolist()):
+        wg = wd[gi].t() if trans else wd[gi]
+        pieces.append(xd[s: s + c] @ wg)
+        s += c
+    want = torch.cat(pieces).to(dtype)
+    from mojo_opset_amd.core import check_tol_diff
+    check_tol_diff(to_cpu(got), to_cpu(want), atol=1, rtol=2 ** -6, ptol=0.90)
+    # and much tighter than the reference demands: fp32 accumulation, one rounding
+    assert max_ulp_bf16ish(to_cpu(got), to_cpu(want), atol=0.05) <= 2
+    # launch-to-launch determinism (race screen for the staged pipeline)
+    for _ in range(5):
+        assert torch.equal(op(x.to(DEV), counts.to(DEV)), got)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("counts,k,n,trans", [
+    ([256], 128, 64, False), ([16, 64, 32, 80], 64, 96, False), ([48, 80, 64, 64], 128, 96, True),
+    ([64, 128], 128, 96, False), ([64, 128], 128, 96, True),
+])
+def test_group_gemm_reference_space_small(dtype, counts, k, n, trans):
+    torch.manual_seed(1)
+    g = len(counts)
+    x = torch.randn(sum(counts), k, dtype=dtype)
+    w = torch.randn(g, n, k, dtype=dtype) if trans else torch.randn(g, k, n, dtype=dtype)
+    gl = torch.tensor(counts, dtype=torch.int32)
+    want = torch_cls("MojoGroupGemm")(w, trans)(x, gl)
+    got = to_cpu(hip_cls("MojoGroupGemm")(w.to(DEV), trans)(x.to(DEV), gl.to(DEV)))
+    # (1) against the exactly-rounded product (fp64 accumulate, one rounding): at most one unit in the
+    #     last place.  The host's fp16 matmul itself is up to ~10 ulp away from this (it does not keep an
+    #     fp32 accumulator throughout), so the oracle comparison (2) uses the reference's loose bound.
+    exact, s0 = [], 0
+    for gi, c in enumerate(counts):
+        wg = w[gi].double().t() if trans else w[gi].double()
+        exact.append(x[s0: s0 + c].double() @ wg)
+        s0 += c
+    assert max_ulp_bf16ish(got, torch.cat(exact).to(dtype), atol=1e-3) <= 1
+    # (2) against the oracle, the reference's bound for this op (test_gemm.py:298-301)
+    from mojo_opset_amd.core import check_tol_diff
+    check_tol_diff(got, want, atol=1, rtol=2 ** -6, ptol=0.90)
+    if dtype == torch.bfloat16:
+        assert max_ulp_bf16ish(got, want, atol=1e-3) <= 1
+
+
+@pytest.mark.parametrize("xs,ws,dtype", [
+    ((16, 32), (32, 64), torch.float32), ((8, 16), (16, 32), torch.float32),
+    ((3, 4), (4, 6), torch.float16), ((5, 4), (4, 6), torch.float16), ((10, 4), (4, 6), torch.bfloat16),
+])
+def test_group_gemm_tiny_odd_shapes(xs, ws, dtype):
+    torch.manual_seed(2)
+    x, w = torch.randn(*xs, dtype=dtype), torch.randn(*ws, dtype=dtype)
+    gl = torch.tensor([xs[0]], dtype=torch.int32)
+    got = to_cpu(hip_cls("MojoGroupGemm")(w.unsqueeze(0).to(DEV), False)(x.to(DEV), gl.to(DEV)))
+    torch.testing.assert_close(got.float(), (x.float() @ w.float()), atol=2e-2 if dtype != torch.float32 else 1e-5,
+                               rtol=2e-2 if dtype != torch.float32 else 1e-5)
+
+
+def test_group_gemm_accepts_int64_and_cpu_group_list_and_checks_contract():
+    x = torch.randn(96, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.randn(2, 64, 32, dtype=torch.bfloat16, device=DEV)
+    op = hip_cls("MojoGroupGemm")(w, False)
+    a = op(x, torch.tensor([40, 56], dtype=torch.int32, device=DEV))
+    b = op(x, torch.tensor([40, 56], dtype=torch.int64))          # CPU int64, as the golden accepts
+    assert torch.equal(a, b)
+    with pytest.raises(AssertionError):
+        op(x, torch.tensor([96], dtype=torch.int32, device=DEV))    # group count mismatch
+    with pytest.raises(AssertionError):
+        op(x[:, :32], torch.tensor([40, 56], dtype=torch.int32, device=DEV))
+
+
+def test_group_gemm_full_size_linearity_mixtral():
+    """BASELINE config 3b at full size: (x1 + x2) @ W == x1 @ W + x2 @ W, exactly.  Operands are small
+    integers and W is sparse, so every output is an integer below 256 — exactly representable in bf16 —
+    and the identity must hold bit for bit; zero-row groups and the ragged split must not disturb their
+    neighbours."""
+    m, k, n, g = 16384, 4096, 14336, 8
+    x1 = _int_data(m, k, lo=-1, hi=2, seed=5)
+    x2 = _int_data(m, k, lo=-1, hi=2, seed=6)
+    gen = torch.Generator().manual_seed(7)
+    w = (torch.randint(-1, 2, (g, k, n), generator=gen) * (torch.rand(g, k, n, generator=gen) < 1 / 32)).to(torch.bfloat16).to(DEV)
+    counts = torch.tensor([8192, 0, 1, 2047, 3000, 1000, 2144, 0], dtype=torch.int32, device=DEV)
+    op = hip_cls("MojoGroupGemm")(w, False)
+    a, b, c = op(x1.to(DEV), counts), op(x2.to(DEV), counts), op((x1 + x2).to(DEV), counts)
+    assert float(c.float().abs().max()) < 256
+    assert torch.equal(a.float() + b.float(), c.float())
+    # spot-check rows at group boundaries against an fp32 matmul (exact for this data)
+    for lo, gi in ((0, 0), (8191, 0), (8192, 2), (8193, 3), (8193 + 2047, 4), (m - 1, 6)):
+        want = x1[lo: lo + 1].to(DEV).float() @ w[gi].float()
+        assert torch.equal(a[lo: lo + 1].float(), want)
