@@ -1,3 +1,3 @@
 from .attention import *  # noqa: F401,F403
-from .gemm import HIPGroupGemm  # noqa: F401
+from .gemm import HIPGroupGemm, HIPQuantGemm  # noqa: F401
 from .streaming import *  # noqa: F401,F403

@@ -60,3 +60,29 @@ class HIPGroupGemm(MojoGroupGemm):
                                         1 if self.trans_weight else 0, L.dtype_code(x.dtype), L.ptr(ws), ws.numel(),
                                         L.stream_of(x)), "HIPGroupGemm")
         return out
+
+
+class HIPQuantGemm(MojoQuantGemm):
+    supported_platforms_list = _ROCM
+
+    def forward(self, input: torch.Tensor, input_scale: torch.Tensor) -> torch.Tensor:
+        self.check_call_contract(input, input_scale)
+        weight = self.weight
+        L.require_cuda(input, input_scale, weight, self.weight_scale)
+        if input.dtype != weight.dtype or input.dtype not in (torch.int8, torch.float8_e4m3fn):
+            raise NotImplementedError("HIPQuantGemm: int8 (or fp8-e4m3) activations and weights of one dtype required")
+        m, k = input.shape
+        n = self.out_features
+        if input_scale.numel() != m:
+            raise ValueError(f"input_scale must have one entry per row, got {tuple(input_scale.shape)} for M={m}")
+        x = input if input.is_contiguous() else input.contiguous()
+        w = weight if weight.is_contiguous() else weight.contiguous()
+        s_in = input_scale.reshape(-1).to(torch.float32).contiguous()
+        s_w = self.weight_scale.to(torch.bfloat16).contiguous()
+        out = torch.empty(m, n, dtype=self.output_dtype, device=x.device)
+        ws = torch.empty(64, dtype=torch.uint8, device=x.device)
+        L.check(L.load().mojo_hip_quant_gemm(L.ptr(x), L.ptr(w), L.ptr(s_in), L.ptr(s_w), L.ptr(out), m, k, n,
+                                             1 if self.trans_weight else 0, L.dtype_code(x.dtype),
+                                             L.dtype_code(self.output_dtype), L.ptr(ws), ws.numel(), L.stream_of(x)),
+                "HIPQuantGemm")
+        return out

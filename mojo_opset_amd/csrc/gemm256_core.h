@@ -1,0 +1,451 @@
+// 256x256 MFMA GEMM core for gfx950, shared by the bf16/fp16 grouped/dense GEMM and the int8/fp8
+// quantised GEMM.  See gemm_mfma256.hip for the design notes (LDS images, staggered 8-phase schedule).
+//
+// Everything is expressed in BYTES along K: a K-tile is 128 bytes of K per row (64 bf16 / 128 int8|fp8
+// elements), a fragment is 16 bytes per lane, so the staging, the LDS images and the read addresses are
+// identical for every element type; only the MFMA call (Policy) and the epilogue differ.
+#pragma once
+#include "gemm.h"
+
+namespace mojo {
+namespace g256 {
+
+constexpr int BM = 256, BN = 256;
+constexpr int KT_BYTES = 128;                     // bytes of K per row per K-tile
+constexpr int HALF_BYTES = 128 * KT_BYTES;        // 16 KiB
+constexpr int KTILE_BYTES = 4 * HALF_BYTES;       // A0 A1 W0 W1
+constexpr int LDS_BYTES = 2 * KTILE_BYTES;        // 128 KiB
+constexpr int PANEL = 8;                          // n-tiles per panel
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef i32x4 frag16;                             // 16 bytes of K for one row / column
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef i32x8 frag32;                             // both 64-byte k-blocks of a K-tile: [ks=0 | ks=1]
+
+__device__ __forceinline__ frag16 half_of(const frag32& f, int ks) {
+  return ks ? __builtin_shufflevector(f, f, 4, 5, 6, 7) : __builtin_shufflevector(f, f, 0, 1, 2, 3);
+}
+__device__ __forceinline__ frag32 join(frag16 lo, frag16 hi) {
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---- element policies --------------------------------------------------------------------------------
+struct PolBF16 {
+  typedef bf16_t elem; typedef f32x4 acc_t; static constexpr int EB = 2, KS = 2;
+  static __device__ __forceinline__ acc_t mma(const frag32& w, const frag32& a, acc_t c, int ks) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, half_of(w, ks)), __builtin_bit_cast(bf16x8, half_of(a, ks)), c, 0, 0, 0);
+  }
+};
+struct PolF16 {
+  typedef f16_t elem; typedef f32x4 acc_t; static constexpr int EB = 2, KS = 2;
+  static __device__ __forceinline__ acc_t mma(const frag32& w, const frag32& a, acc_t c, int ks) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, half_of(w, ks)), __builtin_bit_cast(f16x8, half_of(a, ks)), c, 0, 0, 0);
+  }
+};
+struct PolI8 {
+  typedef int8_t elem; typedef i32x4 acc_t; static constexpr int EB = 1, KS = 2;
+  static __device__ __forceinline__ acc_t mma(const frag32& w, const frag32& a, acc_t c, int ks) {
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(half_of(w, ks), half_of(a, ks), c, 0, 0, 0);
+  }
+};
+struct PolF8 {   // OCP e4m3, v_mfma_f32_16x16x32_fp8_fp8: 8 bytes of K per lane per instruction, bf16 MFMA rate.
+  // (The block-scaled 16x16x128 form would double the rate, but hipcc does not accumulate it in place and
+  //  the 256-VGPR budget of this tile shape spills; left for a later round.)
+  typedef uint8_t elem; typedef f32x4 acc_t; static constexpr int EB = 1, KS = 4;
+  static __device__ __forceinline__ acc_t mma(const frag32& w, const frag32& a, acc_t c, int ks) {
+    typedef long i64x4 __attribute__((ext_vector_type(4)));
+    const i64x4 wl = __builtin_bit_cast(i64x4, w), al = __builtin_bit_cast(i64x4, a);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[ks], al[ks], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc),
+                                   (__attribute__((address_space(3))) void*)(dst_wave_base), 16, 0, 0);
+}
+
+// ---- epilogues ---------------------------------------------------------------------------------------
+// A lane owns row m = ... + (lane & 15) and the 4 consecutive columns n .. n+3 of each 16x16 tile.
+template <typename T>
+struct EpiloguePlain {       // C = round_T(acc) (+ bias, added after the rounding: the golden runs two ops)
+  T* C; int64_t ldc; const T* bias;
+  __device__ __forceinline__ void row_begin(int) {}
+  __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
+    typedef typename vec_of<T, 4>::type V4;
+    V4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[e]);
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < n_limit) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
+    }
+    T* dst = C + static_cast<int64_t>(m) * ldc + n;
+    if (n + 4 <= n_limit) {
+      *reinterpret_cast<V4*>(dst) = o;
+    } else {
+      for (int e = 0; e < 4 && n + e < n_limit; ++e) dst[e] = o[e];
+    }
+  }
+};
+
+template <typename TO, typename ACC>
+struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_scale[n] )   (golden: gemm.py:213-223)
+  TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;
+  float rs;
+  __device__ __forceinline__ void row_begin(int m) { rs = row_scale[m]; }
+  __device__ __forceinline__ void store(int m, int n, int n_limit, ACC acc) const {
+    TO* dst = C + static_cast<int64_t>(m) * ldc + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e < n_limit) {
+        float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), rs), static_cast<float>(col_scale[n + e]));
+        // keep the fp32 product a value of its own: hipcc would otherwise fuse multiply + narrowing into
+        // v_fma_mixlo_f16 (ONE rounding), while the golden rounds to fp32 first and to the output type second
+        asm volatile("" : "+v"(v));
+        dst[e] = elt<TO>::from_f(v);
+      }
+    }
+  }
+};
+
+// ---- the kernel ------------------------------------------------------------------------------------------
+template <typename P, bool W_NMAJOR /* true: W is [K,N] (n contiguous); false: [N,K] */, typename Epi>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
+  typedef typename P::elem E;
+  typedef typename P::acc_t acc_t;
+  constexpr int EB = P::EB;
+  constexpr int BK = KT_BYTES / EB;                 // elements of K per K-tile
+  extern __shared__ __attribute__((aligned(1024))) char smem_generic[];
+  lds_char* smem = (lds_char*)smem_generic;
+
+  // ---- which tile ------------------------------------------------------------------------------------
+  const int n_tiles = (a.N + BN - 1) / BN;
+  const int m_tiles = a.tile_start[a.G];
+  const int total = m_tiles * n_tiles;
+  const int bid = blockIdx.x;
+  if (bid >= total) return;
+  int tile;
+  {  // bijective XCD remap: blocks b, b+8, ... share an XCD; give each XCD one contiguous run of tiles
+    const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  int mi, ni;
+  {  // panel-major order: panels of PANEL n-tiles; inside a panel m-tile by m-tile
+    const int full_panels = n_tiles / PANEL, rem = n_tiles - full_panels * PANEL;
+    const int in_full = full_panels * m_tiles * PANEL;
+    if (tile < in_full) {
+      const int p = tile / (m_tiles * PANEL), t = tile - p * (m_tiles * PANEL);
+      mi = t / PANEL;
+      ni = p * PANEL + (t - mi * PANEL);
+    } else {
+      const int t = tile - in_full;
+      mi = t / rem;
+      ni = full_panels * PANEL + (t - mi * rem);
+    }
+  }
+  int g;
+  {
+    int lo = 0, hi = a.G;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.tile_start[mid] <= mi) lo = mid; else hi = mid;
+    }
+    g = lo;
+  }
+  const int m0 = a.row_start[g] + (mi - a.tile_start[g]) * BM;
+  const int m_end = a.row_start[g + 1];              // exclusive; m0 < m_end by construction
+  const int n0 = ni * BN;
+  const int nkt = a.K / BK;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- staging: per-lane global source pointers (bytes) ---------------------------------------------------
+  // K-major half-tile h: wave w fills row-block w (16 rows) with two glds (64-byte k-blocks 0,1).
+  //   lane l -> row l/4, 16-byte chunk (l%4) ^ (2 if row >= 8)           [st_16x32 on the source side]
+  const char* A = static_cast<const char*>(a.A);
+  const char* W = static_cast<const char*>(a.W) + static_cast<int64_t>(g) * a.w_group * EB;
+  const char* srcA[2];
+  {
+    const int row = lane >> 2;
+    const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int m = m0 + h * 128 + wave * 16 + row;
+      if (m >= m_end) m = m_end - 1;                 // rows past the group: re-read a valid row, never stored
+      srcA[h] = A + (static_cast<int64_t>(m) * a.lda) * EB + chunk * 16;
+    }
+  }
+  const char* srcW[2];
+  int64_t w_step;                                   // byte advance per K-tile
+  int w2_off[2] = {64, 64};                         // byte offset of the wave's second glds
+  if constexpr (!W_NMAJOR) {
+    const int row = lane >> 2;
+    const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int n = n0 + h * 128 + wave * 16 + row;
+      if (n >= a.N) n = a.N - 1;
+      srcW[h] = W + (static_cast<int64_t>(n) * a.w_n) * EB + chunk * 16;
+    }
+    w_step = KT_BYTES;
+  } else if constexpr (EB == 2) {
+    // [k/8][n/16][8 k][16 n] image (256-byte blocks): wave w fills k-block w with two glds (n-blocks 0-3,
+    // 4-7); lane l -> n-block l/16, stored row (l%16)/2, columns (l%2)*8..+8; odd k-blocks hold rows 4-7 first
+    const int rr = ((lane & 15) >> 1) ^ ((wave & 1) ? 4 : 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + h * 128 + (lane >> 4) * 16 + (lane & 1) * 8;
+      const int n_a = n > a.N - 8 ? a.N - 8 : n;                     // partial n-tile: stay inside the row
+      const int n_b = n + 64 > a.N - 8 ? a.N - 8 : n + 64;
+      srcW[h] = W + (static_cast<int64_t>(wave * 8 + rr) * a.w_k + n_a) * 2;
+      w2_off[h] = (n_b - n_a) * 2;
+    }
+    w_step = static_cast<int64_t>(BK) * a.w_k * 2;
+  } else {
+    // 1-byte elements: [k/8][n/16][8 k][16 n] image (128-byte blocks), block (kb, nb) stored at
+    // kb*8 + (nb ^ ((kb>>1)&1)); wave w fills k-blocks 2w and 2w+1 (one glds each = 8 k-rows x 128 n)
+    const int rr = lane & 7;
+    const int nb = (lane >> 3) ^ (wave & 1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int n = n0 + h * 128 + nb * 16;
+      if (n > a.N - 16) n = a.N - 16;
+      srcW[h] = W + static_cast<int64_t>(wave * 16 + rr) * a.w_k + n;
+      w2_off[h] = static_cast<int>(8 * a.w_k);                      // k-block 2w+1: eight rows further down
+    }
+    w_step = static_cast<int64_t>(BK) * a.w_k;
+  }
+
+  // stage half-tile `which` (0:A0 1:A1 2:W0 3:W1) of K-tile kt into buffer buf
+  auto stage = [&](int which, int kt, int buf) {
+    if (kt >= nkt) kt = nkt - 1;                    // keep the vmcnt bookkeeping uniform at the tail
+    lds_char* dst = smem + buf * KTILE_BYTES + which * HALF_BYTES + wave * 2048;
+    if (which < 2) {
+      const char* p = srcA[which] + static_cast<int64_t>(kt) * KT_BYTES;
+      glds16(p, dst);
+      glds16(p + 64, dst + 1024);
+    } else {
+      const int h = which - 2;
+      const char* p = srcW[h] + static_cast<int64_t>(kt) * w_step;
+      glds16(p, dst);
+      glds16(p + w2_off[h], dst + 1024);
+    }
+  };
+
+  // ---- fragment read offsets ------------------------------------------------------------------------------
+  // K-major: sub-tile (rb, ks) at (rb*2+ks)*1024; lane reads row l&15, chunk (l>>4) ^ (2 if row >= 8)
+  const int kmaj_lane = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 8) ? 2 : 0)) * 16);
+  const int grp = lane >> 4;
+
+  typedef const __attribute__((address_space(3))) frag16* lds_frag_ptr;
+  auto read_a = [&](frag32 (&fa)[4], int h, int buf) {
+    const lds_char* base = smem + buf * KTILE_BYTES + h * HALF_BYTES + (wm * 4) * 2048 + kmaj_lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      fa[i] = join(*reinterpret_cast<lds_frag_ptr>(base + i * 2048), *reinterpret_cast<lds_frag_ptr>(base + i * 2048 + 1024));
+  };
+  auto read_w = [&](frag32 (&fw)[2], int h, int buf) {              // K-major W ([N,K])
+    const lds_char* base = smem + buf * KTILE_BYTES + (2 + h) * HALF_BYTES + (wn * 2) * 2048 + kmaj_lane;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fw[j] = join(*reinterpret_cast<lds_frag_ptr>(base + j * 2048), *reinterpret_cast<lds_frag_ptr>(base + j * 2048 + 1024));
+  };
+  // N-major W ([K,N]): transposed reads.  hipcc drains vmcnt(0) in front of the ds_read_tr builtins (it
+  // cannot prove the read independent of the LDS-DMA writes in flight), which serialises the pipeline;
+  // so the reads are issued from inline asm and retired by an explicit lgkmcnt wait that names every
+  // destination register (the compiler may not touch them in between).
+  struct TrRegs { i32x2 r[8]; };                                   // [j][ks][first | second 8 bytes of K]
+  const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
+  // EB == 2: block (kb, nb) at (kb*8+nb)*256, kb = ks*4 + grp; lane 4q+p -> stored row q (+4), cols 4p
+  // EB == 1: block (kb, nb) at (kb*8 + (nb ^ ((kb>>1)&1)))*128, kb = ks*8 + 2*grp + half; lane 2q+p -> row q, cols 8p
+  unsigned tr_lane[2];
+  if constexpr (EB == 2) {
+    const int qq = (lane & 15) >> 2, pp = lane & 3;
+    tr_lane[0] = grp * 2048 + (qq + ((grp & 1) ? 4 : 0)) * 32 + pp * 8;     // k rows 0-3 of the block
+    tr_lane[1] = grp * 2048 + (qq + ((grp & 1) ? 0 : 4)) * 32 + pp * 8;     // k rows 4-7
+  } else {
+    const int qq = (lane & 15) >> 1, pp = lane & 1;
+    tr_lane[0] = grp * 2048 + ((0 ^ (grp & 1)) * 128) + qq * 16 + pp * 8;   // j = 0
+    tr_lane[1] = grp * 2048 + ((1 ^ (grp & 1)) * 128) + qq * 16 + pp * 8;   // j = 1
+  }
+  auto issue_w_tr = [&](TrRegs& t, int h, int buf) {
+    const unsigned base = smem_u32 + buf * KTILE_BYTES + (2 + h) * HALF_BYTES + (wn * 2) * (EB == 2 ? 256 : 128);
+    const unsigned a0 = base + tr_lane[0], a1 = base + tr_lane[1];
+    if constexpr (EB == 2) {
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %8\n\t"
+          "ds_read_b64_tr_b16 %1, %9\n\t"
+          "ds_read_b64_tr_b16 %2, %8 offset:8192\n\t"
+          "ds_read_b64_tr_b16 %3, %9 offset:8192\n\t"
+          "ds_read_b64_tr_b16 %4, %8 offset:256\n\t"
+          "ds_read_b64_tr_b16 %5, %9 offset:256\n\t"
+          "ds_read_b64_tr_b16 %6, %8 offset:8448\n\t"
+          "ds_read_b64_tr_b16 %7, %9 offset:8448"
+          : "=v"(t.r[0]), "=v"(t.r[1]), "=v"(t.r[2]), "=v"(t.r[3]), "=v"(t.r[4]), "=v"(t.r[5]), "=v"(t.r[6]), "=v"(t.r[7])
+          : "v"(a0), "v"(a1)
+          : "memory");
+    } else {
+      asm volatile(
+          "ds_read_b64_tr_b8 %0, %8\n\t"
+          "ds_read_b64_tr_b8 %1, %8 offset:1024\n\t"
+          "ds_read_b64_tr_b8 %2, %8 offset:8192\n\t"
+          "ds_read_b64_tr_b8 %3, %8 offset:9216\n\t"
+          "ds_read_b64_tr_b8 %4, %9\n\t"
+          "ds_read_b64_tr_b8 %5, %9 offset:1024\n\t"
+          "ds_read_b64_tr_b8 %6, %9 offset:8192\n\t"
+          "ds_read_b64_tr_b8 %7, %9 offset:9216"
+          : "=v"(t.r[0]), "=v"(t.r[1]), "=v"(t.r[2]), "=v"(t.r[3]), "=v"(t.r[4]), "=v"(t.r[5]), "=v"(t.r[6]), "=v"(t.r[7])
+          : "v"(a0), "v"(a1)
+          : "memory");
+    }
+  };
+  auto retire_w_tr = [&](TrRegs& t, frag32 (&fw)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t.r[0]), "+v"(t.r[1]), "+v"(t.r[2]), "+v"(t.r[3]), "+v"(t.r[4]), "+v"(t.r[5]), "+v"(t.r[6]), "+v"(t.r[7])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      fw[j] = frag32{t.r[j * 4][0], t.r[j * 4][1], t.r[j * 4 + 1][0], t.r[j * 4 + 1][1],
+                     t.r[j * 4 + 2][0], t.r[j * 4 + 2][1], t.r[j * 4 + 3][0], t.r[j * 4 + 3][1]};
+  };
+
+  // acc[mt][nt]: mt = h_m*4 + i (16-row tiles of this wave), nt = h_n*2 + j (16-col tiles)
+  acc_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  auto quadrant = [&](const frag32 (&fa)[4], const frag32 (&fw)[2], int hm, int hn) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < P::KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[hm * 4 + i][hn * 2 + j] = P::mma(fw[j], fa[i], acc[hm * 4 + i][hn * 2 + j], ks);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- schedule -------------------------------------------------------------------------------------
+  // A K-tile is 4 phases; a phase is two segments separated by barriers:
+  //     R_p : issue one half-tile of a future K-tile (2 glds) + this phase's fragment reads
+  //     M_p : 16 MFMAs (one 64x32 C-quadrant), then s_waitcnt vmcnt(6)
+  // Waves 4-7 (wm = 1) run ONE barrier behind waves 0-3, so on every SIMD one wave is in its M
+  // segment while its partner is in R: the matrix pipe and the LDS/VMEM pipes ping-pong.
+  // Hazards under that stagger (a lagging reader / stager is one segment late):
+  //   WAR: a half-tile is restaged >= 2 phases after the phase that last ds_read it;
+  //   RAW: the counted wait that retires a half-tile sits at the end of the phase TWO before the
+  //        phase that first reads it (wait -> barrier -> barrier -> read, for either group).
+  // Steady state, K-tile t in buffer b (reads: P1 A0+W0, P2 W1, P3 A1, P4 none - W0 stays in VGPRs):
+  //     P1 stages W1(t+1)->b^1   P2 stages A1(t+1)->b^1   P3 stages A0(t+2)->b   P4 stages W0(t+2)->b
+  // After every phase "all but the last 3 half-tiles issued" have landed, which is exactly what the
+  // read two phases later needs (GroupGemm schedule table).
+  stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
+  stage(0, 1, 1); stage(2, 1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 has landed
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
+
+  frag32 fa[4], fw0[2], fw1[2];
+  TrRegs tr;
+
+  auto seg_end = [&]() {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto ktile = [&](int t, int buf) {
+    // P1
+    stage(3, t + 1, buf ^ 1);
+    if constexpr (W_NMAJOR) issue_w_tr(tr, 0, buf); else read_w(fw0, 0, buf);
+    read_a(fa, 0, buf);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (W_NMAJOR) retire_w_tr(tr, fw0);
+    quadrant(fa, fw0, 0, 0);
+    seg_end();
+    // P2
+    stage(1, t + 1, buf ^ 1);
+    if constexpr (W_NMAJOR) issue_w_tr(tr, 1, buf); else read_w(fw1, 1, buf);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (W_NMAJOR) retire_w_tr(tr, fw1);
+    quadrant(fa, fw1, 0, 1);
+    seg_end();
+    // P3
+    stage(0, t + 2, buf);
+    read_a(fa, 1, buf);
+    __builtin_amdgcn_s_barrier();
+    quadrant(fa, fw1, 1, 1);
+    seg_end();
+    // P4
+    stage(2, t + 2, buf);
+    __builtin_amdgcn_s_barrier();
+    quadrant(fa, fw0, 1, 0);
+    seg_end();
+  };
+
+  int t = 0;
+  for (; t + 1 < nkt; t += 2) {
+    ktile(t, 0);
+    ktile(t + 1, 1);
+  }
+  if (t < nkt) ktile(t, 0);
+  if (wm == 0) __builtin_amdgcn_s_barrier();            // pair the stagger barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue ---------------------------------------------------------------------------------------
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
+    if (m >= m_end) continue;
+    epi.row_begin(m);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + (lane >> 4) * 4;
+      if (n >= a.N) continue;
+      epi.store(m, n, a.N, acc[mt][nt]);
+    }
+  }
+}
+
+// shared precondition checks (bytes along K); eb = element bytes
+inline bool gemm256_layout_ok(const GemmArgs& a, int eb) {
+  const int bk = KT_BYTES / eb, al = 16 / eb;
+  if (a.K < bk || a.K % bk != 0 || a.N < al) return false;
+  if (a.lda % al != 0) return false;
+  if (!aligned_to(a.A, 16) || !aligned_to(a.W, 16)) return false;
+  if (a.w_n == 1) {                                   // [K,N]
+    if (a.w_k % al != 0 || a.w_group % al != 0 || a.N % al != 0) return false;
+  } else if (a.w_k == 1) {                            // [N,K]
+    if (a.w_n % al != 0 || a.w_group % al != 0) return false;
+  } else {
+    return false;
+  }
+  return true;
+}
+
+template <typename P, typename Epi>
+inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
+  const int64_t n_tiles = ceil_div(a.N, BN);
+  const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles;   // upper bound; surplus blocks exit
+  MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
+  if (a.w_n == 1) {
+    auto* fn = gemm256_kernel<P, true, Epi>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); done = true; }
+    hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
+  } else {
+    auto* fn = gemm256_kernel<P, false, Epi>;
+    static bool done = false;
+    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); done = true; }
+    hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
+  }
+  MOJO_CHECK_LAUNCH("gemm256");
+  return MOJO_OK;
+}
+
+}  // namespace g256
+}  // namespace mojo

@@ -1,0 +1,102 @@
+"""GPU parity of MojoQuantGemm through the C ABI.
+
+int8: the accelerated result must equal the exact integer formula — atol = rtol = 0 — exactly as the
+reference demands of its golden (mojo_opset/tests/accuracy/operators/test_gemm.py:95-111).
+fp8-e4m3 (extension, parity unpinned): compared with the oracle restatement at fp32-accumulate tolerance."""
+import pytest
+import torch
+
+from conftest import bit_equal, load_golden
+from hip_utils import DEV, hip_cls, run_hip_case, to_cpu, torch_cls
+from oracle import quant_gemm_formula
+
+pytestmark = pytest.mark.gpu
+
+
+def _quantize(x):
+    scale = x.abs().amax(dim=-1).clamp_min(1e-8) / 127.0
+    return torch.clamp(torch.round(x / scale.unsqueeze(-1)), -128, 127).to(torch.int8), scale
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"qg-{i}") for i, c in enumerate(load_golden("quant_gemm"))])
+def test_quant_gemm_vectors_bit_exact(case):
+    assert bit_equal(to_cpu(run_hip_case(case)), case["out"])
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 4096, 4096), (32, 4096, 11008), (128, 2048, 4096), (64, 4096, 4096),
+                                   (300, 1024, 1000), (257, 128, 264), (5, 96, 40)])
+@pytest.mark.parametrize("trans_weight", [False, True])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16, torch.float32])
+def test_quant_gemm_int8_equals_integer_formula(m, k, n, trans_weight, odt):
+    torch.manual_seed(0)
+    xq, xs = _quantize(torch.randn(m, k))
+    wq, ws = _quantize(torch.randn(n, k))
+    op = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=odt, trans_weight=trans_weight, device=DEV)
+    op.weight.copy_(wq if trans_weight else wq.t())
+    op.weight_scale.copy_(ws.to(torch.bfloat16))
+    scale = xs if (m + k) % 2 else xs.unsqueeze(-1)
+    out = to_cpu(op(xq.to(DEV), scale.to(DEV)))
+    expect = quant_gemm_formula(xq, wq.t(), xs, ws.to(torch.bfloat16), odt)
+    torch.testing.assert_close(out, expect, atol=0, rtol=0)
+    assert set(op.state_dict()) == {"weight", "weight_scale"}
+
+
+def test_quant_gemm_int8_extreme_values_accumulate_in_int32():
+    """+-127/128 everywhere: |sum| = K*16384 > 2^24, where an fp32 running sum would round — the int32
+    accumulator must stay exact (the oracle's float64 formula is the arbiter here)."""
+    m, k, n = 64, 8192, 256
+    xq = torch.full((m, k), -128, dtype=torch.int8)
+    wq = torch.full((n, k), 127, dtype=torch.int8)
+    wq[::2] = -128
+    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=torch.float32, trans_weight=True, device=DEV)
+    op.weight.copy_(wq)
+    op.weight_scale.fill_(1.0)
+    out = to_cpu(op(xq.to(DEV), torch.ones(m, device=DEV)))
+    expect = (xq.double() @ wq.double().t()).float()
+    assert torch.equal(out, expect)
+
+
+def test_quant_gemm_error_conventions():
+    op = hip_cls("MojoQuantGemm")(64, 32, device=DEV)
+    with pytest.raises(ValueError):
+        op(torch.zeros(2, 3, 64, dtype=torch.int8, device=DEV), torch.ones(2, device=DEV))
+    with pytest.raises(ValueError):
+        op(torch.zeros(2, 48, dtype=torch.int8, device=DEV), torch.ones(2, device=DEV))
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 7168, 1536), (32, 2048, 7168), (1, 512, 256), (300, 1024, 1000), (7, 96, 40)])
+@pytest.mark.parametrize("trans_weight", [False, True])
+def test_quant_gemm_fp8_matches_oracle(m, k, n, trans_weight):
+    """Extension dtype — parity unpinned: there is no reference implementation (gemm.py:171-173 asserts int8)."""
+    torch.manual_seed(1)
+    f8 = torch.float8_e4m3fn
+    x = torch.randn(m, k).to(f8)
+    w_nk = torch.randn(n, k).to(f8)
+    s_in, s_w = torch.rand(m) + 0.5, (torch.rand(n) + 0.5).to(torch.bfloat16)
+    kw = dict(in_features=k, out_features=n, output_dtype=torch.bfloat16, trans_weight=trans_weight, quant_dtype=f8, weight_dtype=f8)
+    ref = torch_cls("MojoQuantGemm")(**kw)
+    op = hip_cls("MojoQuantGemm")(**kw, device=DEV)
+    for o in (ref, op):
+        o.weight.copy_((w_nk if trans_weight else w_nk.t().contiguous()).to(o.weight.device))
+        o.weight_scale.copy_(s_w)
+    want = ref(x, s_in)
+    got = to_cpu(op(x.to(DEV), s_in.to(DEV)))
+    exact = quant_gemm_formula(x, w_nk.t(), s_in, s_w, torch.bfloat16)
+    torch.testing.assert_close(got.float(), exact.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -7)
+    torch.testing.assert_close(got.float(), want.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -6)
+
+
+def test_quant_gemm_fp8_small_integers_exact():
+    """fp8 values that are small integers: products and sums are exact, so the operand mapping of the
+    fp8 MFMA and both weight layouts are checked element for element."""
+    f8 = torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(3)
+    m, k, n = 300, 512, 520
+    x = torch.randint(-3, 4, (m, k), generator=g).float()
+    w = torch.randint(-3, 4, (n, k), generator=g).float()
+    for trans in (False, True):
+        op = hip_cls("MojoQuantGemm")(k, n, output_dtype=torch.float32, trans_weight=trans, quant_dtype=f8, weight_dtype=f8, device=DEV)
+        op.weight.copy_((w if trans else w.t().contiguous()).to(f8))
+        op.weight_scale.fill_(1.0)
+        out = to_cpu(op(x.to(f8).to(DEV), torch.ones(m, device=DEV)))
+        assert torch.equal(out, x @ w.t())
