@@ -58,3 +58,38 @@ class HIPPagedDecodeGQA(MojoPagedDecodeGQA):
             key_cache.stride(1), key_cache.stride(2), hint, scale, 1 if self.gqa_layout == "ABAB" else 0,
             L.dtype_code(q.dtype), L.stream_of(q)), "HIPPagedDecodeGQA")
         return out
+
+
+class HIPPagedPrefillGQA(MojoPagedPrefillGQA):
+    supported_platforms_list = _ROCM
+
+    def forward(self, query, key_cache, value_cache, cu_q_lens, block_tables, softmax_scale: Optional[float] = None,
+                cu_total_seq_lens: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                max_q_len: Optional[int] = None, max_total_seq_len: Optional[int] = None):
+        assert_paged_prefill_contract(cu_q_lens, block_tables, cu_total_seq_lens)
+        if not self.is_causal or mask is not None:
+            raise NotImplementedError("HIPPagedPrefillGQA supports causal attention without an explicit mask only")
+        L.require_cuda(query, key_cache, value_cache, cu_q_lens, block_tables, cu_total_seq_lens)
+        tokens, hq, dim = query.shape
+        n_blocks, hkv, page, dim_c = key_cache.shape
+        assert dim_c == dim and value_cache.shape == key_cache.shape and hq % hkv == 0
+        assert query.dtype == key_cache.dtype == value_cache.dtype
+        _check_cache_layout(key_cache, value_cache, "HIPPagedPrefillGQA")
+        batch = cu_q_lens.shape[0] - 1
+        if _validate_tables() and batch > 0 and block_tables.shape[1] > 0:
+            q_lens = cu_q_lens[1:] - cu_q_lens[:-1]
+            kv_lens = q_lens if cu_total_seq_lens is None else cu_total_seq_lens[1:] - cu_total_seq_lens[:-1]
+            if bool(((q_lens > 0) & (kv_lens > 0) & (block_tables[:, 0] < 0)).any()):
+                raise ValueError("Paged prefill requires a valid block table for rows with kv lens > 0.")
+        q = query if query.is_contiguous() else query.contiguous()
+        tables = block_tables if block_tables.stride(1) == 1 else block_tables.contiguous()
+        cu_q = cu_q_lens.contiguous()
+        cu_kv = None if cu_total_seq_lens is None else cu_total_seq_lens.contiguous()
+        scale = 1.0 / math.sqrt(dim) if softmax_scale is None else float(softmax_scale)
+        out = torch.empty_like(q)
+        L.check(L.load().mojo_hip_paged_prefill_gqa(
+            L.ptr(q), L.ptr(key_cache), L.ptr(value_cache), L.ptr(cu_q), L.ptr(cu_kv), L.ptr(tables), L.ptr(out),
+            tokens, batch, hq, hkv, dim, page, tables.shape[1], tables.stride(0), key_cache.stride(0),
+            key_cache.stride(1), key_cache.stride(2), int(max_q_len) if max_q_len else 0, scale,
+            1 if self.gqa_layout == "ABAB" else 0, L.dtype_code(q.dtype), L.stream_of(q)), "HIPPagedPrefillGQA")
+        return out

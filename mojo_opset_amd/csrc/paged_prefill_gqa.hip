@@ -1,0 +1,374 @@
+// MojoPagedPrefillGQA — flash attention (online softmax) over a paged KV cache on MFMA, gfx950.
+//
+// Work decomposition
+//   grid = (q blocks, Hkv, B); one 256-thread workgroup owns 128 "rows" = the G = Hq/Hkv query heads of one
+//   kv-head times 128/G consecutive query positions, so every K/V tile is read once per kv-head.
+//   Each of the 4 waves owns 32 rows = two 16-row MFMA tiles.
+//   K/V advance in tiles of 64 keys, double-buffered in LDS (2 x (16 + 16) KiB), filled by direct-to-LDS
+//   loads straight from the pages (4 keys x 256 B per wave instruction, page ids looked up per 4 keys).
+//
+// MFMA formulation (v_mfma_f32_16x16x32): everything is computed transposed so that softmax statistics
+// are lane-local per query row and the probabilities feed the second product without leaving registers:
+//   S^T[key][q]  = sum_d K[key][d] * Q[q][d]          A = K fragment (ds_read_b128), B = Q fragment (VGPRs)
+//   O^T[d][q]   += sum_key V[key][d] * P^T[key][q]    A = V^T fragment (ds_read_b64_tr_b16), B = P^T built from
+//                                                     the S^T accumulators (key order inside a k-step is the
+//                                                     accumulator's own order; V^T is read in the same order)
+// LDS images: rows of 256 B (head_dim <= 128); K: 16-byte chunk c of key r stored at c ^ (r & 15);
+// V: chunk c stored at c ^ ((r & 7) << 1); both conflict-free for their read pattern, applied on the
+// SOURCE address of the lane-linear LDS-DMA.
+//
+// Numerics: fp32 scores and statistics, probabilities rounded to the storage type for the PV product
+// (as the golden does), fp32 output accumulation.  Parity by tolerance: atol = rtol = 2e-2.
+//
+// Algorithmic FLOPs (causal): sum_b 4 * Hq * D * (q_b * kv_b - q_b^2 / 2).   Bound: MFMA.
+#include <math.h>
+
+#include "common.h"
+
+namespace mojo {
+
+typedef __attribute__((address_space(3))) char lds_c;
+
+struct PrefillArgs {
+  const void* q;
+  const void* kc;
+  const void* vc;
+  void* out;
+  const int32_t* cu_q;
+  const int32_t* cu_kv;      // may be null: kv_len = q_len
+  const int32_t* tables;
+  int64_t table_stride, c_blk, c_head, c_tok;
+  int hq, hkv, dim, page, page_shift, max_pages;
+  float scale_log2;
+  int abab;
+};
+
+template <typename T> struct pf_mfma;
+template <> struct pf_mfma<bf16_t> {
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct pf_mfma<f16_t> {
+  typedef f16x8 frag;
+  static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int PF_KEYS = 64;                  // keys per tile
+constexpr int PF_TILE_BYTES = PF_KEYS * 256; // 16 KiB per K or V tile
+constexpr int PF_LDS = 4 * PF_TILE_BYTES;    // K0 V0 K1 V1
+
+template <typename T, int G /* q heads per kv head */, int DK /* head_dim / 32 */>
+__global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
+  typedef typename pf_mfma<T>::frag frag;
+  constexpr int QPB = 128 / G;               // query positions per workgroup
+  constexpr int DT = DK * 2;                 // 16-wide d tiles
+  extern __shared__ __attribute__((aligned(1024))) char smem_generic[];
+  lds_c* smem = (lds_c*)smem_generic;
+
+  const int b = blockIdx.z, kvh = blockIdx.y, qb = blockIdx.x;
+  const int q_start = a.cu_q[b];
+  const int q_len = a.cu_q[b + 1] - q_start;
+  const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
+  if (qb * QPB >= q_len || kv_len <= 0) return;        // rows of skipped sequences stay zero (memset by the caller)
+  const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = lane >> 4, l15 = lane & 15;
+  const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
+
+  // first negative page id (golden: rows behind it read as zero K/V)
+  const int pos_hi = min(q_len, (qb + 1) * QPB) - 1;    // last query position of this block
+  int kv_hi = min(kv_len, offset + pos_hi + 1);          // keys [0, kv_hi) are visible to some row
+  if (kv_hi < 1) kv_hi = 1;
+  int first_neg_key = 0x7fffffff;
+  {
+    int p1 = (kv_hi + a.page - 1) / a.page;
+    int fn = 0x7fffffff;
+    if (p1 > a.max_pages) { fn = a.max_pages; p1 = a.max_pages; }
+    for (int base = 0; base < p1; base += 64) {
+      const int idx = base + lane;
+      const int v = idx < p1 ? table[idx] : 0;
+      const unsigned long long neg = __ballot(v < 0);
+      if (neg) { fn = base + __builtin_ctzll(neg); break; }
+    }
+    if (fn != 0x7fffffff) first_neg_key = fn * a.page;
+  }
+  const int n_kb = (kv_hi + PF_KEYS - 1) / PF_KEYS;
+
+  // ---- this wave's rows: two 16-row tiles; row -> (head g, query position) -------------------------------
+  int row_pos[2], row_head[2];
+  const T* qptr[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int r = wave * 32 + qt * 16 + l15;
+    const int g = r / QPB;
+    int pos = qb * QPB + (r % QPB);
+    row_head[qt] = a.abab ? g * a.hkv + kvh : kvh * G + g;
+    row_pos[qt] = pos;
+    if (pos >= q_len) pos = q_len - 1;                   // clamp: computed, never stored
+    qptr[qt] = static_cast<const T*>(a.q) + (static_cast<int64_t>(q_start + pos) * a.hq + row_head[qt]) * a.dim;
+  }
+  frag qf[2][DK];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) qf[qt][ks] = *reinterpret_cast<const frag*>(qptr[qt] + ks * 32 + grp * 8);
+
+  // ---- staging ------------------------------------------------------------------------------------------
+  // wave w fills keys [16w, 16w+16) of a tile with 4 LDS-DMA instructions per tensor (4 keys x 256 B each);
+  // lane l: key l/16 of the four, LDS chunk position l%16
+  const T* kbase = static_cast<const T*>(a.kc) + kvh * a.c_head;
+  const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head;
+  const int chunks = a.dim / 8;
+  auto stage = [&](int kb, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kl = wave * 16 + i * 4 + (lane >> 4);                       // key inside the tile
+      int key = kb * PF_KEYS + kl;
+      if (key >= kv_hi) key = kv_hi - 1;
+      const int lp = a.page_shift >= 0 ? (key >> a.page_shift) : key / a.page;
+      int phys = (lp < a.max_pages) ? table[lp] : 0;
+      if (phys < 0) phys = 0;                                               // value is masked later
+      const int64_t row = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key - lp * a.page) * a.c_tok;
+      const int cp = lane & 15;
+      int ck = cp ^ (kl & 15);
+      int cv = cp ^ ((kl & 7) << 1);
+      if (ck >= chunks) ck = chunks - 1;
+      if (cv >= chunks) cv = chunks - 1;
+      lds_c* dk = smem + buf * 2 * PF_TILE_BYTES + (wave * 16 + i * 4) * 256;
+      lds_c* dv = dk + PF_TILE_BYTES;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + row + ck * 8),
+                                       (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + row + cv * 8),
+                                       (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+    }
+  };
+
+  // ---- state ----------------------------------------------------------------------------------------------
+  f32x4 o[2][DT];
+  float m[2], lsum[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    m[qt] = -INFINITY;
+    lsum[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
+  // V^T transposed-read lane offset: lane 4q+p of a 16-group -> key row (4*grp + q), 8 bytes at column 4p
+  const int tq = l15 >> 2, tp = l15 & 3;
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int kb = 0; kb < n_kb; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
+    const lds_c* kt = smem + buf * 2 * PF_TILE_BYTES;
+    const unsigned vt = smem_u32 + buf * 2 * PF_TILE_BYTES + PF_TILE_BYTES;
+
+    // ---- S^T = K Q^T : 4 key tiles x 2 q tiles -------------------------------------------------------------
+    f32x4 s[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int key_row = t * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        const int chunk = (ks * 4 + grp) ^ (key_row & 15);
+        const frag kf = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(kt + key_row * 256 + chunk * 16);
+        s[0][t] = pf_mfma<T>::run(kf, qf[0][ks], s[0][t]);
+        s[1][t] = pf_mfma<T>::run(kf, qf[1][ks], s[1][t]);
+      }
+    }
+    // lane holds, for query column l15 of each q tile, keys  kb*64 + 16t + 4*grp + r
+    const int key0 = kb * PF_KEYS + 4 * grp;
+    const bool need_mask = (kb + 1) * PF_KEYS > min(kv_len, offset + qb * QPB + 1);   // diagonal / tail tile
+    const bool has_hole = (kb + 1) * PF_KEYS > first_neg_key;
+    frag pf[2][2];                                                                   // [q tile][32-key step]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float sc[4][4];
+      float mx = m[qt];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[qt][t][r] * a.scale_log2;
+          const int key = key0 + 16 * t + r;
+          if (has_hole && key >= first_neg_key) v = 0.f;                             // zero K rows: score 0
+          if (need_mask && (key > offset + row_pos[qt] || key >= kv_len)) v = -INFINITY;
+          sc[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float ms = mx == -INFINITY ? 0.f : mx;
+      const float alpha = exp2f(m[qt] - ms);
+      m[qt] = mx;
+      float ps = 0.f;
+      float p[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[t][r] = exp2f(sc[t][r] - ms);
+          ps += p[t][r];
+          if (has_hole && key0 + 16 * t + r >= first_neg_key) p[t][r] = 0.f;        // zero V rows: no contribution
+        }
+      lsum[qt] = lsum[qt] * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+      // P^T operand of 32-key step kk: k-slot j<4 -> key tile 2kk reg j, j>=4 -> key tile 2kk+1 reg j-4
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        frag f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = static_cast<T>(p[2 * kk][r]);
+          f[4 + r] = static_cast<T>(p[2 * kk + 1][r]);
+        }
+        pf[qt][kk] = f;
+      }
+    }
+
+    // ---- O^T += V^T P^T : per d tile, two 32-key steps ---------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      s16x4 v4[4];                                                                   // [kk][first/second 4 keys]
+      {
+        unsigned addr[4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int key_row = kk * 32 + hf * 16 + 4 * grp + tq;
+            const int chunk = (2 * dt + (tp >> 1)) ^ ((key_row & 7) << 1);
+            addr[kk * 2 + hf] = vt + key_row * 256 + chunk * 16 + (tp & 1) * 8;
+          }
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %4\n\t"
+            "ds_read_b64_tr_b16 %1, %5\n\t"
+            "ds_read_b64_tr_b16 %2, %6\n\t"
+            "ds_read_b64_tr_b16 %3, %7\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(v4[0]), "=&v"(v4[1]), "=&v"(v4[2]), "=&v"(v4[3])
+            : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
+            : "memory");
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const s16x8 both = {v4[kk * 2][0], v4[kk * 2][1], v4[kk * 2][2], v4[kk * 2][3],
+                            v4[kk * 2 + 1][0], v4[kk * 2 + 1][1], v4[kk * 2 + 1][2], v4[kk * 2 + 1][3]};
+        const frag vf = __builtin_bit_cast(frag, both);
+        o[0][dt] = pf_mfma<T>::run(vf, pf[0][kk], o[0][dt]);
+        o[1][dt] = pf_mfma<T>::run(vf, pf[1][kk], o[1][dt]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile landed (issued a whole tile ago)
+    __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
+  }
+
+  // ---- finish: reduce the row sums over the 4 lane groups, normalise, store ----------------------------------
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = lsum[qt];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (row_pos[qt] >= q_len) continue;
+    const float inv = 1.0f / l;
+    T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + row_pos[qt]) * a.hq + row_head[qt]) * a.dim;
+    typedef typename vec_of<T, 4>::type V4;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      V4 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov[r] = static_cast<T>(o[qt][dt][r] * inv);
+      *reinterpret_cast<V4*>(dst + dt * 16 + grp * 4) = ov;
+    }
+  }
+}
+
+template <typename T, int G, int DK>
+static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
+  auto* fn = prefill_kernel<T, G, DK>;
+  static bool done = false;
+  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS); done = true; }
+  hipLaunchKernelGGL(fn, grid, dim3(256), PF_LDS, s, a);
+}
+
+template <typename T, int G>
+static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
+  switch (a.dim) {
+    case 64: launch_pf<T, G, 2>(a, grid, s); break;
+    case 96: launch_pf<T, G, 3>(a, grid, s); break;
+    case 128: launch_pf<T, G, 4>(a, grid, s); break;
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_prefill_gqa: head_dim %d (64, 96, 128)", a.dim);
+  }
+  MOJO_CHECK_LAUNCH("paged_prefill_gqa");
+  return MOJO_OK;
+}
+
+template <typename T>
+static int dispatch_g(const PrefillArgs& a, int G, int64_t batch, int64_t max_q, hipStream_t s) {
+  const int qpb = 128 / G;
+  dim3 grid(static_cast<unsigned>(ceil_div(max_q, qpb)), static_cast<unsigned>(a.hkv), static_cast<unsigned>(batch));
+  switch (G) {
+    case 1: return dispatch_dk<T, 1>(a, grid, s);
+    case 2: return dispatch_dk<T, 2>(a, grid, s);
+    case 4: return dispatch_dk<T, 4>(a, grid, s);
+    case 8: return dispatch_dk<T, 8>(a, grid, s);
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_prefill_gqa: group size %d (1, 2, 4, 8)", G);
+  }
+}
+
+}  // namespace mojo
+
+using namespace mojo;
+
+extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const void* value_cache,
+                                          const int32_t* cu_q_lens, const int32_t* cu_total_seq_lens,
+                                          const int32_t* block_tables, void* out, int64_t total_tokens, int64_t batch,
+                                          int64_t q_heads, int64_t kv_heads, int64_t head_dim, int64_t block_size,
+                                          int64_t max_blocks_per_seq, int64_t block_table_stride,
+                                          int64_t cache_block_stride, int64_t cache_head_stride,
+                                          int64_t cache_token_stride, int64_t max_q_len_hint, float softmax_scale,
+                                          int layout_abab, int dtype, mojo_stream_t stream) {
+  if (total_tokens == 0) return MOJO_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MOJO_REQUIRE(query && key_cache && value_cache && cu_q_lens && block_tables && out, MOJO_EINVAL,
+               "paged_prefill_gqa: null pointer");
+  MOJO_REQUIRE(q_heads > 0 && kv_heads > 0 && q_heads % kv_heads == 0 && batch >= 0, MOJO_EINVAL,
+               "paged_prefill_gqa: bad head counts Hq=%lld Hkv=%lld", (long long)q_heads, (long long)kv_heads);
+  MOJO_REQUIRE(dtype == MOJO_BF16 || dtype == MOJO_F16, MOJO_EUNSUPPORTED, "paged_prefill_gqa: dtype %d (bf16/fp16 only)", dtype);
+  MOJO_REQUIRE(block_size % 4 == 0, MOJO_EUNSUPPORTED, "paged_prefill_gqa: block_size %lld must be a multiple of 4",
+               (long long)block_size);
+  MOJO_REQUIRE(cache_token_stride % 8 == 0 && cache_head_stride % 8 == 0 && cache_block_stride % 8 == 0 &&
+                   aligned_to(key_cache, 16) && aligned_to(value_cache, 16) && aligned_to(query, 16) && aligned_to(out, 8),
+               MOJO_EUNSUPPORTED, "paged_prefill_gqa: tensors must be 16-byte aligned with 16-byte row strides");
+  MOJO_REQUIRE(batch <= 65535 && kv_heads <= 65535, MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
+  // rows that no workgroup writes (empty sequences, padding tokens) must read as zeros
+  const int64_t eb = 2;
+  if (hipMemsetAsync(out, 0, static_cast<size_t>(total_tokens * q_heads * head_dim * eb), s) != hipSuccess) {
+    set_error("paged_prefill_gqa: memset failed");
+    return MOJO_ELAUNCH;
+  }
+  if (batch == 0) return MOJO_OK;
+  PrefillArgs a;
+  a.q = query; a.kc = key_cache; a.vc = value_cache; a.out = out; a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens;
+  a.tables = block_tables; a.table_stride = block_table_stride; a.c_blk = cache_block_stride;
+  a.c_head = cache_head_stride; a.c_tok = cache_token_stride;
+  a.hq = static_cast<int>(q_heads); a.hkv = static_cast<int>(kv_heads); a.dim = static_cast<int>(head_dim);
+  a.page = static_cast<int>(block_size);
+  a.page_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctzll(block_size) : -1;
+  a.max_pages = static_cast<int>(max_blocks_per_seq);
+  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.abab = layout_abab ? 1 : 0;
+  int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
+  const int G = static_cast<int>(q_heads / kv_heads);
+  return dtype == MOJO_BF16 ? dispatch_g<bf16_t>(a, G, batch, max_q, s) : dispatch_g<f16_t>(a, G, batch, max_q, s);
+}

@@ -1,0 +1,118 @@
+"""GPU parity of MojoPagedPrefillGQA through the C ABI.  Tolerance atol = rtol = 2e-2 — the reference's
+strict bound for this op (mojo_opset/tests/accuracy/operators/test_attention.py:577-582)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+
+pytestmark = pytest.mark.gpu
+ATOL = RTOL = 2e-2
+
+
+def cu(lens):
+    return torch.tensor([0] + list(torch.tensor(lens).cumsum(0).tolist()), dtype=torch.int32)
+
+
+def make_prefill_inputs(q_lens, cached, hq, hkv, d, page, dtype=torch.bfloat16, seed=0, pad_tokens=0):
+    g = torch.Generator().manual_seed(seed)
+    kv_lens = [a + b for a, b in zip(q_lens, cached)]
+    need = [(n + page - 1) // page for n in kv_lens]
+    total = max(sum(need), 1) + 10
+    k = torch.randn(total, hkv, page, d, generator=g).to(dtype)
+    v = torch.randn(total, hkv, page, d, generator=g).to(dtype)
+    table = torch.full((len(q_lens), max(max(need), 1)), -1, dtype=torch.int32)
+    free = torch.randperm(total, generator=g, dtype=torch.int32)
+    at = 0
+    for b, n in enumerate(need):
+        table[b, :n] = free[at: at + n]
+        at += n
+    q = torch.randn(sum(q_lens) + pad_tokens, hq, d, generator=g).to(dtype)
+    return q, k, v, cu(q_lens), table, (cu(kv_lens) if any(cached) else None), kv_lens
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"prefill-{i}") for i, c in enumerate(load_golden("paged_prefill_gqa"))])
+def test_prefill_vectors(case):
+    assert_close_tree(to_cpu(run_hip_case(case)), case["out"], ATOL, RTOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (B, Hq, Hkv, D, max_q, max_cached, page) of the reference (test_attention.py:433-461), lengths drawn below
+    (2, 16, 4, 128, 1024, 0, 32), (2, 16, 4, 96, 1024, 0, 128), (2, 8, 1, 128, 2048, 4096, 128),
+    (2, 8, 1, 128, 1024, 2048, 1024), (2, 8, 1, 128, 0, 0, 1024), (5, 4, 2, 128, 77, 50, 16),
+    (3, 32, 8, 128, 512, 300, 16),
+], ids=["M_BF16", "PADDIM", "LONG_CACHED", "BIGPAGE", "EMPTY", "BUCKET_PAGE16", "MIXTRAL_SHAPE"])
+@pytest.mark.parametrize("layout", ["ABAB", "AABB"])
+def test_prefill_reference_space(cfg, layout):
+    batch, hq, hkv, d, max_q, max_c, page = cfg
+    g = torch.Generator().manual_seed(batch * 1000 + max_q)
+    q_lens = [int(x) for x in (torch.randint(max_q // 2, max_q + 1, (batch,), generator=g) if max_q else torch.zeros(batch))]
+    cached = [int(x) for x in (torch.randint(0, max_c + 1, (batch,), generator=g) if max_c else torch.zeros(batch))]
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hq, hkv, d, page, seed=batch)
+    op = hip_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout=layout)
+    ref = torch_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout=layout)
+    kw = dict(softmax_scale=1.0 / math.sqrt(d), max_q_len=max(q_lens + [0]), max_total_seq_len=max(kv_lens + [0]))
+    if cu_kv is not None:
+        kw["cu_total_seq_lens"] = cu_kv
+    want = ref(q, k, v, cu_q, table, **kw)
+    dkw = {k_: (v_.to(DEV) if isinstance(v_, torch.Tensor) else v_) for k_, v_ in kw.items()}
+    got = op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), **dkw)
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    # without host hints the grid bound falls back to the token count: same numbers
+    dkw.pop("max_q_len"), dkw.pop("max_total_seq_len")
+    got2 = op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), **dkw)
+    assert torch.equal(got, got2)
+
+
+def test_prefill_padding_tokens_and_empty_sequences_are_zero():
+    q, k, v, cu_q, table, cu_kv, _ = make_prefill_inputs([0, 40, 0, 9], [5, 0, 0, 100], 8, 2, 128, 16, pad_tokens=7)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    got = to_cpu(op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), cu_total_seq_lens=cu_kv.to(DEV)))
+    want = torch_cls("MojoPagedPrefillGQA")()(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv)
+    assert torch.count_nonzero(got[49:]) == 0
+    assert_close_tree(got, want, ATOL, RTOL)
+
+
+def test_prefill_fp16_and_contract():
+    q, k, v, cu_q, table, cu_kv, _ = make_prefill_inputs([33, 70], [12, 0], 8, 2, 64, 16, dtype=torch.float16)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    got = op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), cu_total_seq_lens=cu_kv.to(DEV))
+    want = torch_cls("MojoPagedPrefillGQA")()(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv)
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    with pytest.raises(AssertionError):
+        op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.long().to(DEV), table.to(DEV))
+    with pytest.raises(NotImplementedError):
+        hip_cls("MojoPagedPrefillGQA")(is_causal=False)(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV))
+
+
+def test_prefill_full_size_properties():
+    """BASELINE config 3a at full size: 4 x 2048 new tokens over 2048 cached, Hq=32, Hkv=8, D=128, page=16."""
+    q_lens, cached = [2048] * 4, [2048] * 4
+    q, k, v, cu_q, table, cu_kv, _ = make_prefill_inputs(q_lens, cached, 32, 8, 128, 16, seed=11)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    dev = [t.to(DEV) for t in (q, k, v, cu_q, table, cu_kv)]
+    out = op(*dev[:5], cu_total_seq_lens=dev[5], max_q_len=2048, max_total_seq_len=4096)
+    assert torch.isfinite(out.float()).all()
+    # (1) softmax rows are convex weights: constant V comes back unchanged
+    outc = op(dev[0], dev[1], torch.full_like(dev[2], 0.25), dev[3], dev[4], cu_total_seq_lens=dev[5])
+    torch.testing.assert_close(outc.float(), torch.full_like(outc, 0.25).float(), atol=2e-3, rtol=0)
+    # (2) causality: corrupting the last kv position changes only the last query row of each sequence
+    k2, v2 = dev[1].clone(), dev[2].clone()
+    for b in range(4):
+        pid = int(table[b, (4096 - 1) // 16])
+        k2[pid, :, 15] += 3.0
+        v2[pid, :, 15] -= 2.0
+    out2 = op(dev[0], k2, v2, dev[3], dev[4], cu_total_seq_lens=dev[5])
+    same = (out2 == out).flatten(1).all(dim=1)
+    expect_changed = torch.zeros(8192, dtype=torch.bool, device=DEV)
+    expect_changed[2047::2048] = True
+    assert torch.equal(~same, expect_changed)
+    # (3) the oracle on the first 96 and the last 64 query rows of sequence 1
+    ref = torch_cls("MojoPagedPrefillGQA")()
+    for lo, hi in ((0, 96), (2048 - 64, 2048)):
+        n = hi - lo
+        qs = q[2048 + lo: 2048 + hi]
+        want = ref(qs, k, v, cu([n]), table[1:2], cu_total_seq_lens=cu([2048 + hi]))
+        assert_close_tree(to_cpu(out[2048 + lo: 2048 + hi]), want, ATOL, RTOL)
