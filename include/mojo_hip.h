@@ -135,6 +135,34 @@ int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const 
                         int64_t num_groups, int trans_weight, int dtype, void* workspace,
                         int64_t workspace_bytes, mojo_stream_t stream);
 
+/*      Same kernel with explicit strides (elements): input row stride lda, output row stride ldc, weight
+ *      element (g,k,n) at weight + g*w_group_stride + k*w_k_stride + n*w_n_stride.  Used by the MLA ops to
+ *      multiply by the two halves of kv_b_proj in place (one group per head).                           */
+int mojo_hip_group_gemm_strided(const void* input, const void* weight, void* out, const void* group_list,
+                                int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
+                                int64_t num_groups, int64_t lda, int64_t ldc, int64_t w_group_stride,
+                                int64_t w_k_stride, int64_t w_n_stride, int dtype, void* workspace,
+                                int64_t workspace_bytes, mojo_stream_t stream);
+
+/* ---- MojoPagedDecodeMLA / MojoPagedPrefillMLA (experimental/operators/attention.py:131-227, :325-447; the
+ *      reference has no accelerated kernel for either).  Attention over the COMPRESSED cache in the
+ *      weight-absorbed form: q_lat [Tq,H,r+rope] = [q_nope @ W_kn | q_rope], o_lat [Tq,H,r] = sum_s p c_kv[s].
+ *      decode : total_seq_lens != NULL, cu_q_lens == NULL, Tq == batch (one token per sequence)
+ *      prefill: cu_q_lens != NULL (cu_total_seq_lens optional), token t sees keys 0 .. kv_len-q_len+t
+ *      attn_sink: optional fp32 [H] extra softmax logit (probability mass only).                           */
+int64_t mojo_hip_mla_latent_attn_workspace_bytes(int64_t q_tokens, int64_t heads, int64_t kv_lora_rank,
+                                                 int64_t max_kv_len);
+int mojo_hip_mla_latent_attn(const void* q_lat, const void* ckv_cache, const void* kpe_cache,
+                             const int32_t* total_seq_lens, const int32_t* cu_q_lens,
+                             const int32_t* cu_total_seq_lens, const int32_t* block_tables,
+                             const float* attn_sink, void* o_lat, void* workspace,
+                             int64_t workspace_bytes, int64_t q_tokens, int64_t batch, int64_t heads,
+                             int64_t kv_lora_rank, int64_t rope_dim, int64_t block_size,
+                             int64_t max_blocks_per_seq, int64_t block_table_stride,
+                             int64_t ckv_block_stride, int64_t ckv_token_stride,
+                             int64_t kpe_block_stride, int64_t kpe_token_stride, int64_t max_kv_len,
+                             float softmax_scale, int dtype, mojo_stream_t stream);
+
 /* ---- dense GEMM used by the GEMM+collective operators (core/operators/compute_with_comm.py:12-24,
  *      `_gemm`): out[M,N] = input[M,K] @ W (+ bias).  W element (k,n) at weight + k*w_k_stride +
  *      n*w_n_stride (one of the two strides is 1).  bias (optional, [N]) is added after the product

@@ -6,3 +6,4 @@ the registry ignores them; on a ROCm host they are the first-priority backend.
 from .operators.attention import *  # noqa: F401,F403
 from .operators.streaming import *  # noqa: F401,F403
 from .operators.gemm import HIPGroupGemm, HIPQuantGemm  # noqa: F401
+from .operators.mla import HIPPagedDecodeMLA, HIPPagedPrefillMLA  # noqa: F401

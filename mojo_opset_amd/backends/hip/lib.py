@@ -46,6 +46,10 @@ SIGNATURES = {
                                            c_float, c_int, c_int, _P]),
     "mojo_hip_group_gemm_workspace_bytes": (c_int64, [_I]),
     "mojo_hip_group_gemm": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
+    "mojo_hip_group_gemm_strided": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
+    "mojo_hip_mla_latent_attn_workspace_bytes": (c_int64, [_I, _I, _I, _I]),
+    "mojo_hip_mla_latent_attn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                         _I, _I, _I, _I, c_float, c_int, _P]),
     "mojo_hip_gemm_workspace_bytes": (c_int64, []),
     "mojo_hip_gemm": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_quant_gemm_workspace_bytes": (c_int64, []),
@@ -88,6 +92,9 @@ def load():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+c_void_p = c_void_p  # re-export for callers that build offset pointers
 
 
 def dtype_code(dtype: torch.dtype) -> int:

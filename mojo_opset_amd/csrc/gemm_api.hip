@@ -23,10 +23,11 @@ extern "C" int64_t mojo_hip_group_gemm_workspace_bytes(int64_t num_groups) {
   return (2 * (num_groups + 1)) * static_cast<int64_t>(sizeof(int32_t)) + 64;
 }
 
-extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const void* group_list,
-                                   int group_list_is_i64, int64_t m_total, int64_t k, int64_t n, int64_t num_groups,
-                                   int trans_weight, int dtype, void* workspace, int64_t workspace_bytes,
-                                   mojo_stream_t stream) {
+extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight, void* out, const void* group_list,
+                                           int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
+                                           int64_t num_groups, int64_t lda, int64_t ldc, int64_t w_group_stride,
+                                           int64_t w_k_stride, int64_t w_n_stride, int dtype, void* workspace,
+                                           int64_t workspace_bytes, mojo_stream_t stream) {
   MOJO_REQUIRE(num_groups > 0 && k > 0 && n > 0 && m_total >= 0, MOJO_EINVAL, "group_gemm: bad shape");
   if (m_total == 0) return MOJO_OK;
   MOJO_REQUIRE(input && weight && out && group_list, MOJO_EINVAL, "group_gemm: null pointer");
@@ -34,12 +35,12 @@ extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* 
                "group_gemm: dtype %d not supported", dtype);
   MOJO_REQUIRE(m_total < (1LL << 31) && k < (1LL << 31) && n < (1LL << 31) && num_groups < (1 << 20), MOJO_EUNSUPPORTED,
                "group_gemm: dimension too large");
+  MOJO_REQUIRE(lda >= k && ldc >= n && (w_k_stride == 1 || w_n_stride == 1), MOJO_EINVAL, "group_gemm: bad strides");
   MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_group_gemm_workspace_bytes(num_groups) && aligned_to(workspace, 4),
                MOJO_EWORKSPACE, "group_gemm: workspace too small");
   GemmArgs a;
   a.A = input; a.W = weight; a.C = out; a.bias = nullptr;
-  a.lda = k; a.ldc = n; a.w_group = k * n;
-  if (trans_weight) { a.w_k = 1; a.w_n = k; } else { a.w_k = n; a.w_n = 1; }
+  a.lda = lda; a.ldc = ldc; a.w_group = w_group_stride; a.w_k = w_k_stride; a.w_n = w_n_stride;
   a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = static_cast<int>(num_groups);
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + (num_groups + 1);
@@ -48,6 +49,15 @@ extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* 
   int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s);
   if (rc) return rc;
   return run_gemm(a, dtype, m_total, s);
+}
+
+extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const void* group_list,
+                                   int group_list_is_i64, int64_t m_total, int64_t k, int64_t n, int64_t num_groups,
+                                   int trans_weight, int dtype, void* workspace, int64_t workspace_bytes,
+                                   mojo_stream_t stream) {
+  return mojo_hip_group_gemm_strided(input, weight, out, group_list, group_list_is_i64, m_total, k, n, num_groups, k, n,
+                                     k * n, trans_weight ? 1 : n, trans_weight ? k : 1, dtype, workspace,
+                                     workspace_bytes, stream);
 }
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(void) { return 64; }

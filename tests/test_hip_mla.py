@@ -1,0 +1,194 @@
+"""GPU parity of MojoPagedDecodeMLA / MojoPagedPrefillMLA through the C ABI.  Tolerance atol = rtol = 1e-2,
+the reference's bound (mojo_opset/tests/accuracy/operators/test_attention.py:1173-1187, :1254-1257)."""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+
+pytestmark = pytest.mark.gpu
+# The reference's bound for these ops is atol = rtol = 1e-2, but it was never exercised against an accelerated
+# backend (none exists; its test skips).  The golden rounds the decompressed K/V, the scores and the
+# probabilities to bf16, which puts the GOLDEN ITSELF up to ~3e-2 away from the exactly computed result at
+# the magnitudes of these tests (measured: tests/golden paged_mla case 2, |golden - fp64| = 0.030 while the
+# weight-absorbed evaluation is 0.009 away).  Parity is therefore stated as:
+#   (1) |hip - fp64 exact| <= 1e-2 (+1e-2 relative)  — the reference's number, against the true value;
+#   (2) hip is never farther from the exact value than the golden is (plus one bf16 ulp of slack);
+#   (3) |hip - golden| <= 4e-2 (+4e-2 relative)      — the golden's own noise band.
+ATOL = RTOL = 1e-2
+GOLDEN_BAND = 4e-2
+
+
+def _unpage(cache, row, n):
+    page = cache.shape[2]
+    parts = []
+    for j in range((n + page - 1) // page):
+        if int(row[j]) < 0:
+            break
+        parts.append(cache[int(row[j]), 0, : min(page, n - j * page)])
+    return torch.cat(parts) if parts else None
+
+
+def exact_mla(q, ckv, kpe, table, w, sink, h, nope, rope, vd, r, kv_lens, q_off=None, scale=None):
+    """fp64 evaluation of the op's definition (decompress, softmax with optional sink, PV); decode when
+    ``q_off`` is None, else packed causal prefill with ``q_off`` the cumulative query offsets."""
+    dt = torch.float64
+    wd = w.to(dt).view(h, nope + vd, r)
+    scale = 1.0 / math.sqrt(nope + rope) if scale is None else scale
+    out = torch.zeros(q.shape[0], h, vd, dtype=dt)
+    for b, n in enumerate(kv_lens):
+        rows = [b] if q_off is None else list(range(q_off[b], q_off[b + 1]))
+        if n <= 0 or not rows:
+            continue
+        c = _unpage(ckv, table[b], n)
+        pe = _unpage(kpe, table[b], n)
+        if c is None:
+            continue
+        c, pe = c.to(dt), pe.to(dt)
+        k = torch.cat([torch.einsum("sr,hdr->shd", c, wd[:, :nope]), pe[:, None, :].expand(-1, h, -1)], -1)
+        v = torch.einsum("sr,hdr->shd", c, wd[:, nope:])
+        for i, t in enumerate(rows):
+            vis = c.shape[0] if q_off is None else min(c.shape[0], n - len(rows) + i + 1)
+            s = torch.einsum("hd,shd->hs", q[t].to(dt), k[:vis]) * scale
+            if sink is not None:
+                s = torch.cat([s, sink.to(dt)[:, None]], -1)
+            p = torch.softmax(s, -1)
+            if sink is not None:
+                p = p[:, :-1]
+            out[t] = torch.einsum("hs,shd->hd", p, v[:vis])
+    return out
+
+
+def check_mla(got, want_golden, exact):
+    got, want_golden = got.double(), want_golden.double()
+    assert got.shape == exact.shape == want_golden.shape
+    if got.numel() == 0:
+        return
+    torch.testing.assert_close(got, exact, atol=ATOL, rtol=RTOL)                              # (1)
+    err_hip, err_gold = (got - exact).abs().max(), (want_golden - exact).abs().max()
+    assert err_hip <= err_gold + 2.0 ** -8 * exact.abs().max().clamp_min(1.0), (err_hip, err_gold)   # (2)
+    torch.testing.assert_close(got, want_golden, atol=GOLDEN_BAND, rtol=GOLDEN_BAND)           # (3)
+
+
+def cu(lens):
+    return torch.tensor([0] + list(torch.tensor(lens).cumsum(0).tolist()), dtype=torch.int32)
+
+
+def make_mla(lens, h, nope, rope, vd, r, page, sink=False, seed=0, dtype=torch.bfloat16, wscale=0.2):
+    g = torch.Generator().manual_seed(seed)
+    need = [(n + page - 1) // page for n in lens]
+    total = max(sum(need), 1) + 3
+    ckv = torch.randn(total, 1, page, r, generator=g).to(dtype)
+    kpe = torch.randn(total, 1, page, rope, generator=g).to(dtype)
+    ids = torch.randperm(total, generator=g, dtype=torch.int32)
+    table = torch.full((len(lens), max(max(need), 1)), -1, dtype=torch.int32)
+    at = 0
+    for b, n in enumerate(need):
+        table[b, :n] = ids[at: at + n]
+        at += n
+    w = (torch.randn(h * (nope + vd), r, generator=g) * wscale).to(dtype)
+    sk = torch.randn(h, generator=g) if sink else None
+    return ckv, kpe, table, w, sk
+
+
+def build(cls_name, h, nope, rope, vd, r, sink, w, sk, device, dtype=torch.bfloat16, **extra):
+    kind = hip_cls if device == DEV else torch_cls
+    op = kind(cls_name)(h, nope, rope, vd, r, use_attn_sink=sink, **extra).to(dtype).to(device)
+    with torch.no_grad():
+        op.kv_b_proj.copy_(w.to(device))
+        if sink:
+            op.attn_sink.copy_(sk.to(device))
+    return op
+
+
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"mla-{i}-{c['op']}") for i, c in enumerate(load_golden("paged_mla"))])
+def test_mla_vectors(case):
+    got = to_cpu(run_hip_case(case))
+    kw = case["ctor"]["kwargs"]
+    h, nope, rope, vd, r = (kw[k] for k in ("num_heads", "qk_nope_head_dim", "qk_rope_head_dim", "v_head_dim", "kv_lora_rank"))
+    w, sink = case["state"]["kv_b_proj"], case["state"].get("attn_sink")
+    if case["op"] == "MojoPagedDecodeMLA":
+        q, ckv, kpe, lens, table = case["args"]
+        exact = exact_mla(q, ckv, kpe, table, w, sink, h, nope, rope, vd, r, lens.tolist())
+    else:
+        q, ckv, kpe, cu_q, table = case["args"]
+        cu_kv = case["kwargs"]["cu_total_seq_lens"]
+        kv_lens = (cu_kv[1:] - cu_kv[:-1]).tolist()
+        exact = exact_mla(q, ckv, kpe, table, w, sink, h, nope, rope, vd, r, kv_lens, q_off=cu_q.tolist())
+    check_mla(got, case["out"], exact)
+
+
+@pytest.mark.parametrize("cfg", [
+    (4, 16, 96, 32, 128, 64, 256, 64), (2, 8, 64, 32, 64, 32, 128, 32), (3, 8, 64, 32, 64, 32, 0, 32),
+    (2, 128, 128, 64, 128, 512, 700, 16),                  # DeepSeek-V3 dimensions, page 16
+], ids=["REF0", "REF1", "REF_EMPTY", "DEEPSEEK_V3"])
+@pytest.mark.parametrize("sink", [False, True])
+def test_mla_decode_reference_space(cfg, sink):
+    b, h, nope, rope, vd, r, s_max, page = cfg
+    g = torch.Generator().manual_seed(b + h)
+    lens = [int(x) for x in (torch.randint(1, s_max + 1, (b,), generator=g) if s_max else torch.tensor([0, 45, 0][:b]))]
+    ckv, kpe, table, w, sk = make_mla(lens, h, nope, rope, vd, r, page, sink, seed=h, wscale=0.2 if r <= 64 else 0.05)
+    q = torch.randn(b, h, nope + rope, generator=g).to(torch.bfloat16)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    ref = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, "cpu")
+    op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, DEV)
+    want = ref(q, ckv, kpe, lens_t, table)
+    got = op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV))
+    check_mla(to_cpu(got), want, exact_mla(q, ckv, kpe, table, w, sk, h, nope, rope, vd, r, lens))
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 8, 64, 32, 64, 32, 48, 32), (3, 8, 64, 32, 64, 32, 0, 32), (2, 16, 96, 32, 128, 64, 150, 16),
+    (1, 128, 128, 64, 128, 512, 200, 16),
+], ids=["REF0", "REF_EMPTY", "MID", "DEEPSEEK_V3"])
+@pytest.mark.parametrize("sink", [False, True])
+def test_mla_prefill_reference_space(cfg, sink):
+    b, h, nope, rope, vd, r, s_max, page = cfg
+    g = torch.Generator().manual_seed(b * 7 + h)
+    # s_max == 0: the reference's "empty" case — here a mix of empty and short sequences
+    kv_lens = [int(x) for x in (torch.randint(1, s_max + 1, (b,), generator=g) if s_max else torch.tensor([0, 37, 0][:b]))]
+    q_lens = [min(n, 1 + int(torch.randint(0, 40, (1,), generator=g))) for n in kv_lens]
+    ckv, kpe, table, w, sk = make_mla(kv_lens, h, nope, rope, vd, r, page, sink, seed=h + 1, wscale=0.2 if r <= 64 else 0.05)
+    q = torch.randn(sum(q_lens), h, nope + rope, generator=g).to(torch.bfloat16)
+    ref = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, sink, w, sk, "cpu", is_causal=True)
+    op = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, sink, w, sk, DEV, is_causal=True)
+    want = ref(q, ckv, kpe, cu(q_lens), table, cu_total_seq_lens=cu(kv_lens))
+    got = op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV))
+    check_mla(to_cpu(got), want, exact_mla(q, ckv, kpe, table, w, sk, h, nope, rope, vd, r, kv_lens, q_off=cu(q_lens).tolist()))
+
+
+def test_mla_uncast_module_raises_like_the_golden():
+    ckv, kpe, table, w, _ = make_mla([20], 8, 64, 32, 64, 32, 16)
+    op = hip_cls("MojoPagedDecodeMLA")(8, 64, 32, 64, 32).to(DEV)          # kv_b_proj stays fp32 (reference quirk)
+    q = torch.randn(1, 8, 96, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError):
+        op(q, ckv.to(DEV), kpe.to(DEV), torch.tensor([20], dtype=torch.int32, device=DEV), table.to(DEV))
+
+
+def test_mla_decode_full_size_properties():
+    """BASELINE config 5a at full size (B=64, H=128, 128/64/128, r=512, page=16, ctx=4096)."""
+    b, h, nope, rope, vd, r, page, ctx = 64, 128, 128, 64, 128, 512, 16, 4096
+    lens = [ctx] * b
+    ckv, kpe, table, w, _ = make_mla(lens, h, nope, rope, vd, r, page, seed=3, wscale=0.02)
+    g = torch.Generator().manual_seed(9)
+    q = torch.randn(b, h, nope + rope, generator=g).to(torch.bfloat16)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w, None, DEV)
+    dev = [t.to(DEV) for t in (q, ckv, kpe, lens_t, table)]
+    out = op(*dev)
+    assert torch.isfinite(out.float()).all()
+    # the oracle on two whole sequences (the golden decompresses [4096,512] x [512,32768] per sequence)
+    ref = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w, None, "cpu")
+    for i in (0, b - 1):
+        want = ref(q[i: i + 1], ckv, kpe, lens_t[i: i + 1], table[i: i + 1])
+        exact = exact_mla(q[i: i + 1], ckv, kpe, table[i: i + 1], w, None, h, nope, rope, vd, r, [ctx])
+        check_mla(to_cpu(out[i: i + 1]), want, exact)
+    # page relabelling must not change a single bit
+    perm = torch.randperm(ckv.shape[0], generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel())
+    table2 = inv[table.long()].to(torch.int32)
+    out2 = op(dev[0], ckv[perm].to(DEV), kpe[perm].to(DEV), dev[3], table2.to(DEV))
+    assert torch.equal(out, out2)
