@@ -173,6 +173,14 @@ int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void*
                   int64_t w_n_stride, int dtype, void* workspace, int64_t workspace_bytes,
                   mojo_stream_t stream);
 
+/*      Same with row maps {rc, ml, off} (NULL or rc == 0: identity): logical row m reads A row
+ *      (m / rc) * ml + off + m % rc, and likewise for the C row it writes.  One launch can thus consume or
+ *      produce the "c-th sub-chunk of every rank" view of the chunked reduce-scatter / all-gather pipelines. */
+int mojo_hip_gemm_rowmap(const void* input, const void* weight, const void* bias, void* out, int64_t m,
+                         int64_t k, int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride,
+                         int64_t w_n_stride, const int64_t a_map[3], const int64_t c_map[3], int dtype,
+                         void* workspace, int64_t workspace_bytes, mojo_stream_t stream);
+
 /* ---- MojoQuantGemm (core/operators/gemm.py:127-231; the reference's accelerated int8 kernel is
  *      backends/ttx/kernels/ilu/int8_gemm.py:18-66).  out = (A_q @ W_q) * input_scale[m] * weight_scale[n]
  *      input [M,K] and weight ([K,N], or [N,K] when trans_weight) are int8 (MOJO_I8) or OCP fp8-e4m3

@@ -1,0 +1,81 @@
+"""HIP<Op> classes of the GEMM + collective operators: the C-ABI GEMM plugged into `mojo_opset_amd.comm`."""
+from typing import Optional
+
+import torch
+
+from ....comm import GemmEngine, all_gather_gemm, gemm_all2all, gemm_all_reduce, gemm_reduce_scatter
+from ....core.operators.compute_with_comm import (MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllReduce,
+                                                  MojoGemmReduceScatter, is_dist_initialized)
+from .. import lib as L
+
+_ROCM = ["rocm"]
+
+
+class HipGemmEngine(GemmEngine):
+    """`mojo_hip_gemm_rowmap` on the current stream."""
+
+    def __call__(self, x, weight, bias, trans_weight, *, out=None, rows=None, a_map=None, c_map=None):
+        L.require_cuda(x, weight, bias, out)
+        if weight.dim() != 2 or x.dtype != weight.dtype or (bias is not None and bias.dtype != x.dtype):
+            raise NotImplementedError("hip gemm: 2-D weight and one common dtype required")
+        k = x.shape[-1]
+        if trans_weight:
+            assert weight.shape[0] == k, "input K must match weight K"
+            n = weight.shape[1]
+        else:
+            assert weight.shape[1] == k, "input K must match weight K"
+            n = weight.shape[0]
+        if weight.stride(0) != 1 and weight.stride(1) != 1:
+            weight = weight.contiguous()
+        w_k, w_n = (weight.stride(0), weight.stride(1)) if trans_weight else (weight.stride(1), weight.stride(0))
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        rows = x.shape[0] if rows is None else rows
+        if out is None:
+            out = torch.empty(rows, n, dtype=x.dtype, device=x.device)
+        assert out.dim() == 2 and out.shape[1] == n and out.stride(1) == 1 and out.dtype == x.dtype
+        ws = torch.empty(64, dtype=torch.uint8, device=x.device)
+        amap = None if a_map is None else L.strides3(*a_map)
+        cmap = None if c_map is None else L.strides3(*c_map)
+        L.check(L.load().mojo_hip_gemm_rowmap(
+            L.ptr(x), L.ptr(weight), L.ptr(None if bias is None else bias.contiguous()), L.ptr(out), rows, k, n,
+            x.stride(0), out.stride(0), w_k, w_n, amap, cmap, L.dtype_code(x.dtype), L.ptr(ws), ws.numel(),
+            L.stream_of(x)), "hip gemm")
+        return out
+
+
+_ENGINE = HipGemmEngine()
+
+
+def _group_of(op):
+    return op._group() if is_dist_initialized() else None
+
+
+class HIPGemmAllReduce(MojoGemmAllReduce):
+    supported_platforms_list = _ROCM
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return gemm_all_reduce(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self))
+
+
+class HIPAllGatherGemm(MojoAllGatherGemm):
+    supported_platforms_list = _ROCM
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return all_gather_gemm(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self), self.gather_dim)
+
+
+class HIPGemmAll2All(MojoGemmAll2All):
+    supported_platforms_list = _ROCM
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return gemm_all2all(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self),
+                            self.scatter_dim, self.gather_dim)
+
+
+class HIPGemmReduceScatter(MojoGemmReduceScatter):
+    supported_platforms_list = _ROCM
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return gemm_reduce_scatter(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self),
+                                   self.scatter_dim)

@@ -1,0 +1,193 @@
+"""GEMM + collective pipelines for the four ComputeComm operators.
+
+Each op is a local GEMM plus exactly one exchange step over the tensor-parallel group.  The golden
+(`mojo_opset/core/operators/compute_with_comm.py:96-111, :160-176, :234-253, :316-332`) runs them back to
+back: one GEMM, one blocking collective, no overlap.  Here the GEMM is cut into row chunks and the chunk's
+collective is enqueued asynchronously as soon as the chunk is computed — `torch.distributed` (backend
+"nccl" = RCCL) runs it on the process group's own HIP stream, ordered after the GEMM by an event — so the
+xGMI transfer of chunk c overlaps the matrix work of chunk c+1:
+
+    all-reduce      : chunk c of the output rows   -> all_reduce(out[rows_c])            (in place)
+    reduce-scatter  : sub-chunk c of EVERY rank's row block, produced contiguously by the GEMM's A-row map
+                      -> reduce_scatter_tensor(out[rows_c], buf_c)
+    all-gather      : sub-chunk c of every rank's input rows -> all_gather_into_tensor(buf_c, x[rows_c]);
+                      the GEMM on buf_c writes its rows to their final place through the C-row map
+    all-to-all      : one all_to_all_single of the whole product (no accelerated version exists upstream)
+
+The pipelines only orchestrate; the matrix product is delegated to a `GemmEngine` (the hip backend passes
+the C-ABI GEMM; the multi-process CPU tests pass a torch engine over gloo).
+"""
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class GemmEngine:
+    """``out[c_map(m)] = x[a_map(m)] @ W (+ bias)`` for logical rows ``m in [0, rows)``.
+
+    ``a_map`` / ``c_map`` are ``(rc, ml, off)`` triples meaning ``row = (m // rc) * ml + off + m % rc``
+    (``None`` = identity).  ``weight`` is ``[K, N]`` when ``trans_weight`` else ``[N, K]``.
+    """
+
+    def __call__(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], trans_weight: bool, *,
+                 out: Optional[torch.Tensor] = None, rows: Optional[int] = None,
+                 a_map: Optional[Tuple[int, int, int]] = None,
+                 c_map: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+        raise NotImplementedError
+
+    @staticmethod
+    def out_features(weight: torch.Tensor, trans_weight: bool) -> int:
+        return weight.shape[1] if trans_weight else weight.shape[0]
+
+
+def plan_row_chunks(rows: int, max_chunks: Optional[int] = None, min_rows: int = 512) -> List[Tuple[int, int]]:
+    """Split ``rows`` into at most ``max_chunks`` contiguous ranges of >= ``min_rows`` rows (multiples of 256 so
+    every chunk is whole GEMM tiles); ``MOJO_HIP_COMM_CHUNKS`` overrides the chunk count."""
+    if rows <= 0:
+        return []
+    env = os.environ.get("MOJO_HIP_COMM_CHUNKS")
+    want = int(env) if env else (4 if max_chunks is None else max_chunks)
+    want = max(1, min(want, rows // min_rows if rows >= min_rows else 1))
+    step = -(-rows // want)
+    step = -(-step // 256) * 256 if rows >= 256 else step
+    out, lo = [], 0
+    while lo < rows:
+        hi = min(rows, lo + step)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def _group_info(group):
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def _flatten(x: torch.Tensor) -> torch.Tensor:
+    x2 = x.reshape(-1, x.shape[-1])
+    return x2 if x2.stride(-1) == 1 else x2.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+def gemm_all_reduce(engine: GemmEngine, x, weight, bias, trans_weight, group) -> torch.Tensor:
+    """allreduce_sum(x @ W (+ bias)); the bias joins every rank's partial, as in the golden (:106-110)."""
+    n = engine.out_features(weight, trans_weight)
+    x2 = _flatten(x)
+    m = x2.shape[0]
+    out = torch.empty(m, n, dtype=x.dtype, device=x.device)
+    if group is None:
+        engine(x2, weight, bias, trans_weight, out=out)
+        return out.reshape(*x.shape[:-1], n)
+    works = []
+    for lo, hi in plan_row_chunks(m):
+        engine(x2[lo:hi], weight, bias, trans_weight, out=out[lo:hi])
+        works.append(dist.all_reduce(out[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    return out.reshape(*x.shape[:-1], n)
+
+
+def gemm_reduce_scatter(engine: GemmEngine, x, weight, bias, trans_weight, group, scatter_dim: int) -> torch.Tensor:
+    """This rank's ``scatter_dim`` chunk of sum_ranks(x @ W (+ bias))."""
+    n = engine.out_features(weight, trans_weight)
+    if group is None:
+        return engine(_flatten(x), weight, bias, trans_weight).reshape(*x.shape[:-1], n)
+    ws, rank = _group_info(group)
+    out_shape = list(x.shape[:-1]) + [n]
+    sd = scatter_dim % len(out_shape)
+    if out_shape[sd] % ws != 0:
+        raise ValueError(f"reduce_scatter: dimension {sd} of size {out_shape[sd]} is not divisible by world size {ws}")
+    if sd != 0:
+        # not row-blocked in the flattened product: compute it whole, exchange contiguous copies of the chunks
+        y = engine(_flatten(x), weight, bias, trans_weight).reshape(out_shape)
+        chunks = [c.contiguous() for c in y.chunk(ws, dim=sd)]
+        mine = torch.empty_like(chunks[rank])
+        dist.reduce_scatter(mine, chunks, op=dist.ReduceOp.SUM, group=group)
+        return mine
+    x2 = _flatten(x)
+    m = x2.shape[0]
+    ml = m // ws                                   # rows every rank keeps
+    out = torch.empty(ml, n, dtype=x.dtype, device=x.device)
+    works, keep = [], []
+    for lo, hi in plan_row_chunks(ml):
+        rc = hi - lo
+        buf = torch.empty(ws * rc, n, dtype=x.dtype, device=x.device)   # [dest rank][rc rows]
+        engine(x2, weight, bias, trans_weight, out=buf, rows=ws * rc, a_map=(rc, ml, lo))
+        works.append(dist.reduce_scatter_tensor(out[lo:hi], buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        keep.append(buf)
+    for w in works:
+        w.wait()
+    out_shape[0] //= ws
+    return out.reshape(out_shape)
+
+
+def all_gather_gemm(engine: GemmEngine, x, weight, bias, trans_weight, group, gather_dim: int) -> torch.Tensor:
+    """allgather(x, gather_dim) @ W (+ bias)."""
+    n = engine.out_features(weight, trans_weight)
+    if group is None:
+        return engine(_flatten(x), weight, bias, trans_weight).reshape(*x.shape[:-1], n)
+    ws, _ = _group_info(group)
+    gd = gather_dim % x.dim()
+    if gd != 0 or gd == x.dim() - 1:
+        parts = [torch.empty_like(x) for _ in range(ws)]
+        dist.all_gather(parts, x.contiguous(), group=group)
+        full = torch.cat(parts, dim=gd)
+        return engine(_flatten(full), weight, bias, trans_weight).reshape(*full.shape[:-1], n)
+    x2 = _flatten(x)
+    ml, k = x2.shape
+    out = torch.empty(ws * ml, n, dtype=x.dtype, device=x.device)
+    chunks = plan_row_chunks(ml)
+    stages = []
+    for lo, hi in chunks:                          # enqueue every gather first: they run back to back on the comm stream
+        buf = torch.empty(ws * (hi - lo), k, dtype=x.dtype, device=x.device)
+        stages.append((buf, dist.all_gather_into_tensor(buf, x2[lo:hi].contiguous(), group=group, async_op=True)))
+    for (lo, hi), (buf, work) in zip(chunks, stages):
+        work.wait()                                # the GEMM of chunk c overlaps the gathers of chunks c+1..
+        engine(buf, weight, bias, trans_weight, out=out, rows=buf.shape[0], c_map=(hi - lo, ml, lo))
+    shape = list(x.shape[:-1]) + [n]
+    shape[0] *= ws
+    return out.reshape(shape)
+
+
+def gemm_all2all(engine: GemmEngine, x, weight, bias, trans_weight, group, scatter_dim: int, gather_dim: int) -> torch.Tensor:
+    """cat(all_to_all(chunk(x @ W (+ bias), ws, scatter_dim)), gather_dim)."""
+    n = engine.out_features(weight, trans_weight)
+    y = engine(_flatten(x), weight, bias, trans_weight).reshape(*x.shape[:-1], n)
+    if group is None:
+        return y
+    ws, rank = _group_info(group)
+    sd, gd = scatter_dim % y.dim(), gather_dim % y.dim()
+    if y.shape[sd] % ws != 0:
+        raise ValueError(f"all_to_all: dimension {sd} of size {y.shape[sd]} is not divisible by world size {ws}")
+    if sd == 0:
+        recv = torch.empty_like(y)
+        _all_to_all_single(recv, y, group, ws, rank)
+        pieces: Sequence[torch.Tensor] = recv.chunk(ws, dim=0)
+    else:
+        send = [c.contiguous() for c in y.chunk(ws, dim=sd)]
+        pieces = [torch.empty_like(c) for c in send]
+        _all_to_all_list(list(pieces), send, group, ws, rank)
+    return pieces[0] if ws == 1 else torch.cat(list(pieces), dim=gd)
+
+
+def _all_to_all_single(recv, send, group, ws, rank):
+    try:
+        dist.all_to_all_single(recv, send, group=group)
+    except RuntimeError:                           # gloo has no all-to-all: emulate with an all_gather (tests only)
+        everyone = [torch.empty_like(send) for _ in range(ws)]
+        dist.all_gather(everyone, send.contiguous(), group=group)
+        rows = send.shape[0] // ws
+        for src in range(ws):
+            recv[src * rows: (src + 1) * rows] = everyone[src][rank * rows: (rank + 1) * rows]
+
+
+def _all_to_all_list(recv, send, group, ws, rank):
+    try:
+        dist.all_to_all(recv, send, group=group)
+    except RuntimeError:
+        stacked = torch.stack(send)
+        everyone = [torch.empty_like(stacked) for _ in range(ws)]
+        dist.all_gather(everyone, stacked, group=group)
+        for src in range(ws):
+            recv[src].copy_(everyone[src][rank])

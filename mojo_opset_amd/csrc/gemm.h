@@ -18,7 +18,15 @@ struct GemmArgs {
   int K, N, G;
   const int32_t* row_start;  // [G+1]
   const int32_t* tile_start; // [G+1] prefix of ceil(rows_g / BM)
+  // Optional row maps (dense GEMM only; rc == 0 means identity).  Logical row m of the product reads
+  // A row  (m / a_rc) * a_ml + a_off + m % a_rc   and writes C row  (m / c_rc) * c_ml + c_off + m % c_rc.
+  // They let one launch consume / produce the "every rank's c-th sub-chunk" view that the chunked
+  // reduce-scatter and all-gather pipelines exchange, without staging copies.
+  int a_rc = 0, a_ml = 0, a_off = 0;
+  int c_rc = 0, c_ml = 0, c_off = 0;
 };
+
+__host__ __device__ inline int map_row(int m, int rc, int ml, int off) { return rc ? (m / rc) * ml + off + (m % rc) : m; }
 
 constexpr int GEMM_WS_INTS(int G) { return 2 * (G + 1); }
 

@@ -62,9 +62,10 @@ extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* 
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(void) { return 64; }
 
-extern "C" int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void* out, int64_t m, int64_t k,
-                             int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride, int64_t w_n_stride, int dtype,
-                             void* workspace, int64_t workspace_bytes, mojo_stream_t stream) {
+extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const void* bias, void* out, int64_t m,
+                                    int64_t k, int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride,
+                                    int64_t w_n_stride, const int64_t a_map[3], const int64_t c_map[3], int dtype,
+                                    void* workspace, int64_t workspace_bytes, mojo_stream_t stream) {
   MOJO_REQUIRE(k > 0 && n > 0 && m >= 0, MOJO_EINVAL, "gemm: bad shape");
   if (m == 0) return MOJO_OK;
   MOJO_REQUIRE(input && weight && out, MOJO_EINVAL, "gemm: null pointer");
@@ -76,6 +77,14 @@ extern "C" int mojo_hip_gemm(const void* input, const void* weight, const void* 
   a.A = input; a.W = weight; a.C = out; a.bias = bias;
   a.lda = lda; a.ldc = ldc; a.w_group = 0; a.w_k = w_k_stride; a.w_n = w_n_stride;
   a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
+  if (a_map) {
+    MOJO_REQUIRE(a_map[0] >= 0 && a_map[0] < (1LL << 31) && a_map[1] < (1LL << 31) && a_map[2] < (1LL << 31), MOJO_EINVAL, "gemm: bad A row map");
+    a.a_rc = static_cast<int>(a_map[0]); a.a_ml = static_cast<int>(a_map[1]); a.a_off = static_cast<int>(a_map[2]);
+  }
+  if (c_map) {
+    MOJO_REQUIRE(c_map[0] >= 0 && c_map[0] < (1LL << 31) && c_map[1] < (1LL << 31) && c_map[2] < (1LL << 31), MOJO_EINVAL, "gemm: bad C row map");
+    a.c_rc = static_cast<int>(c_map[0]); a.c_ml = static_cast<int>(c_map[1]); a.c_off = static_cast<int>(c_map[2]);
+  }
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -83,4 +92,11 @@ extern "C" int mojo_hip_gemm(const void* input, const void* weight, const void* 
   hipLaunchKernelGGL(dense_prefix_kernel, dim3(1), dim3(64), 0, s, static_cast<int>(m), bm, ws, ws + 2);
   MOJO_CHECK_LAUNCH("gemm(prefix)");
   return run_gemm(a, dtype, m, s);
+}
+
+extern "C" int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void* out, int64_t m, int64_t k,
+                             int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride, int64_t w_n_stride, int dtype,
+                             void* workspace, int64_t workspace_bytes, mojo_stream_t stream) {
+  return mojo_hip_gemm_rowmap(input, weight, bias, out, m, k, n, lda, ldc, w_k_stride, w_n_stride, nullptr, nullptr,
+                              dtype, workspace, workspace_bytes, stream);
 }

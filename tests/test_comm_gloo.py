@@ -1,0 +1,183 @@
+"""world_size-2 CPU tests (gloo) of the GEMM + collective pipelines (`mojo_opset_amd.comm`): the same
+orchestration the hip backend runs over RCCL, driven here by a torch GEMM engine, checked against
+(1) the reference's per-rank vectors (tests/golden/compute_with_comm.pt, captured from the reference running
+over gloo) and (2) the oracle classes running in the same processes."""
+import os
+import socket
+import traceback
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+
+class TorchEngine:
+    """Test-only GEMM engine with the `GemmEngine` call signature (row maps included)."""
+
+    @staticmethod
+    def out_features(weight, trans_weight):
+        return weight.shape[1] if trans_weight else weight.shape[0]
+
+    def __call__(self, x, weight, bias, trans_weight, *, out=None, rows=None, a_map=None, c_map=None):
+        rows = x.shape[0] if rows is None else rows
+        m = torch.arange(rows)
+
+        def mapped(mp_):
+            if mp_ is None:
+                return m
+            rc, ml, off = mp_
+            return (m // rc) * ml + off + m % rc
+
+        y = x[mapped(a_map)] @ (weight if trans_weight else weight.t())
+        if bias is not None:
+            y = y + bias
+        if out is None:
+            assert c_map is None
+            return y
+        out[mapped(c_map)] = y
+        return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, ws, port, fn, args, errq):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=ws)
+        fn(rank, ws, *args)
+        dist.barrier()
+    except Exception:
+        errq.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def run_dist(fn, *args, ws=2):
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, ws, _free_port_once(), fn, args, errq)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    assert not errs, "\n".join(f"[rank {r}]\n{t}" for r, t in errs)
+    assert all(p.exitcode == 0 for p in procs)
+
+
+_PORT = {}
+
+
+def _free_port_once():
+    if "p" not in _PORT:
+        _PORT["p"] = _free_port()
+    return _PORT["p"]
+
+
+@pytest.fixture(autouse=True)
+def _fresh_port():
+    _PORT.clear()
+    yield
+
+
+# ---- worker bodies (module level: spawn pickles them by name) ---------------------------------------------
+def _check_vectors(rank, ws, cases):
+    from mojo_opset_amd import comm
+
+    eng = TorchEngine()
+    group = dist.group.WORLD
+    for case in cases:
+        me = case["ranks"][rank]
+        x, w, want = me["x"], me["w"], me["out"]
+        kw = case["ctor_kwargs"]
+        if case["op"] == "MojoGemmAllReduce":
+            got = comm.gemm_all_reduce(eng, x, w, None, True, group)
+        elif case["op"] == "MojoAllGatherGemm":
+            got = comm.all_gather_gemm(eng, x, w, None, True, group, kw["gather_dim"])
+        elif case["op"] == "MojoGemmReduceScatter":
+            got = comm.gemm_reduce_scatter(eng, x, w, None, True, group, kw["scatter_dim"])
+        else:
+            got = comm.gemm_all2all(eng, x, w, None, True, group, kw["scatter_dim"], kw["gather_dim"])
+        tol = 5e-3 if x.dtype != torch.float32 else 1e-4            # reference bounds: test_compute_with_comm.py:124,164,247
+        torch.testing.assert_close(got.float(), want.float(), atol=tol, rtol=tol, msg=lambda m: f"{case['name']}: {m}")
+
+
+def _check_against_oracle(rank, ws, chunks):
+    import mojo_opset_amd as mo
+    import oracle  # noqa: F401
+    from mojo_opset_amd import comm
+
+    os.environ["MOJO_HIP_COMM_CHUNKS"] = str(chunks)
+    eng = TorchEngine()
+    group = dist.group.WORLD
+    torch.manual_seed(42 + rank)
+    m, k, n = 1024 * ws, 96, 80
+    for trans in (True, False):
+        for with_bias in (False, True):
+            x = torch.randn(m, k)
+            w = torch.randn(k, n) * 0.1 if trans else torch.randn(n, k) * 0.1
+            b = torch.randn(n) if with_bias else None
+            ref = mo.MojoGemmAllReduce.get_backend_impl("torch")(w, b, trans)(x)
+            got = comm.gemm_all_reduce(eng, x, w, b, trans, group)
+            torch.testing.assert_close(got, torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
+            ref = mo.MojoGemmReduceScatter.get_backend_impl("torch")(w, b, trans, scatter_dim=0)(x)
+            got = comm.gemm_reduce_scatter(eng, x, w, b, trans, group, 0)
+            torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)
+            ref = mo.MojoAllGatherGemm.get_backend_impl("torch")(w, b, trans, gather_dim=0)(x)
+            got = comm.all_gather_gemm(eng, x, w, b, trans, group, 0)
+            torch.testing.assert_close(got, torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
+            for sd, gd in ((0, 1), (0, 0), (1, 0)):
+                ref = mo.MojoGemmAll2All.get_backend_impl("torch")(w, b, trans, scatter_dim=sd, gather_dim=gd)(x)
+                got = comm.gemm_all2all(eng, x, w, b, trans, group, sd, gd)
+                torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)
+    # 3-D input, scatter along a non-leading dimension (fallback path)
+    x3 = torch.randn(4, 6 * ws, k)
+    w = torch.randn(k, n) * 0.1
+    ref = mo.MojoGemmReduceScatter.get_backend_impl("torch")(w, None, True, scatter_dim=1)(x3)
+    got = comm.gemm_reduce_scatter(eng, x3, w, None, True, group, 1)
+    torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)
+    ref = mo.MojoAllGatherGemm.get_backend_impl("torch")(w, None, True, gather_dim=1)(x3)
+    got = comm.all_gather_gemm(eng, x3, w, None, True, group, 1)
+    torch.testing.assert_close(got, torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
+
+
+def test_pipelines_reproduce_reference_vectors_over_gloo():
+    run_dist(_check_vectors, load_golden("compute_with_comm"))
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_pipelines_match_oracle_over_gloo(chunks):
+    run_dist(_check_against_oracle, chunks)
+
+
+def test_plan_row_chunks():
+    from mojo_opset_amd.comm import plan_row_chunks
+
+    assert plan_row_chunks(0) == []
+    assert plan_row_chunks(100) == [(0, 100)]
+    c = plan_row_chunks(4096)
+    assert c[0][0] == 0 and c[-1][1] == 4096 and all(a[1] == b[0] for a, b in zip(c, c[1:]))
+    assert all((hi - lo) % 256 == 0 for lo, hi in c[:-1]) and len(c) <= 4
+
+
+def test_identity_without_process_group():
+    from mojo_opset_amd import comm
+
+    eng = TorchEngine()
+    x, w = torch.randn(10, 8), torch.randn(8, 6)
+    for got in (comm.gemm_all_reduce(eng, x, w, None, True, None), comm.gemm_reduce_scatter(eng, x, w, None, True, None, 0),
+                comm.all_gather_gemm(eng, x, w, None, True, None, 0), comm.gemm_all2all(eng, x, w, None, True, None, 0, 1)):
+        torch.testing.assert_close(got, x @ w)
