@@ -160,16 +160,15 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
                      "kernel": "mojo::decode_split_kernel<bf16,4> + decode_merge_kernel (one op call)"},
     }
-    if rank == 0:
-        if not ns.no_extras:
-            try:
-                from benchmarks.extras import run_extras
+    if not ns.no_extras:            # every rank takes part: the GEMM + collective cases contain collectives
+        try:
+            from benchmarks.extras import run_extras
 
-                line["extras"] = run_extras(device, world)
-            except Exception as e:  # extras must never break the headline line
-                line["extras"] = {"error": repr(e)}
-        if world == 1 and not ns.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["extras"] = run_extras(device, world, rank)
+        except Exception as e:      # extras must never break the headline line
+            line["extras"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not ns.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,15 +1,20 @@
-"""Secondary measurements reported under ``extras`` on bench.py's JSON line: every other op of the
-hot path at the BASELINE shapes, as absolute rate and fraction of its roofline (HBM 8 TB/s or bf16
-MFMA 2.5 PFLOP/s dense).  Timing: HIP events on the launch stream, >= 20 launches after warm-up."""
+"""Secondary measurements reported under ``extras`` on bench.py's JSON line: the other ops of the hot path
+at the BASELINE shapes, as absolute rate and fraction of the roofline that bounds them (HBM 8 TB/s, bf16
+MFMA 2.5 PFLOP/s dense, int8 5 POP/s).  Timing: HIP events on the launch stream, >= 10 launches after warm-up.
+With world > 1 every rank runs the GEMM + collective cases together (they contain collectives)."""
+import math
+
 import torch
+import torch.distributed as dist
 
 import mojo_opset_amd as mo
 
 HBM_PEAK_GBS = 8000.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_I8_PEAK_TOPS = 5000.0
 
 
-def _time(fn, iters=20, warmup=3):
+def _time(fn, iters=10, warmup=2):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -26,6 +31,16 @@ def hip(name):
     return getattr(mo, name).get_backend_impl("hip", strict=True)
 
 
+def _mfma(t, flops, peak=MFMA_BF16_PEAK_TFLOPS):
+    tf = flops / t / 1e12
+    return {"us": t * 1e6, "tflops": tf, "frac_of_mfma_peak": tf / peak}
+
+
+def _hbm(t, nbytes):
+    gbs = nbytes / t / 1e9
+    return {"us": t * 1e6, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+
+
 def group_gemm_case(device, m, k, n, groups, trans, split="balanced", dtype=torch.bfloat16):
     x = torch.randn(m, k, device=device, dtype=dtype)
     w = torch.randn(groups, n, k, device=device, dtype=dtype) if trans else torch.randn(groups, k, n, device=device, dtype=dtype)
@@ -37,14 +52,11 @@ def group_gemm_case(device, m, k, n, groups, trans, split="balanced", dtype=torc
     counts[-1] += m - int(counts.sum())
     counts = counts.to(device)
     op = hip("MojoGroupGemm")(w, trans)
-    t = _time(lambda: op(x, counts))
-    tf = 2.0 * m * k * n / t / 1e12
-    return {"us": t * 1e6, "tflops": tf, "frac_of_mfma_peak": tf / MFMA_BF16_PEAK_TFLOPS}
+    return _mfma(_time(lambda: op(x, counts)), 2.0 * m * k * n)
 
 
-def run_extras(device, world):
+def bench_group_gemm(device):
     out = {}
-    gg = {}
     for name, (m, k, n, g, trans, split) in {
         "ref_case_20480x4096x4096_G8_KN": (20480, 4096, 4096, 8, False, "balanced"),
         "mixtral_up_16384x4096x28672_G8_KN": (16384, 4096, 28672, 8, False, "balanced"),
@@ -53,10 +65,182 @@ def run_extras(device, world):
         "mixtral_up_16384_skewed_KN": (16384, 4096, 28672, 8, False, "skewed"),
         "mixtral_up_4096x4096x28672_G8_KN": (4096, 4096, 28672, 8, False, "balanced"),
     }.items():
-        try:
-            gg[name] = group_gemm_case(device, m, k, n, g, trans, split)
-        except Exception as e:
-            gg[name] = {"error": repr(e)}
+        out[name] = group_gemm_case(device, m, k, n, g, trans, split)
         torch.cuda.empty_cache()
-    out["MojoGroupGemm_bf16"] = gg
+    return out
+
+
+def bench_quant_gemm(device):
+    out = {}
+    for qname, qd, peak in (("int8", torch.int8, MFMA_I8_PEAK_TOPS), ("fp8_e4m3", torch.float8_e4m3fn, MFMA_BF16_PEAK_TFLOPS)):
+        for m, k, n in ((4096, 7168, 36864), (4096, 18432, 7168), (128, 7168, 4096)):
+            op = hip("MojoQuantGemm")(k, n, trans_weight=True, quant_dtype=qd, weight_dtype=qd, device=device)
+            if qd == torch.int8:
+                op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=device))
+                x = torch.randint(-127, 128, (m, k), dtype=torch.int8, device=device)
+            else:
+                op.weight.copy_(torch.randn(n, k, device=device).to(qd))
+                x = torch.randn(m, k, device=device).to(qd)
+            op.weight_scale.fill_(0.01)
+            s = torch.rand(m, device=device)
+            out[f"{qname}_{m}x{k}x{n}_NK"] = _mfma(_time(lambda: op(x, s)), 2.0 * m * k * n, peak)
+            del op, x
+            torch.cuda.empty_cache()
+    return out
+
+
+def _paged(device, lens, hkv, d, page, dtype=torch.bfloat16):
+    need = [(n + page - 1) // page for n in lens]
+    total = sum(need) + 4
+    k = torch.randn(total, hkv, page, d, device=device, dtype=dtype)
+    v = torch.randn(total, hkv, page, d, device=device, dtype=dtype)
+    perm = torch.randperm(total, dtype=torch.int32)
+    table = torch.full((len(lens), max(need)), -1, dtype=torch.int32)
+    at = 0
+    for b, n in enumerate(need):
+        table[b, :n] = perm[at: at + n]
+        at += n
+    return k, v, table.to(device)
+
+
+def bench_prefill(device):
+    out = {}
+    hq, hkv, d, page = 32, 8, 128, 16
+    op = hip("MojoPagedPrefillGQA")()
+    for name, (q_lens, cached) in {"4x2048_nocache": ([2048] * 4, [0] * 4), "4x2048_cached2048": ([2048] * 4, [2048] * 4)}.items():
+        kv = [a + b for a, b in zip(q_lens, cached)]
+        k, v, table = _paged(device, kv, hkv, d, page)
+        q = torch.randn(sum(q_lens), hq, d, device=device, dtype=torch.bfloat16)
+        cu = lambda l: torch.tensor([0] + list(torch.tensor(l).cumsum(0).tolist()), dtype=torch.int32, device=device)  # noqa: E731
+        cu_q, cu_kv = cu(q_lens), cu(kv)
+        flops = sum(4.0 * hq * d * (a * b - a * a / 2.0) for a, b in zip(q_lens, kv))
+        t = _time(lambda: op(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv, max_q_len=max(q_lens), max_total_seq_len=max(kv)))
+        out[name] = _mfma(t, flops)
+    return out
+
+
+def bench_mla_decode(device):
+    b, h, nope, rope, vd, r, page, ctx = 64, 128, 128, 64, 128, 512, 16, 4096
+    op = hip("MojoPagedDecodeMLA")(h, nope, rope, vd, r).to(torch.bfloat16).to(device)
+    with torch.no_grad():
+        op.kv_b_proj.copy_(torch.randn_like(op.kv_b_proj) * 0.02)
+    pages = ctx // page
+    total = b * pages + 4
+    ckv = torch.randn(total, 1, page, r, device=device, dtype=torch.bfloat16)
+    kpe = torch.randn(total, 1, page, rope, device=device, dtype=torch.bfloat16)
+    table = torch.randperm(total, dtype=torch.int32)[: b * pages].view(b, pages).to(device)
+    lens = torch.full((b,), ctx, dtype=torch.int32, device=device)
+    q = torch.randn(b, h, nope + rope, device=device, dtype=torch.bfloat16)
+    t = _time(lambda: op(q, ckv, kpe, lens, table))
+    nbytes = b * ctx * (r + rope) * 2 + h * (nope + vd) * r * 2 + 2 * b * h * (nope + rope + vd) * 2
+    res = _hbm(t, nbytes)
+    flops = 2.0 * b * h * ctx * (2 * r + rope) + 2.0 * b * h * r * (nope + vd) * 2
+    res.update({"tflops": flops / t / 1e12, "tokens_per_s": b / t})
+    return {"B64_H128_ctx4096_page16": res}
+
+
+def bench_streaming(device):
+    out = {}
+    rows, d = 2048, 4096
+    for dtype, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        x, r = torch.randn(rows, d, device=device, dtype=dtype), torch.randn(rows, d, device=device, dtype=dtype)
+        norm = hip("MojoResidualAddRMSNorm")(d, 1e-5, "pre", dtype=dtype, device=device)
+        with torch.no_grad():
+            norm.weight.copy_(torch.randn(d))
+        es = x.element_size()
+        out[f"residual_add_rmsnorm_{tag}_2048x4096"] = _hbm(_time(lambda: norm(x, r), 50, 5), 4 * rows * d * es + d * es)
+        act = hip("MojoSwiGLU")()
+        out[f"swiglu_{tag}_2048x4096"] = _hbm(_time(lambda: act(x, r), 50, 5), 3 * rows * d * es)
+    # larger streams (past the 256 MiB MALL) for the bandwidth-bound picture
+    rows = 65536
+    x, r = torch.randn(rows, d, device=device, dtype=torch.bfloat16), torch.randn(rows, d, device=device, dtype=torch.bfloat16)
+    norm = hip("MojoResidualAddRMSNorm")(d, 1e-5, "pre", dtype=torch.bfloat16, device=device)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(d))
+    out["residual_add_rmsnorm_bf16_65536x4096"] = _hbm(_time(lambda: norm(x, r), 20, 3), 4 * rows * d * 2)
+    out["swiglu_bf16_65536x4096"] = _hbm(_time(lambda: hip("MojoSwiGLU")()(x, r), 20, 3), 3 * rows * d * 2)
+    del x, r
+    # RoPE: q [1,32,8192,128] + k [1,8,8192,128] head-first bf16 (the reference's published case)
+    q = torch.randn(1, 32, 8192, 128, device=device, dtype=torch.bfloat16)
+    k = torch.randn(1, 8, 8192, 128, device=device, dtype=torch.bfloat16)
+    cos, sin = torch.randn(8192, 128, device=device), torch.randn(8192, 128, device=device)
+    rope = hip("MojoApplyRoPE")()
+    out["apply_rope_bf16_q32_k8_8192x128"] = _hbm(_time(lambda: rope(q, k, cos, sin, head_first=True), 50, 5),
+                                                  2 * (q.numel() + k.numel()) * 2 + 2 * cos.numel() * 4)
+    # StorePagedKVCache decode step: 64 sequences x 1 token, 8 kv heads x 128, page 16
+    hkv, dd, page, bsz = 8, 128, 16, 64
+    kc = torch.zeros(bsz * 256 + 4, hkv, page, dd, device=device, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    table = torch.randperm(bsz * 256, dtype=torch.int32).view(bsz, 256).to(device)
+    ks, vs = torch.randn(bsz, hkv, dd, device=device, dtype=torch.bfloat16), torch.randn(bsz, hkv, dd, device=device, dtype=torch.bfloat16)
+    ctx = torch.full((bsz,), 4000, dtype=torch.int32, device=device)
+    store = hip("MojoStorePagedKVCache")()
+    out["store_paged_kv_decode_64x8x128"] = _hbm(_time(lambda: store(ks, vs, kc, vc, table, None, ctx), 50, 5), 4 * bsz * hkv * dd * 2)
+    # prefill store: 8192 tokens
+    ks, vs = torch.randn(8192, hkv, dd, device=device, dtype=torch.bfloat16), torch.randn(8192, hkv, dd, device=device, dtype=torch.bfloat16)
+    cu = torch.arange(0, 8192 + 1, 2048, dtype=torch.int32, device=device)
+    ctx4 = torch.zeros(4, dtype=torch.int32, device=device)
+    out["store_paged_kv_prefill_8192x8x128"] = _hbm(_time(lambda: store(ks, vs, kc, vc, table[:4], cu, ctx4), 50, 5), 4 * 8192 * hkv * dd * 2)
+    return out
+
+
+def bench_compute_comm(device, world, rank):
+    """Llama-3-70B row/column-parallel projections at tp = world (config 4).  Every rank reports its own time;
+    rank 0's is kept.  speedup_vs_tp1 compares with the full-K (or full-N) GEMM on one GPU in the same run."""
+    out = {}
+    group = dist.group.WORLD if world > 1 else None
+    m = 4096
+    dt = torch.bfloat16
+    # GemmAllReduce / GemmReduceScatter: down-proj K = 28672 split over ranks, N = 8192
+    k_total, n = 28672, 8192
+    kl = k_total // world
+    x = torch.randn(m, kl, device=device, dtype=dt)
+    w = torch.randn(kl, n, device=device, dtype=dt) * 0.02
+    for name, cls, kw in (("gemm_allreduce", "MojoGemmAllReduce", {}), ("gemm_reducescatter", "MojoGemmReduceScatter", {"scatter_dim": 0})):
+        op = hip(cls)(w, None, True, **kw)
+        t = _time(lambda: op(x), 10, 2)
+        out[f"{name}_M4096_K28672_N8192_tp{world}"] = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k_total * n / t / 1e12,
+                                                       "payload_MB_per_rank": m * n * 2 / 1e6}
+    if world > 1:
+        xf = torch.randn(m, k_total, device=device, dtype=dt)
+        wf = torch.randn(k_total, n, device=device, dtype=dt) * 0.02
+        full = hip("MojoGemmAllReduce")(wf, None, True, process_group=None)
+        from mojo_opset_amd.backends.hip.operators.compute_with_comm import _ENGINE
+        t1 = _time(lambda: _ENGINE(xf, wf, None, True), 10, 2)
+        for name in ("gemm_allreduce", "gemm_reducescatter"):
+            key = f"{name}_M4096_K28672_N8192_tp{world}"
+            out[key]["tp1_full_gemm_us"] = t1 * 1e6
+            out[key]["speedup_vs_tp1"] = t1 * 1e6 / out[key]["us"]
+        del xf, wf, full
+    # AllGatherGemm: x [M/tp, 8192], QKV projection N_total = 10240 split over ranks
+    k2, n_total = 8192, 10240
+    nl = n_total // world
+    xs = torch.randn(m // world, k2, device=device, dtype=dt)
+    w2 = torch.randn(k2, nl, device=device, dtype=dt) * 0.02
+    op = hip("MojoAllGatherGemm")(w2, None, True, gather_dim=0)
+    t = _time(lambda: op(xs), 10, 2)
+    out[f"allgather_gemm_M4096_K8192_N10240_tp{world}"] = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k2 * n_total / t / 1e12}
+    # GemmAll2All (Ulysses-style): x [M/tp, 8192] @ W [8192, 10240] then all-to-all rows -> columns
+    xs2 = torch.randn(max(m // world, world), k2, device=device, dtype=dt)
+    w3 = torch.randn(k2, n_total, device=device, dtype=dt) * 0.02
+    op = hip("MojoGemmAll2All")(w3, None, True, scatter_dim=0, gather_dim=1)
+    t = _time(lambda: op(xs2), 10, 2)
+    out[f"gemm_all2all_M{xs2.shape[0]}_K8192_N10240_tp{world}"] = {"us": t * 1e6, "aggregate_tflops": 2.0 * xs2.shape[0] * world * k2 * n_total / t / 1e12}
+    return out
+
+
+def run_extras(device, world, rank=0):
+    out = {}
+    for name, fn in (("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
+                     ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
+                     ("streaming_ops", bench_streaming)):
+        try:
+            out[name] = fn(device)
+        except Exception as e:  # one failing extra must not hide the others
+            out[name] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    try:
+        out["compute_comm_bf16"] = bench_compute_comm(device, world, rank)
+    except Exception as e:
+        out["compute_comm_bf16"] = {"error": repr(e)}
     return out
