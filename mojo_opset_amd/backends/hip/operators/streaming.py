@@ -118,7 +118,7 @@ class HIPRotaryEmbedding(MojoRotaryEmbedding):
         self.check_index_contract(x, cu_q_lens, total_seq_lens, position_ids)
         L.require_cuda(x, cu_q_lens, total_seq_lens, position_ids)
         dev = x.device
-        d = self.rope_dim
+        d = 2 * self.inv_freq.shape[0]            # rope_dim (the reference's class keeps only inv_freq)
         batch = 0
         if cu_q_lens is not None:
             mode, lead = 2, (x.shape[0],)
