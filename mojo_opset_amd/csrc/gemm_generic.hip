@@ -5,31 +5,72 @@
 
 namespace mojo {
 
+// One 256-thread block: exclusive prefix sums of the per-group row counts (row_start) and of the per-group
+// tile counts (tile_start).  Counts are clamped so that no row beyond m_total is ever addressed.
 template <typename IdxT>
-__global__ void prefix_kernel(const IdxT* counts, int G, int bm, long long m_total, int32_t* row_start,
-                              int32_t* tile_start) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  long long r = 0, t = 0;
-  for (int g = 0; g < G; ++g) {
-    row_start[g] = static_cast<int32_t>(r);
-    tile_start[g] = static_cast<int32_t>(t);
-    long long c = static_cast<long long>(counts[g]);
-    if (c < 0) c = 0;
-    if (r + c > m_total) c = m_total - r;       // never address rows the caller did not provide
-    r += c;
-    t += (c + bm - 1) / bm;
+__global__ __launch_bounds__(256) void prefix_kernel(const IdxT* counts, int G, int bm, long long m_total,
+                                                     int32_t* row_start, int32_t* tile_start) {
+  __shared__ long long s_rows[256];
+  __shared__ long long s_tiles[256];
+  __shared__ long long carry[2];
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry[0] = 0; carry[1] = 0; }
+  __syncthreads();
+  for (int base = 0; base < G; base += 256) {
+    const int g = base + tid;
+    long long c = 0;
+    if (g < G) {
+      c = static_cast<long long>(counts[g]);
+      if (c < 0) c = 0;
+    }
+    s_rows[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                 // inclusive scan of the raw counts
+      const long long v = tid >= off ? s_rows[tid - off] : 0;
+      __syncthreads();
+      s_rows[tid] += v;
+      __syncthreads();
+    }
+    const long long r0 = carry[0];
+    // clamp against m_total: group g covers [min(start, M), min(end, M))
+    long long end = r0 + s_rows[tid], start = end - c;
+    if (end > m_total) end = m_total;
+    if (start > m_total) start = m_total;
+    const long long rows = end - start;
+    s_tiles[tid] = (rows + bm - 1) / bm;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const long long v = tid >= off ? s_tiles[tid - off] : 0;
+      __syncthreads();
+      s_tiles[tid] += v;
+      __syncthreads();
+    }
+    if (g < G) {
+      row_start[g] = static_cast<int32_t>(start);
+      tile_start[g] = static_cast<int32_t>(carry[1] + s_tiles[tid] - (rows + bm - 1) / bm);
+    }
+    __syncthreads();
+    if (tid == 255) {
+      long long e = r0 + s_rows[255];
+      carry[0] = e;                                            // un-clamped running sum keeps later starts consistent
+      carry[1] += s_tiles[255];
+    }
+    __syncthreads();
   }
-  row_start[G] = static_cast<int32_t>(r);
-  tile_start[G] = static_cast<int32_t>(t);
+  if (tid == 0) {
+    long long e = carry[0] > m_total ? m_total : carry[0];
+    row_start[G] = static_cast<int32_t>(e);
+    tile_start[G] = static_cast<int32_t>(carry[1]);
+  }
 }
 
 int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
                         int32_t* tile_start, hipStream_t s) {
   if (counts_are_i64)
-    hipLaunchKernelGGL(prefix_kernel<int64_t>, dim3(1), dim3(64), 0, s, static_cast<const int64_t*>(counts), G, bm,
+    hipLaunchKernelGGL(prefix_kernel<int64_t>, dim3(1), dim3(256), 0, s, static_cast<const int64_t*>(counts), G, bm,
                        static_cast<long long>(m_total), row_start, tile_start);
   else
-    hipLaunchKernelGGL(prefix_kernel<int32_t>, dim3(1), dim3(64), 0, s, static_cast<const int32_t*>(counts), G, bm,
+    hipLaunchKernelGGL(prefix_kernel<int32_t>, dim3(1), dim3(256), 0, s, static_cast<const int32_t*>(counts), G, bm,
                        static_cast<long long>(m_total), row_start, tile_start);
   MOJO_CHECK_LAUNCH("group_prefix");
   return MOJO_OK;

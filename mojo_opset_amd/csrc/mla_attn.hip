@@ -61,7 +61,8 @@ template <int R, int ROPE> struct mla_geom {
   static constexpr int CHS = ((CH8 / 8) % 2 == 0) ? CH8 + 8 : CH8;       // row stride: odd multiple of 128 B
   static constexpr int ROW_BYTES = CHS * 16;
   static constexpr int TILE_BYTES = MLA_KEYS * ROW_BYTES;
-  static constexpr int LDS_BYTES = 2 * TILE_BYTES;
+  static constexpr int TABLE_ENTRIES = 4096;                              // block-table slice cached in LDS
+  static constexpr int LDS_BYTES = 2 * TILE_BYTES + TABLE_ENTRIES * 4;
   static constexpr int NK = (R + ROPE) / 32;                              // k-steps of QK^T
   static constexpr int ND = R / 16;                                        // 16-wide d tiles of O
 };
@@ -113,6 +114,16 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
   }
   const int k_begin = split * a.split_keys;
   const int k_end = min(n_vis, k_begin + a.split_keys);
+  // the page ids of this workgroup's key range, cached in LDS (a dependent global load per staged chunk would
+  // otherwise sit in front of every LDS-DMA)
+  int* s_table = reinterpret_cast<int*>(smem_generic + 2 * GE::TILE_BYTES);
+  const int p_begin = a.page_shift >= 0 ? (k_begin >> a.page_shift) : k_begin / a.page;
+  const int p_count = k_end > k_begin ? ((a.page_shift >= 0 ? ((k_end - 1) >> a.page_shift) : (k_end - 1) / a.page) - p_begin + 1) : 0;
+  const bool lds_table = p_count <= GE::TABLE_ENTRIES;
+  if (lds_table) {
+    for (int i = threadIdx.x; i < p_count; i += NTHREADS) s_table[i] = table[p_begin + i];
+    __syncthreads();
+  }
   const bool active = wave * 16 * NQ < a.heads;            // waves beyond the head count only help staging
   int head[NQ];
 #pragma unroll
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
       int key = k_begin + kt * MLA_KEYS + kl;
       if (key >= k_end) key = k_end - 1;
       const int lp = a.page_shift >= 0 ? (key >> a.page_shift) : key / a.page;
-      int phys = table[lp];
+      int phys = lds_table ? s_table[lp - p_begin] : table[lp];
       if (phys < 0) phys = 0;
       const int slot = key - lp * a.page;
       const T* src = cs < R / 8
@@ -242,9 +253,14 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
           pf[c][kk] = f;
         }
         lsum[c] = lsum[c] * alpha + ps;
+        if (!__all(alpha == 1.0f)) {                       // the running max moved for some row of this wave
 #pragma unroll
-        for (int dt = 0; dt < GE::ND; ++dt) o[c][dt] *= alpha;
+          for (int dt = 0; dt < GE::ND; ++dt) o[c][dt] *= alpha;
+        }
       }
+      // O^T += C_kv^T P^T: per d tile four transposed reads (both 32-key steps) and their MFMAs.  Reads and their
+      // wait live in ONE asm statement: scalar loads share lgkmcnt and return out of order, so a counted wait
+      // across statements is not safe in compiler-scheduled code; latency is covered by the partner wave.
 #pragma unroll
       for (int dt = 0; dt < GE::ND; ++dt) {
         s16x4 v4[4];
