@@ -99,6 +99,10 @@ __device__ __forceinline__ float block_sum(float x, float* smem /* >= NWAVES flo
   return t;
 }
 
+// 2^x as ONE v_exp_f32 (exp2f() expands to a scale / v_exp / v_ldexp / select sequence for denormal results;
+// softmax terms that small contribute nothing, and -inf -> 0 holds for the raw instruction too)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // element traits ----------------------------------------------------------------------------
 template <typename T> struct elt;
 template <> struct elt<float> {

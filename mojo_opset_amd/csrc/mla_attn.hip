@@ -114,16 +114,16 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
   }
   const int k_begin = split * a.split_keys;
   const int k_end = min(n_vis, k_begin + a.split_keys);
-  // the page ids of this workgroup's key range, cached in LDS (a dependent global load per staged chunk would
-  // otherwise sit in front of every LDS-DMA)
+  // A window of TABLE_ENTRIES page ids lives in LDS (refilled when the key loop walks past it): no dependent
+  // global load — and no FLAT load, which hipcc guards with vmcnt(0)/lgkmcnt(0) — sits in front of the LDS-DMA.
   int* s_table = reinterpret_cast<int*>(smem_generic + 2 * GE::TILE_BYTES);
-  const int p_begin = a.page_shift >= 0 ? (k_begin >> a.page_shift) : k_begin / a.page;
-  const int p_count = k_end > k_begin ? ((a.page_shift >= 0 ? ((k_end - 1) >> a.page_shift) : (k_end - 1) / a.page) - p_begin + 1) : 0;
-  const bool lds_table = p_count <= GE::TABLE_ENTRIES;
-  if (lds_table) {
-    for (int i = threadIdx.x; i < p_count; i += NTHREADS) s_table[i] = table[p_begin + i];
+  int win_base = 0;
+  auto fill_window = [&](int p0) {
+    for (int i = threadIdx.x; i < GE::TABLE_ENTRIES; i += NTHREADS) s_table[i] = (p0 + i < a.max_pages) ? table[p0 + i] : -1;
+    win_base = p0;
     __syncthreads();
-  }
+  };
+  fill_window(a.page_shift >= 0 ? (k_begin >> a.page_shift) : k_begin / a.page);
   const bool active = wave * 16 * NQ < a.heads;            // waves beyond the head count only help staging
   int head[NQ];
 #pragma unroll
@@ -141,6 +141,15 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
 
   // ---- staging: the tile is GE::CHS * 64 chunks, laid out linearly; 512 lanes take 512 chunks per round ------
   auto stage = [&](int kt, int buf) {
+    {  // wave-uniform for the whole workgroup
+      const int k_first = k_begin + kt * MLA_KEYS;
+      const int k_last = min(k_first + MLA_KEYS - 1, k_end - 1);
+      const int p_last = a.page_shift >= 0 ? (k_last >> a.page_shift) : k_last / a.page;
+      if (p_last >= win_base + GE::TABLE_ENTRIES) {
+        __syncthreads();
+        fill_window(a.page_shift >= 0 ? (k_first >> a.page_shift) : k_first / a.page);
+      }
+    }
     constexpr int TOTAL = MLA_KEYS * GE::CHS;
     constexpr int ROUNDS = (TOTAL + NTHREADS - 1) / NTHREADS;
 #pragma unroll
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
       int key = k_begin + kt * MLA_KEYS + kl;
       if (key >= k_end) key = k_end - 1;
       const int lp = a.page_shift >= 0 ? (key >> a.page_shift) : key / a.page;
-      int phys = lds_table ? s_table[lp - p_begin] : table[lp];
+      int phys = s_table[lp - win_base];
       if (phys < 0) phys = 0;
       const int slot = key - lp * a.page;
       const T* src = cs < R / 8

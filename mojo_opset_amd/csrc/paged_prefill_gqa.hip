@@ -23,6 +23,8 @@
 // Algorithmic FLOPs (causal): sum_b 4 * Hq * D * (q_b * kv_b - q_b^2 / 2).   Bound: MFMA.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mojo {
@@ -55,7 +57,8 @@ template <> struct pf_mfma<f16_t> {
 
 constexpr int PF_KEYS = 64;                  // keys per tile
 constexpr int PF_TILE_BYTES = PF_KEYS * 256; // 16 KiB per K or V tile
-constexpr int PF_LDS = 4 * PF_TILE_BYTES;    // K0 V0 K1 V1
+constexpr int PF_TABLE = 1024;                // block-table entries cached in LDS
+constexpr int PF_LDS = 4 * PF_TILE_BYTES + PF_TABLE * 4;    // K0 V0 K1 V1 | table slice
 
 template <typename T, int G /* q heads per kv head */, int DK /* head_dim / 32 */>
 __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
@@ -95,6 +98,17 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     if (fn != 0x7fffffff) first_neg_key = fn * a.page;
   }
   const int n_kb = (kv_hi + PF_KEYS - 1) / PF_KEYS;
+  // A window of PF_TABLE page ids of this sequence lives in LDS (refilled when the key loop walks past it), so the
+  // staging code never issues a dependent global load in front of its LDS-DMA — and never a FLAT load, which hipcc
+  // emits for "LDS or global" pointer selects and guards with vmcnt(0)/lgkmcnt(0), draining the whole pipeline.
+  int* s_table = reinterpret_cast<int*>(smem_generic + 4 * PF_TILE_BYTES);
+  int win_base = 0;
+  auto fill_window = [&](int p0) {
+    for (int i = threadIdx.x; i < PF_TABLE; i += 256) s_table[i] = (p0 + i < a.max_pages) ? table[p0 + i] : -1;
+    win_base = p0;
+    __syncthreads();
+  };
+  fill_window(0);
 
   // ---- this wave's rows: two 16-row tiles; row -> (head g, query position) -------------------------------
   int row_pos[2], row_head[2];
@@ -122,13 +136,21 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head;
   const int chunks = a.dim / 8;
   auto stage = [&](int kb, int buf) {
+    {  // wave-uniform for the whole workgroup: all waves stage the same key block
+      const int k_last = min(kb * PF_KEYS + PF_KEYS - 1, kv_hi - 1);
+      const int p_last = a.page_shift >= 0 ? (k_last >> a.page_shift) : k_last / a.page;
+      if (p_last >= win_base + PF_TABLE) {
+        __syncthreads();
+        fill_window(a.page_shift >= 0 ? ((kb * PF_KEYS) >> a.page_shift) : (kb * PF_KEYS) / a.page);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kl = wave * 16 + i * 4 + (lane >> 4);                       // key inside the tile
       int key = kb * PF_KEYS + kl;
       if (key >= kv_hi) key = kv_hi - 1;
       const int lp = a.page_shift >= 0 ? (key >> a.page_shift) : key / a.page;
-      int phys = (lp < a.max_pages) ? table[lp] : 0;
+      int phys = s_table[lp - win_base];
       if (phys < 0) phys = 0;                                               // value is masked later
       const int64_t row = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key - lp * a.page) * a.c_tok;
       const int cp = lane & 15;
@@ -164,7 +186,8 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  for (int kb = 0; kb < n_kb; ++kb) {
+  auto key_block = [&](auto masked_tag, int kb) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int buf = kb & 1;
     if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
     const lds_c* kt = smem + buf * 2 * PF_TILE_BYTES;
@@ -185,93 +208,148 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         s[1][t] = pf_mfma<T>::run(kf, qf[1][ks], s[1][t]);
       }
     }
+    // ---- V^T fragments: transposed reads, 4 per d tile, issued in two batches of DT/2 d tiles.
+    // Each batch is one asm statement (issue) + one wait statement naming every destination (hipcc must not touch
+    // them in between); the waits are lgkmcnt(0) because scalar loads share the counter and return out of order.
+    constexpr int HB = DT / 2 * 4;                       // reads per batch (<= 16)
+    auto issue_v = [&](s16x4 (&dst)[16], int dt0) {
+      // rows 16 apart share row & 7, so the 4 reads of a d tile differ by compile-time offsets; the swizzled chunk
+      // depends on dt: chunk = (2dt + (tp>>1)) ^ ((row & 7) << 1)
+      unsigned ad[4];
+#pragma unroll
+      for (int i = 0; i < DT / 2; ++i) {
+        const int dt = dt0 + i;
+        const int row = 4 * grp + tq;
+        ad[i] = vt + row * 256 + (((2 * dt + (tp >> 1)) ^ ((row & 7) << 1)) * 16) + (tp & 1) * 8;
+      }
+      if constexpr (DT / 2 == 4) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:4096\n\tds_read_b64_tr_b16 %2, %16 offset:8192\n\tds_read_b64_tr_b16 %3, %16 offset:12288\n\t"
+            "ds_read_b64_tr_b16 %4, %17\n\tds_read_b64_tr_b16 %5, %17 offset:4096\n\tds_read_b64_tr_b16 %6, %17 offset:8192\n\tds_read_b64_tr_b16 %7, %17 offset:12288\n\t"
+            "ds_read_b64_tr_b16 %8, %18\n\tds_read_b64_tr_b16 %9, %18 offset:4096\n\tds_read_b64_tr_b16 %10, %18 offset:8192\n\tds_read_b64_tr_b16 %11, %18 offset:12288\n\t"
+            "ds_read_b64_tr_b16 %12, %19\n\tds_read_b64_tr_b16 %13, %19 offset:4096\n\tds_read_b64_tr_b16 %14, %19 offset:8192\n\tds_read_b64_tr_b16 %15, %19 offset:12288"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7]),
+              "=&v"(dst[8]), "=&v"(dst[9]), "=&v"(dst[10]), "=&v"(dst[11]), "=&v"(dst[12]), "=&v"(dst[13]), "=&v"(dst[14]), "=&v"(dst[15])
+            : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+            : "memory");
+      } else if constexpr (DT / 2 == 3) {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %12\n\tds_read_b64_tr_b16 %1, %12 offset:4096\n\tds_read_b64_tr_b16 %2, %12 offset:8192\n\tds_read_b64_tr_b16 %3, %12 offset:12288\n\t"
+            "ds_read_b64_tr_b16 %4, %13\n\tds_read_b64_tr_b16 %5, %13 offset:4096\n\tds_read_b64_tr_b16 %6, %13 offset:8192\n\tds_read_b64_tr_b16 %7, %13 offset:12288\n\t"
+            "ds_read_b64_tr_b16 %8, %14\n\tds_read_b64_tr_b16 %9, %14 offset:4096\n\tds_read_b64_tr_b16 %10, %14 offset:8192\n\tds_read_b64_tr_b16 %11, %14 offset:12288"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7]),
+              "=&v"(dst[8]), "=&v"(dst[9]), "=&v"(dst[10]), "=&v"(dst[11])
+            : "v"(ad[0]), "v"(ad[1]), "v"(ad[2])
+            : "memory");
+      } else {
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:4096\n\tds_read_b64_tr_b16 %2, %8 offset:8192\n\tds_read_b64_tr_b16 %3, %8 offset:12288\n\t"
+            "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:4096\n\tds_read_b64_tr_b16 %6, %9 offset:8192\n\tds_read_b64_tr_b16 %7, %9 offset:12288"
+            : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]), "=&v"(dst[7])
+            : "v"(ad[0]), "v"(ad[1])
+            : "memory");
+      }
+    };
+    auto retire_v = [&](s16x4 (&dst)[16]) {
+      if constexpr (HB == 16) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]), "+v"(dst[7]),
+                       "+v"(dst[8]), "+v"(dst[9]), "+v"(dst[10]), "+v"(dst[11]), "+v"(dst[12]), "+v"(dst[13]), "+v"(dst[14]), "+v"(dst[15])
+                     : : "memory");
+      } else if constexpr (HB == 12) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]), "+v"(dst[7]),
+                       "+v"(dst[8]), "+v"(dst[9]), "+v"(dst[10]), "+v"(dst[11])
+                     : : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]), "+v"(dst[7])
+                     : : "memory");
+      }
+    };
     // lane holds, for query column l15 of each q tile, keys  kb*64 + 16t + 4*grp + r
     const int key0 = kb * PF_KEYS + 4 * grp;
-    const bool need_mask = (kb + 1) * PF_KEYS > min(kv_len, offset + qb * QPB + 1);   // diagonal / tail tile
-    const bool has_hole = (kb + 1) * PF_KEYS > first_neg_key;
+    const bool has_hole = MASKED && (kb + 1) * PF_KEYS > first_neg_key;
     frag pf[2][2];                                                                   // [q tile][32-key step]
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float sc[4][4];
-      float mx = m[qt];
+    // p = 2^(s*scale_log2 - m): the maximum is taken over the RAW scores (scale > 0) and the scale is folded into
+    // one fma per element.  The masked variant (diagonal / tail / hole tiles) is a separate wave-uniform path.
+    auto softmax_tile = [&](int qt) {
+      f32x4 (&sc)[4] = s[qt];
+      float mx = m[qt];                                                              // running max of raw scores
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = s[qt][t][r] * a.scale_log2;
-          const int key = key0 + 16 * t + r;
-          if (has_hole && key >= first_neg_key) v = 0.f;                             // zero K rows: score 0
-          if (need_mask && (key > offset + row_pos[qt] || key >= kv_len)) v = -INFINITY;
-          sc[t][r] = v;
-          mx = fmaxf(mx, v);
+          if constexpr (MASKED) {
+            const int key = key0 + 16 * t + r;
+            if (has_hole && key >= first_neg_key) sc[t][r] = 0.f;                   // zero K rows: score 0
+            if (key > offset + row_pos[qt] || key >= kv_len) sc[t][r] = -INFINITY;
+          }
+          mx = fmaxf(mx, sc[t][r]);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float ms = mx == -INFINITY ? 0.f : mx;
-      const float alpha = exp2f(m[qt] - ms);
+      const float ms = (mx == -INFINITY ? 0.f : mx) * a.scale_log2;
+      const float alpha = fast_exp2(m[qt] * a.scale_log2 - ms);
       m[qt] = mx;
       float ps = 0.f;
-      float p[4][4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[t][r] = exp2f(sc[t][r] - ms);
-          ps += p[t][r];
-          if (has_hole && key0 + 16 * t + r >= first_neg_key) p[t][r] = 0.f;        // zero V rows: no contribution
-        }
-      lsum[qt] = lsum[qt] * alpha + ps;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
-      // P^T operand of 32-key step kk: k-slot j<4 -> key tile 2kk reg j, j>=4 -> key tile 2kk+1 reg j-4
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         frag f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          f[r] = static_cast<T>(p[2 * kk][r]);
-          f[4 + r] = static_cast<T>(p[2 * kk + 1][r]);
+          float p0 = fast_exp2(fmaf(sc[2 * kk][r], a.scale_log2, -ms));
+          float p1 = fast_exp2(fmaf(sc[2 * kk + 1][r], a.scale_log2, -ms));
+          ps += p0 + p1;
+          if constexpr (MASKED) {                                                    // zero V rows: no contribution
+            if (has_hole && key0 + 32 * kk + r >= first_neg_key) p0 = 0.f;
+            if (has_hole && key0 + 32 * kk + 16 + r >= first_neg_key) p1 = 0.f;
+          }
+          f[r] = static_cast<T>(p0);
+          f[4 + r] = static_cast<T>(p1);
         }
         pf[qt][kk] = f;
       }
-    }
+      lsum[qt] = lsum[qt] * alpha + ps;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+      }
+    };
+    softmax_tile(0);
+    softmax_tile(1);
 
-    // ---- O^T += V^T P^T : per d tile, two 32-key steps ---------------------------------------------------------
+    // ---- O^T += V^T P^T -------------------------------------------------------------------------------------------
+    auto pv_batch = [&](const s16x4 (&src)[16], int dt0) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      s16x4 v4[4];                                                                   // [kk][first/second 4 keys]
-      {
-        unsigned addr[4];
+      for (int i = 0; i < DT / 2; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            const int key_row = kk * 32 + hf * 16 + 4 * grp + tq;
-            const int chunk = (2 * dt + (tp >> 1)) ^ ((key_row & 7) << 1);
-            addr[kk * 2 + hf] = vt + key_row * 256 + chunk * 16 + (tp & 1) * 8;
-          }
-        asm volatile(
-            "ds_read_b64_tr_b16 %0, %4\n\t"
-            "ds_read_b64_tr_b16 %1, %5\n\t"
-            "ds_read_b64_tr_b16 %2, %6\n\t"
-            "ds_read_b64_tr_b16 %3, %7\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : "=&v"(v4[0]), "=&v"(v4[1]), "=&v"(v4[2]), "=&v"(v4[3])
-            : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3])
-            : "memory");
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const s16x8 both = {v4[kk * 2][0], v4[kk * 2][1], v4[kk * 2][2], v4[kk * 2][3],
-                            v4[kk * 2 + 1][0], v4[kk * 2 + 1][1], v4[kk * 2 + 1][2], v4[kk * 2 + 1][3]};
-        const frag vf = __builtin_bit_cast(frag, both);
-        o[0][dt] = pf_mfma<T>::run(vf, pf[0][kk], o[0][dt]);
-        o[1][dt] = pf_mfma<T>::run(vf, pf[1][kk], o[1][dt]);
-      }
+        for (int kk = 0; kk < 2; ++kk) {
+          const s16x4 lo = src[i * 4 + kk * 2], hi = src[i * 4 + kk * 2 + 1];
+          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const frag vf = __builtin_bit_cast(frag, both);
+          o[0][dt0 + i] = pf_mfma<T>::run(vf, pf[0][kk], o[0][dt0 + i]);
+          o[1][dt0 + i] = pf_mfma<T>::run(vf, pf[1][kk], o[1][dt0 + i]);
+        }
+    };
+    {
+      s16x4 vb[16];                                      // reuses the registers the scores just vacated
+      issue_v(vb, 0);
+      retire_v(vb);
+      pv_batch(vb, 0);
+      issue_v(vb, DT / 2);
+      retire_v(vb);
+      pv_batch(vb, DT / 2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile landed (issued a whole tile ago)
     __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
-  }
+  };
+  // leading key blocks that every row of this workgroup sees completely need no masking at all; the diagonal /
+  // tail / hole blocks run the masked variant.  Two loops, so neither carries the other's state.
+  const int n_full = min(min(kv_len, offset + qb * QPB + 1), first_neg_key) / PF_KEYS;
+  int kb_i = 0;
+  for (; kb_i < n_full; ++kb_i) key_block(std::false_type{}, kb_i);
+  for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, kb_i);
 
   // ---- finish: reduce the row sums over the 4 lane groups, normalise, store ----------------------------------
 #pragma unroll
