@@ -350,7 +350,8 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
 //   * PV is software-pipelined in batches of 4 d tiles (16 transposed reads per asm statement): batch b+1 is in
 //     flight while the 8 MFMAs of batch b run; the counted lgkmcnt wait is safe because the loop body contains no
 //     scalar loads (checked in the generated ISA: tests/test_isa_invariants.py).
-template <typename T>
+// ABL: timing-only ablations (wrong results): 1 = no PV, 2 = no QK^T, 3 = stage only the first tile
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
   typedef typename mla_mfma<T>::frag frag;
   constexpr int R = 512, ROPE = 64, NK = 18, ND = 32, WAVES = 4, HPB = 64;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
     win_base = p0;
     __syncthreads();
   };
-  auto page_of = [&](int key) { return a.page_shift >= 0 ? (key >> a.page_shift) : key / a.page; };
+  auto page_of = [&](int key) { return key >> a.page_shift; };   // power-of-two pages only (dispatch guarantees it)
   fill_window(page_of(k_begin));
 
   const int head0 = hb * HPB + wave * 16;
@@ -432,15 +433,23 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
     }
     lds_m* ta = smem + buf * TILE;
     lds_m* tb = ta + A_BYTES;
-    // region A: wave w stages rows w, w+4, ...: one instruction per row, page id wave-uniform
+    // region A: wave w stages rows w, w+4, ...: one instruction per row.  Lane i < 16 looks up the page of row
+    // w + 4i (ONE LDS round trip for all 16 rows); each row's page id then comes out of that vector with
+    // v_readlane, so page id, slot and row address are wave-uniform scalars.  Page sizes are powers of two here
+    // (other sizes take the generic kernel).
+    const int mask = a.page - 1;
+    int my_phys;
+    {
+      const int key_l = min(k_first + wave + 4 * (lane & 15), k_end - 1);
+      my_phys = s_table[(key_l >> a.page_shift) - win_base];
+      if (my_phys < 0) my_phys = 0;
+    }
 #pragma unroll
     for (int i = 0; i < MLA_KEYS / WAVES; ++i) {
       const int row = i * WAVES + wave;
       const int key = min(k_first + row, k_end - 1);
-      const int lp = page_of(key);
-      int phys = __builtin_amdgcn_readfirstlane(s_table[lp - win_base]);
-      if (phys < 0) phys = 0;
-      const T* src = ckv + static_cast<int64_t>(phys) * a.ckv_blk + static_cast<int64_t>(key - lp * a.page) * a.ckv_tok;
+      const int phys = __builtin_amdgcn_readlane(my_phys, i);
+      const T* src = ckv + static_cast<int64_t>(phys) * a.ckv_blk + static_cast<int64_t>(key & mask) * a.ckv_tok;
       const int cs = lane ^ ((row & 7) << 1);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + cs * 8),
                                        (__attribute__((address_space(3))) void*)(ta + row * 1024), 16, 0, 0);
@@ -451,11 +460,10 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
       const int rb = (wave * 2 + j) * 8;
       const int row = rb + (lane >> 3);
       const int key = min(k_first + row, k_end - 1);
-      const int lp = page_of(key);
-      int phys = s_table[lp - win_base];
+      int phys = s_table[(key >> a.page_shift) - win_base];
       if (phys < 0) phys = 0;
       const int cs = (lane & 7) ^ (row & 7);
-      const T* src = kpe + static_cast<int64_t>(phys) * a.kpe_blk + static_cast<int64_t>(key - lp * a.page) * a.kpe_tok + cs * 8;
+      const T* src = kpe + static_cast<int64_t>(phys) * a.kpe_blk + static_cast<int64_t>(key & mask) * a.kpe_tok + cs * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(tb + rb * 128), 16, 0, 0);
     }
@@ -487,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
   }
   for (int kt = 0; kt < n_kt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_kt) stage(kt + 1, buf ^ 1);
+    if (kt + 1 < n_kt && ABL != 3) stage(kt + 1, buf ^ 1);
     if (active) {
       const lds_m* tl = smem + buf * TILE;
       // ---- S^T = K_lat Q_lat^T -------------------------------------------------------------------------------
@@ -495,6 +503,7 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (ABL == 2) { s[t][0] = qf[t][0]; continue; }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           const frag kf = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(tl + ka[ks & 3] + t * 16384 + (ks >> 2) * 256);
@@ -574,10 +583,12 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
 #define MLA512_STEP2(J)                                                                                               \
       MLA512_ISSUE(vb, (J) + 1); MLA512_RETIRE(va, 8); MLA512_PV(va, (J));                                            \
       MLA512_ISSUE(va, (J) + 2); MLA512_RETIRE(vb, 8); MLA512_PV(vb, (J) + 1);
+      if constexpr (ABL != 1) {
       MLA512_ISSUE(va, 0);
       MLA512_STEP2(0) MLA512_STEP2(2) MLA512_STEP2(4) MLA512_STEP2(6) MLA512_STEP2(8) MLA512_STEP2(10) MLA512_STEP2(12)
       MLA512_ISSUE(vb, 15); MLA512_RETIRE(va, 8); MLA512_PV(va, 14);
       MLA512_RETIRE(vb, 0); MLA512_PV(vb, 15);
+      } else { o[0][0] += pf[0][0] + pf[1][1]; }
 #undef MLA512_STEP2
 #undef MLA512_ISSUE
 #undef MLA512_RETIRE
@@ -672,11 +683,11 @@ static int launch_mla(const MlaArgs& a, hipStream_t s) {
 
 template <typename T>
 static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
-  if (r == 512 && rope == 64) {
+  if (r == 512 && rope == 64 && a.page_shift >= 0) {
     constexpr int LDS = 2 * (MLA_KEYS * 1024 + MLA_KEYS * 128) + 2048 * 4;
-    auto* fn = mla512_kernel<T>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); done = true; }
+    static const int abl = [] { const char* e = getenv("MOJO_HIP_MLA_ABLATE"); return e ? atoi(e) : 0; }();
+    void (*fn)(MlaArgs) = abl == 1 ? mla512_kernel<T, 1> : abl == 2 ? mla512_kernel<T, 2> : abl == 3 ? mla512_kernel<T, 3> : mla512_kernel<T, 0>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int head_blocks = (a.heads + 63) / 64;
     hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), LDS, s, a);
     MOJO_CHECK_LAUNCH("mla512");
