@@ -87,12 +87,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % n_dev)
+    device = torch.device("cuda", local_rank % n_dev)
     if dist_on:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        # "nccl" is RCCL on ROCm.  MOJO_BENCH_DIST_BACKEND=gloo exists only to dry-run the multi-process control
+        # flow on a single-GPU box (several ranks on one device, which RCCL refuses).
+        backend = os.environ.get("MOJO_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import mojo_opset_amd as mo
 
@@ -123,7 +130,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if dist_on:
-        t = torch.tensor([wall], device=device, dtype=torch.float64)
+        t = torch.tensor([wall], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 

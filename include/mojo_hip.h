@@ -185,8 +185,9 @@ int mojo_hip_gemm_rowmap(const void* input, const void* weight, const void* bias
  *      backends/ttx/kernels/ilu/int8_gemm.py:18-66).  out = (A_q @ W_q) * input_scale[m] * weight_scale[n]
  *      input [M,K] and weight ([K,N], or [N,K] when trans_weight) are int8 (MOJO_I8) or OCP fp8-e4m3
  *      (MOJO_F8E4M3, an extension: no reference implementation, parity unpinned); input_scale fp32 [M];
- *      weight_scale bf16 [N]; out_dtype in {f32, f16, bf16}.                                          */
-int64_t mojo_hip_quant_gemm_workspace_bytes(void);
+ *      weight_scale bf16 [N]; out_dtype in {f32, f16, bf16}.  Decode-sized M is cut along K into slices
+ *      whose raw accumulators go to the workspace and are summed in a fixed order (deterministic).          */
+int64_t mojo_hip_quant_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n);
 int mojo_hip_quant_gemm(const void* input, const void* weight, const float* input_scale,
                         const void* weight_scale, void* out, int64_t m, int64_t k, int64_t n,
                         int trans_weight, int quant_dtype, int out_dtype, void* workspace,

@@ -80,8 +80,9 @@ class HIPQuantGemm(MojoQuantGemm):
         s_in = input_scale.reshape(-1).to(torch.float32).contiguous()
         s_w = self.weight_scale.to(torch.bfloat16).contiguous()
         out = torch.empty(m, n, dtype=self.output_dtype, device=x.device)
-        ws = torch.empty(64, dtype=torch.uint8, device=x.device)
-        L.check(L.load().mojo_hip_quant_gemm(L.ptr(x), L.ptr(w), L.ptr(s_in), L.ptr(s_w), L.ptr(out), m, k, n,
+        lib = L.load()
+        ws = torch.empty(lib.mojo_hip_quant_gemm_workspace_bytes(m, k, n), dtype=torch.uint8, device=x.device)
+        L.check(lib.mojo_hip_quant_gemm(L.ptr(x), L.ptr(w), L.ptr(s_in), L.ptr(s_w), L.ptr(out), m, k, n,
                                              1 if self.trans_weight else 0, L.dtype_code(x.dtype),
                                              L.dtype_code(self.output_dtype), L.ptr(ws), ws.numel(), L.stream_of(x)),
                 "HIPQuantGemm")

@@ -24,6 +24,12 @@ struct GemmArgs {
   // reduce-scatter and all-gather pipelines exchange, without staging copies.
   int a_rc = 0, a_ml = 0, a_off = 0;
   int c_rc = 0, c_ml = 0, c_off = 0;
+  // Optional split-K (dense problems with few output tiles, e.g. decode-sized M): the K range is cut into `splitk`
+  // slices, slice s writes its raw fp32 / int32 accumulators to slab[s][M][N]; a finalize kernel sums the slices
+  // in a fixed order (deterministic) and applies the epilogue.
+  int splitk = 1;
+  void* slab = nullptr;
+  int slab_rows = 0;
 };
 
 __host__ __device__ inline int map_row(int m, int rc, int ml, int off) { return rc ? (m / rc) * ml + off + (m % rc) : m; }

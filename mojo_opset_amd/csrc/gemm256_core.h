@@ -122,7 +122,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   // ---- which tile ------------------------------------------------------------------------------------
   const int n_tiles = (a.N + BN - 1) / BN;
   const int m_tiles = a.tile_start[a.G];
-  const int total = m_tiles * n_tiles;
+  const int tiles_mn = m_tiles * n_tiles;
+  const int total = tiles_mn * a.splitk;
   const int bid = blockIdx.x;
   if (bid >= total) return;
   int tile;
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
+  const int kslice = tile / tiles_mn;                // split-K slice (0 when splitk == 1)
+  tile -= kslice * tiles_mn;
   int mi, ni;
   {  // panel-major order: panels of PANEL n-tiles; inside a panel m-tile by m-tile
     const int full_panels = n_tiles / PANEL, rem = n_tiles - full_panels * PANEL;
@@ -156,7 +159,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   const int m0 = a.row_start[g] + (mi - a.tile_start[g]) * BM;
   const int m_end = a.row_start[g + 1];              // exclusive; m0 < m_end by construction
   const int n0 = ni * BN;
-  const int nkt = a.K / BK;
+  const int nkt_all = a.K / BK;
+  const int kt0 = static_cast<int>(static_cast<int64_t>(nkt_all) * kslice / a.splitk);
+  const int nkt = static_cast<int>(static_cast<int64_t>(nkt_all) * (kslice + 1) / a.splitk) - kt0;   // K-tiles of this slice
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     for (int h = 0; h < 2; ++h) {
       int m = m0 + h * 128 + wave * 16 + row;
       if (m >= m_end) m = m_end - 1;                 // rows past the group: re-read a valid row, never stored
-      srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off)) * a.lda) * EB + chunk * 16;
+      srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(kt0) * KT_BYTES;
     }
   }
   const char* srcW[2];
@@ -219,7 +224,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     w_step = static_cast<int64_t>(BK) * a.w_k;
   }
 
-  // stage half-tile `which` (0:A0 1:A1 2:W0 3:W1) of K-tile kt into buffer buf
+#pragma unroll
+  for (int h = 0; h < 2; ++h) srcW[h] += static_cast<int64_t>(kt0) * w_step;
+  // stage half-tile `which` (0:A0 1:A1 2:W0 3:W1) of K-tile kt (relative to this slice) into buffer buf
   auto stage = [&](int which, int kt, int buf) {
     if (kt >= nkt) kt = nkt - 1;                    // keep the vmcnt bookkeeping uniform at the tail
     lds_char* dst = smem + buf * KTILE_BYTES + which * HALF_BYTES + wave * 2048;
@@ -256,7 +263,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   // N-major W ([K,N]): transposed reads.  hipcc drains vmcnt(0) in front of the ds_read_tr builtins (it
   // cannot prove the read independent of the LDS-DMA writes in flight), which serialises the pipeline;
   // so the reads are issued from inline asm and retired by an explicit lgkmcnt wait that names every
-  // destination register (the compiler may not touch them in between).
+  // destination register (the compiler may not touch them in between).  Outputs are EARLY-CLOBBER: a destination
+  // that shares a register with an address operand is overwritten (asynchronously) while later reads of the same
+  // statement still need the address — observed as wrong tiles in the tail K-tile of odd K-tile counts.
   struct TrRegs { i32x2 r[8]; };                                   // [j][ks][first | second 8 bytes of K]
   const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
   // EB == 2: block (kb, nb) at (kb*8+nb)*256, kb = ks*4 + grp; lane 4q+p -> stored row q (+4), cols 4p
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
           "ds_read_b64_tr_b16 %5, %9 offset:256\n\t"
           "ds_read_b64_tr_b16 %6, %8 offset:8448\n\t"
           "ds_read_b64_tr_b16 %7, %9 offset:8448"
-          : "=v"(t.r[0]), "=v"(t.r[1]), "=v"(t.r[2]), "=v"(t.r[3]), "=v"(t.r[4]), "=v"(t.r[5]), "=v"(t.r[6]), "=v"(t.r[7])
+          : "=&v"(t.r[0]), "=&v"(t.r[1]), "=&v"(t.r[2]), "=&v"(t.r[3]), "=&v"(t.r[4]), "=&v"(t.r[5]), "=&v"(t.r[6]), "=&v"(t.r[7])
           : "v"(a0), "v"(a1)
           : "memory");
     } else {
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
           "ds_read_b64_tr_b8 %5, %9 offset:1024\n\t"
           "ds_read_b64_tr_b8 %6, %9 offset:8192\n\t"
           "ds_read_b64_tr_b8 %7, %9 offset:9216"
-          : "=v"(t.r[0]), "=v"(t.r[1]), "=v"(t.r[2]), "=v"(t.r[3]), "=v"(t.r[4]), "=v"(t.r[5]), "=v"(t.r[6]), "=v"(t.r[7])
+          : "=&v"(t.r[0]), "=&v"(t.r[1]), "=&v"(t.r[2]), "=&v"(t.r[3]), "=&v"(t.r[4]), "=&v"(t.r[5]), "=&v"(t.r[6]), "=&v"(t.r[7])
           : "v"(a0), "v"(a1)
           : "memory");
     }
@@ -397,6 +406,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue ---------------------------------------------------------------------------------------
+  if (a.splitk > 1) {                                  // raw accumulators of this K slice -> slab[kslice][m][n]
+    acc_t* slab = static_cast<acc_t*>(a.slab);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int m = m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
+      if (m >= m_end) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + (lane >> 4) * 4;
+        if (n + 4 <= a.N) slab[((static_cast<int64_t>(kslice) * a.slab_rows + m) * a.N + n) / 4] = acc[mt][nt];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
@@ -431,7 +454,7 @@ inline bool gemm256_layout_ok(const GemmArgs& a, int eb) {
 template <typename P, typename Epi>
 inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
   const int64_t n_tiles = ceil_div(a.N, BN);
-  const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles;   // upper bound; surplus blocks exit
+  const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles * a.splitk;   // upper bound; surplus blocks exit
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
   if (a.w_n == 1) {
     auto* fn = gemm256_kernel<P, true, Epi>;

@@ -32,6 +32,7 @@ def test_group_gemm_vectors(case):
 @pytest.mark.parametrize("counts,k,n", [
     ([256], 64, 256), ([256], 128, 256), ([512, 256], 256, 512), ([300, 0, 17, 1000, 255, 1], 512, 768),
     ([100], 64, 96), ([700, 700], 1024, 1024 + 64), ([2560] * 3, 4096, 512),
+    ([300], 192, 512), ([300], 320, 512), ([513, 7], 448, 264), ([64], 704, 256),      # odd numbers of K-tiles
 ])
 def test_group_gemm_integer_data_is_exact(trans, dtype, counts, k, n):
     """Asymmetric integer operands: every product and partial sum is exact in fp32, so the MFMA tiling,
