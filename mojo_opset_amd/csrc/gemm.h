@@ -27,6 +27,7 @@ struct GemmArgs {
   // Optional split-K (dense problems with few output tiles, e.g. decode-sized M): the K range is cut into `splitk`
   // slices, slice s writes its raw fp32 / int32 accumulators to slab[s][M][N]; a finalize kernel sums the slices
   // in a fixed order (deterministic) and applies the epilogue.
+  int ablate = 0;            // timing-only: 1 = skip the C stores (MOJO_HIP_GEMM_ABLATE)
   int splitk = 1;
   void* slab = nullptr;
   int slab_rows = 0;

@@ -424,6 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
     if (m >= m_end) continue;
+    if (a.ablate == 1 && m != m0) continue;
     epi.row_begin(m);
     const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off);
 #pragma unroll

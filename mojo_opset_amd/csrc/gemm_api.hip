@@ -1,4 +1,6 @@
 // C ABI of the grouped and dense GEMM entry points: argument checks, kernel choice, prefix launch.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace mojo {
@@ -11,6 +13,8 @@ __global__ void dense_prefix_kernel(int m, int bm, int32_t* row_start, int32_t* 
 }
 
 static int run_gemm(GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
+  static const int abl = [] { const char* e = getenv("MOJO_HIP_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+  a.ablate = abl;
   if (gemm_mfma256_ok(a, dtype)) return launch_gemm_mfma256(a, dtype, m_total, s);
   return launch_gemm_generic(a, dtype, m_total, s);
 }
