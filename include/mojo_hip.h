@@ -136,23 +136,29 @@ int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const 
                         int64_t workspace_bytes, mojo_stream_t stream);
 
 /*      Same kernel with explicit strides (elements): input row stride lda, output row stride ldc, weight
- *      element (g,k,n) at weight + g*w_group_stride + k*w_k_stride + n*w_n_stride.  Used by the MLA ops to
- *      multiply by the two halves of kv_b_proj in place (one group per head).                           */
+ *      element (g,k,n) at weight + g*w_group_stride + k*w_k_stride + n*w_n_stride, and optional row maps
+ *      {rc, ml, off, mul} (NULL = identity): logical row m reads input row (m/rc)*ml + off + (m%rc)*mul and
+ *      writes the output row given by c_map.  Used by the MLA ops to multiply by the two halves of kv_b_proj in
+ *      place, one group per head, reading/writing token-major [T,H,*] tensors directly (rc=T, ml=1, mul=H).  */
 int mojo_hip_group_gemm_strided(const void* input, const void* weight, void* out, const void* group_list,
                                 int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
                                 int64_t num_groups, int64_t lda, int64_t ldc, int64_t w_group_stride,
-                                int64_t w_k_stride, int64_t w_n_stride, int dtype, void* workspace,
+                                int64_t w_k_stride, int64_t w_n_stride, const int64_t a_map[4],
+                                const int64_t c_map[4], int dtype, void* workspace,
                                 int64_t workspace_bytes, mojo_stream_t stream);
 
 /* ---- MojoPagedDecodeMLA / MojoPagedPrefillMLA (experimental/operators/attention.py:131-227, :325-447; the
  *      reference has no accelerated kernel for either).  Attention over the COMPRESSED cache in the
- *      weight-absorbed form: q_lat [Tq,H,r+rope] = [q_nope @ W_kn | q_rope], o_lat [Tq,H,r] = sum_s p c_kv[s].
+ *      weight-absorbed form: q_lat [Tq,H,r(+rope)] = [q_nope @ W_kn (| q_rope)], o_lat [Tq,H,r] = sum_s p c_kv[s].
+ *      q_lat rows are q_lat_stride elements apart; the rope part is read from q_rope (row stride q_rope_stride)
+ *      when q_rope != NULL, else from q_lat columns r.. .
  *      decode : total_seq_lens != NULL, cu_q_lens == NULL, Tq == batch (one token per sequence)
  *      prefill: cu_q_lens != NULL (cu_total_seq_lens optional), token t sees keys 0 .. kv_len-q_len+t
  *      attn_sink: optional fp32 [H] extra softmax logit (probability mass only).                           */
 int64_t mojo_hip_mla_latent_attn_workspace_bytes(int64_t q_tokens, int64_t heads, int64_t kv_lora_rank,
                                                  int64_t max_kv_len);
-int mojo_hip_mla_latent_attn(const void* q_lat, const void* ckv_cache, const void* kpe_cache,
+int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride, const void* q_rope, int64_t q_rope_stride,
+                             const void* ckv_cache, const void* kpe_cache,
                              const int32_t* total_seq_lens, const int32_t* cu_q_lens,
                              const int32_t* cu_total_seq_lens, const int32_t* block_tables,
                              const float* attn_sink, void* o_lat, void* workspace,

@@ -46,10 +46,10 @@ SIGNATURES = {
                                            c_float, c_int, c_int, _P]),
     "mojo_hip_group_gemm_workspace_bytes": (c_int64, [_I]),
     "mojo_hip_group_gemm": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
-    "mojo_hip_group_gemm_strided": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
+    "mojo_hip_group_gemm_strided": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_int, _P, _I, _P]),
     "mojo_hip_mla_latent_attn_workspace_bytes": (c_int64, [_I, _I, _I, _I]),
-    "mojo_hip_mla_latent_attn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
-                                         _I, _I, _I, _I, c_float, c_int, _P]),
+    "mojo_hip_mla_latent_attn": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
+                                         _I, _I, _I, _I, _I, _I, c_float, c_int, _P]),
     "mojo_hip_gemm_workspace_bytes": (c_int64, []),
     "mojo_hip_gemm": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_gemm_rowmap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_int, _P, _I, _P]),
@@ -116,6 +116,10 @@ def stream_of(t: torch.Tensor):
 
 def strides3(*vals):
     return _I64x3(*vals)
+
+
+def ints4(*vals):
+    return (c_int64 * 4)(*vals)
 
 
 def check(status: int, what: str):

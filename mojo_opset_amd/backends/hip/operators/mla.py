@@ -11,18 +11,32 @@ from .. import lib as L
 _ROCM = ["rocm"]
 
 
-def _per_head_gemm(x_hm: torch.Tensor, proj: torch.Tensor, heads: int, rows: int, k: int, n: int, w_off: int,
-                   w_group: int, w_k: int, w_n: int) -> torch.Tensor:
-    """``out[h, i, :] = x_hm[h, i, :] @ W[h]`` for W[h] a strided sub-block of ``proj`` (one GEMM group per head)."""
-    out = torch.empty(heads * rows, n, dtype=x_hm.dtype, device=x_hm.device)
-    counts = torch.full((heads,), rows, dtype=torch.int32, device=x_hm.device)
+_COUNTS = {}
+
+
+def _uniform_counts(heads: int, rows: int, device) -> torch.Tensor:
+    key = (heads, rows, str(device))
+    t = _COUNTS.get(key)
+    if t is None:
+        if len(_COUNTS) > 64:
+            _COUNTS.clear()
+        t = _COUNTS[key] = torch.full((heads,), rows, dtype=torch.int32, device=device)
+    return t
+
+
+def _per_head_gemm(x: torch.Tensor, lda: int, out: torch.Tensor, proj: torch.Tensor, heads: int, rows: int, k: int,
+                   n: int, w_off: int, w_group: int, w_k: int, w_n: int) -> None:
+    """``out[t, h, :n] = x[t, h, :k] @ W[h]`` for token-major ``x`` / ``out`` and W[h] a strided sub-block of
+    ``proj``: one GEMM group per head, whose logical row h*rows + t is mapped onto storage row t*heads + h, so neither
+    operand is transposed in memory."""
     lib = L.load()
-    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(heads), dtype=torch.uint8, device=x_hm.device)
+    counts = _uniform_counts(heads, rows, x.device)
+    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(heads), dtype=torch.uint8, device=x.device)
     w_ptr = L.c_void_p(proj.data_ptr() + w_off * proj.element_size())
-    L.check(lib.mojo_hip_group_gemm_strided(L.ptr(x_hm), w_ptr, L.ptr(out), L.ptr(counts), 0, heads * rows, k, n, heads,
-                                            k, n, w_group, w_k, w_n, L.dtype_code(x_hm.dtype), L.ptr(ws), ws.numel(),
-                                            L.stream_of(x_hm)), "hip mla projection")
-    return out.view(heads, rows, n)
+    row_map = L.ints4(rows, 1, 0, heads)
+    L.check(lib.mojo_hip_group_gemm_strided(L.ptr(x), w_ptr, L.ptr(out), L.ptr(counts), 0, heads * rows, k, n, heads,
+                                            lda, n, w_group, w_k, w_n, row_map, row_map, L.dtype_code(x.dtype),
+                                            L.ptr(ws), ws.numel(), L.stream_of(x)), "hip mla projection")
 
 
 def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *, total_seq_lens=None, cu_q_lens=None,
@@ -47,10 +61,14 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     if tq == 0:
         return torch.zeros(0, heads, vdim, dtype=query.dtype, device=dev)
 
-    # 1) absorb W_kn into the query:  q_lat = [q_nope @ W_kn[h] | q_rope]
-    q_hm = query[..., :nope].transpose(0, 1).contiguous()                          # [H, Tq, nope]
-    q_abs = _per_head_gemm(q_hm, proj, heads, tq, nope, r, 0, (nope + vdim) * r, r, 1)   # W_kn[h]: [nope, r] (k rows)
-    q_lat = torch.cat([q_abs.transpose(0, 1), query[..., nope:]], dim=-1).contiguous()   # [Tq, H, r + rope]
+    # 1) absorb W_kn into the query:  q_abs[t, h] = q_nope[t, h] @ W_kn[h]   (W_kn[h]: [nope, r], k rows)
+    if query.stride(2) != 1 or query.stride(1) != qk or query.stride(0) != heads * qk:
+        query = query.contiguous()
+    q_abs = torch.empty(tq, heads, r, dtype=query.dtype, device=dev)
+    _per_head_gemm(query, qk, q_abs, proj, heads, tq, nope, r, 0, (nope + vdim) * r, r, 1)
+    q_rope, q_rope_ld = query[..., nope:], qk                                      # read in place by the kernel
+    if nope % 8 or qk % 8:
+        q_rope, q_rope_ld = q_rope.contiguous(), rope
 
     # 2) attention over the compressed cache
     tables = block_tables if block_tables.stride(1) == 1 else block_tables.contiguous()
@@ -62,7 +80,7 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     sink = getattr(op, "attn_sink", None)
     sink = None if sink is None else sink.detach().to(torch.float32).contiguous()
     L.check(lib.mojo_hip_mla_latent_attn(
-        L.ptr(q_lat), L.ptr(ckv_cache), L.ptr(kpe_cache),
+        L.ptr(q_abs), r, L.ptr(q_rope), q_rope_ld, L.ptr(ckv_cache), L.ptr(kpe_cache),
         L.ptr(None if total_seq_lens is None else total_seq_lens.contiguous()),
         L.ptr(None if cu_q_lens is None else cu_q_lens.contiguous()),
         L.ptr(None if cu_total_seq_lens is None else cu_total_seq_lens.contiguous()),
@@ -70,10 +88,10 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
         tables.stride(0), ckv_cache.stride(0), ckv_cache.stride(2), kpe_cache.stride(0), kpe_cache.stride(2), max_len,
         scale, L.dtype_code(query.dtype), L.stream_of(query)), "hip mla attention")
 
-    # 3) out[h] = o_lat[h] @ W_v[h]^T      (W_v[h]: rows nope.. of head h's block, stored [v, r] = [N, K])
-    o_hm = o_lat.transpose(0, 1).contiguous()                                      # [H, Tq, r]
-    out = _per_head_gemm(o_hm, proj, heads, tq, r, vdim, nope * r, (nope + vdim) * r, 1, r)
-    return out.transpose(0, 1).contiguous()
+    # 3) out[t, h] = o_lat[t, h] @ W_v[h]^T      (W_v[h]: rows nope.. of head h's block, stored [v, r] = [N, K])
+    out = torch.empty(tq, heads, vdim, dtype=query.dtype, device=dev)
+    _per_head_gemm(o_lat, r, out, proj, heads, tq, r, vdim, nope * r, (nope + vdim) * r, 1, r)
+    return out
 
 
 class HIPPagedDecodeMLA(MojoPagedDecodeMLA):

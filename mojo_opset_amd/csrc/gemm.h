@@ -18,12 +18,13 @@ struct GemmArgs {
   int K, N, G;
   const int32_t* row_start;  // [G+1]
   const int32_t* tile_start; // [G+1] prefix of ceil(rows_g / BM)
-  // Optional row maps (dense GEMM only; rc == 0 means identity).  Logical row m of the product reads
-  // A row  (m / a_rc) * a_ml + a_off + m % a_rc   and writes C row  (m / c_rc) * c_ml + c_off + m % c_rc.
-  // They let one launch consume / produce the "every rank's c-th sub-chunk" view that the chunked
-  // reduce-scatter and all-gather pipelines exchange, without staging copies.
-  int a_rc = 0, a_ml = 0, a_off = 0;
-  int c_rc = 0, c_ml = 0, c_off = 0;
+  // Optional row maps (rc == 0 means identity).  Logical row m of the product reads
+  // A row  (m / a_rc) * a_ml + a_off + (m % a_rc) * a_mul   and writes the C row given by the c_* quadruple.
+  // They let one launch consume / produce the "every rank's c-th sub-chunk" view that the chunked reduce-scatter
+  // and all-gather pipelines exchange, and the head-major <-> token-major views of the MLA projections
+  // (rc = tokens, ml = 1, mul = heads), without staging copies.
+  int a_rc = 0, a_ml = 0, a_off = 0, a_mul = 1;
+  int c_rc = 0, c_ml = 0, c_off = 0, c_mul = 1;
   // Optional split-K (dense problems with few output tiles, e.g. decode-sized M): the K range is cut into `splitk`
   // slices, slice s writes its raw fp32 / int32 accumulators to slab[s][M][N]; a finalize kernel sums the slices
   // in a fixed order (deterministic) and applies the epilogue.
@@ -33,7 +34,7 @@ struct GemmArgs {
   int slab_rows = 0;
 };
 
-__host__ __device__ inline int map_row(int m, int rc, int ml, int off) { return rc ? (m / rc) * ml + off + (m % rc) : m; }
+__host__ __device__ inline int map_row(int m, int rc, int ml, int off, int mul = 1) { return rc ? (m / rc) * ml + off + (m % rc) * mul : m; }
 
 constexpr int GEMM_WS_INTS(int G) { return 2 * (G + 1); }
 

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     for (int h = 0; h < 2; ++h) {
       int m = m0 + h * 128 + wave * 16 + row;
       if (m >= m_end) m = m_end - 1;                 // rows past the group: re-read a valid row, never stored
-      srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(kt0) * KT_BYTES;
+      srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(kt0) * KT_BYTES;
     }
   }
   const char* srcW[2];
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     if (m >= m_end) continue;
     if (a.ablate == 1 && m != m0) continue;
     epi.row_begin(m);
-    const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off);
+    const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + (lane >> 4) * 4;

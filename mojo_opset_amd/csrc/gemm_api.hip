@@ -30,7 +30,8 @@ extern "C" int64_t mojo_hip_group_gemm_workspace_bytes(int64_t num_groups) {
 extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight, void* out, const void* group_list,
                                            int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
                                            int64_t num_groups, int64_t lda, int64_t ldc, int64_t w_group_stride,
-                                           int64_t w_k_stride, int64_t w_n_stride, int dtype, void* workspace,
+                                           int64_t w_k_stride, int64_t w_n_stride, const int64_t a_map[4],
+                                           const int64_t c_map[4], int dtype, void* workspace,
                                            int64_t workspace_bytes, mojo_stream_t stream) {
   MOJO_REQUIRE(num_groups > 0 && k > 0 && n > 0 && m_total >= 0, MOJO_EINVAL, "group_gemm: bad shape");
   if (m_total == 0) return MOJO_OK;
@@ -46,6 +47,8 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
   a.A = input; a.W = weight; a.C = out; a.bias = nullptr;
   a.lda = lda; a.ldc = ldc; a.w_group = w_group_stride; a.w_k = w_k_stride; a.w_n = w_n_stride;
   a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = static_cast<int>(num_groups);
+  if (a_map) { a.a_rc = static_cast<int>(a_map[0]); a.a_ml = static_cast<int>(a_map[1]); a.a_off = static_cast<int>(a_map[2]); a.a_mul = static_cast<int>(a_map[3]); }
+  if (c_map) { a.c_rc = static_cast<int>(c_map[0]); a.c_ml = static_cast<int>(c_map[1]); a.c_off = static_cast<int>(c_map[2]); a.c_mul = static_cast<int>(c_map[3]); }
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + (num_groups + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -60,8 +63,8 @@ extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* 
                                    int trans_weight, int dtype, void* workspace, int64_t workspace_bytes,
                                    mojo_stream_t stream) {
   return mojo_hip_group_gemm_strided(input, weight, out, group_list, group_list_is_i64, m_total, k, n, num_groups, k, n,
-                                     k * n, trans_weight ? 1 : n, trans_weight ? k : 1, dtype, workspace,
-                                     workspace_bytes, stream);
+                                     k * n, trans_weight ? 1 : n, trans_weight ? k : 1, nullptr, nullptr, dtype,
+                                     workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(void) { return 64; }

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs a) {
       for (int i = threadIdx.x; i < GT * GK; i += 256) {
         const int r = i / GK, kk = i % GK;
         const int m = m0 + r, k = k0 + kk;
-        sa[kk][r] = (m < m_end && k < a.K) ? elt<T>::to_f(A[static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off)) * a.lda + k]) : 0.f;
+        sa[kk][r] = (m < m_end && k < a.K) ? elt<T>::to_f(A[static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda + k]) : 0.f;
         const int kk2 = i / GT, c = i % GT;
         const int n = n0 + c, k2 = k0 + kk2;
         sb[kk2][c] = (n < a.N && k2 < a.K) ? elt<T>::to_f(W[static_cast<int64_t>(k2) * a.w_k + static_cast<int64_t>(n) * a.w_n]) : 0.f;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs a) {
         if (n >= a.N) continue;
         T o = elt<T>::from_f(acc[i][j]);
         if (bias) o = elt<T>::from_f(elt<T>::to_f(o) + elt<T>::to_f(bias[n]));
-        C[static_cast<int64_t>(map_row(m, a.c_rc, a.c_ml, a.c_off)) * a.ldc + n] = o;
+        C[static_cast<int64_t>(map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n] = o;
       }
     }
   }

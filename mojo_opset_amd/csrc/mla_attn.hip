@@ -27,7 +27,9 @@ namespace mojo {
 typedef __attribute__((address_space(3))) char lds_m;
 
 struct MlaArgs {
-  const void* q_lat;        // [Tq, H, r + rope]
+  const void* q_lat;        // [Tq, H, r (+ rope)], rows q_stride elements apart
+  const void* q_rope;       // rope part of the query, rows q_rope_stride apart (may point into q_lat)
+  int64_t q_stride, q_rope_stride;
   const void* ckv;          // [N, 1, page, r]
   const void* kpe;          // [N, 1, page, rope]
   void* o_lat;              // [Tq, H, r]  storage dtype (final) ...
@@ -134,9 +136,14 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
   frag qf[NQ][GE::NK];
 #pragma unroll
   for (int c = 0; c < NQ; ++c) {
-    const T* qp = static_cast<const T*>(a.q_lat) + (static_cast<int64_t>(tile) * a.heads + head[c]) * (R + ROPE) + grp * 8;
+    const int64_t qrow = static_cast<int64_t>(tile) * a.heads + head[c];
+    const T* qp = static_cast<const T*>(a.q_lat) + qrow * a.q_stride;
+    const T* qr = static_cast<const T*>(a.q_rope) + qrow * a.q_rope_stride;
 #pragma unroll
-    for (int ks = 0; ks < GE::NK; ++ks) qf[c][ks] = *reinterpret_cast<const frag*>(qp + ks * 32);
+    for (int ks = 0; ks < GE::NK; ++ks) {
+      const int e = ks * 32 + grp * 8;
+      qf[c][ks] = *reinterpret_cast<const frag*>(e < R ? qp + e : qr + (e - R));
+    }
   }
 
   // ---- staging: the tile is GE::CHS * 64 chunks, laid out linearly; 512 lanes take 512 chunks per round ------
@@ -414,9 +421,11 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
 
   frag qf[NK];
   {
-    const T* qp = static_cast<const T*>(a.q_lat) + (static_cast<int64_t>(tile) * a.heads + head) * (R + ROPE) + grp * 8;
+    const int64_t qrow = static_cast<int64_t>(tile) * a.heads + head;
+    const T* qp = static_cast<const T*>(a.q_lat) + qrow * a.q_stride + grp * 8;
+    const T* qr = static_cast<const T*>(a.q_rope) + qrow * a.q_rope_stride + grp * 8;
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks) qf[ks] = *reinterpret_cast<const frag*>(qp + ks * 32);
+    for (int ks = 0; ks < NK; ++ks) qf[ks] = *reinterpret_cast<const frag*>(ks * 32 < R ? qp + ks * 32 : qr + (ks * 32 - R));
   }
 
   // ---- staging ----------------------------------------------------------------------------------------------
@@ -725,7 +734,8 @@ extern "C" int64_t mojo_hip_mla_latent_attn_workspace_bytes(int64_t q_tokens, in
   return q_tokens * sp * heads * (kv_lora_rank + 2) * static_cast<int64_t>(sizeof(float)) + 64;
 }
 
-extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, const void* ckv_cache, const void* kpe_cache,
+extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride, const void* q_rope,
+                                        int64_t q_rope_stride, const void* ckv_cache, const void* kpe_cache,
                                         const int32_t* total_seq_lens, const int32_t* cu_q_lens,
                                         const int32_t* cu_total_seq_lens, const int32_t* block_tables,
                                         const float* attn_sink, void* o_lat, void* workspace, int64_t workspace_bytes,
@@ -741,7 +751,8 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, const void* ckv_cache
   MOJO_REQUIRE(dtype == MOJO_BF16 || dtype == MOJO_F16, MOJO_EUNSUPPORTED, "mla_latent_attn: dtype %d (bf16/fp16 only)", dtype);
   MOJO_REQUIRE(heads >= 1 && heads <= 128, MOJO_EUNSUPPORTED, "mla_latent_attn: heads %lld (1..128)", (long long)heads);
   MOJO_REQUIRE(ckv_token_stride % 8 == 0 && kpe_token_stride % 8 == 0 && ckv_block_stride % 8 == 0 && kpe_block_stride % 8 == 0 &&
-                   aligned_to(ckv_cache, 16) && aligned_to(kpe_cache, 16) && aligned_to(q_lat, 16) && aligned_to(o_lat, 8),
+                   aligned_to(ckv_cache, 16) && aligned_to(kpe_cache, 16) && aligned_to(q_lat, 16) && aligned_to(o_lat, 8) && q_lat_stride % 8 == 0 &&
+                   (!q_rope || (aligned_to(q_rope, 16) && q_rope_stride % 8 == 0)),
                MOJO_EUNSUPPORTED, "mla_latent_attn: tensors must be 16-byte aligned with 16-byte row strides");
   MOJO_REQUIRE(q_tokens < (1 << 30), MOJO_EUNSUPPORTED, "mla_latent_attn: too many query tokens");
   const int64_t eb = 2;
@@ -750,7 +761,10 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, const void* ckv_cache
     return MOJO_ELAUNCH;
   }
   MlaArgs a;
-  a.q_lat = q_lat; a.ckv = ckv_cache; a.kpe = kpe_cache; a.o_lat = o_lat;
+  a.q_lat = q_lat; a.q_stride = q_lat_stride;
+  if (q_rope) { a.q_rope = q_rope; a.q_rope_stride = q_rope_stride; }
+  else { a.q_rope = static_cast<const char*>(q_lat) + kv_lora_rank * 2; a.q_rope_stride = q_lat_stride; }
+  a.ckv = ckv_cache; a.kpe = kpe_cache; a.o_lat = o_lat;
   a.seq_lens = total_seq_lens; a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens; a.tables = block_tables; a.sink = attn_sink;
   a.table_stride = block_table_stride; a.ckv_blk = ckv_block_stride; a.ckv_tok = ckv_token_stride;
   a.kpe_blk = kpe_block_stride; a.kpe_tok = kpe_token_stride;
