@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/mojo_hip.h"
 
 namespace mojo {
@@ -136,6 +139,17 @@ __device__ __forceinline__ T vget(const typename vec_of<T, N>::type& v, int i) {
 template <typename T, int N>
 __device__ __forceinline__ void vset(typename vec_of<T, N>::type& v, int i, T x) {
   if constexpr (N == 1) v = x; else v[i] = x;
+}
+
+// compile-time unrolled loop: f(std::integral_constant<int, I>{}) for I = 0..N-1 (inline-asm "i" operands need
+// constant expressions, which a `#pragma unroll` loop variable is not)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
 }
 
 }  // namespace mojo

@@ -344,6 +344,17 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
   }
 }
 
+// K-fragment batch B of the r = 512 kernel's QK^T: key tile B/3, k-steps 6*(B%3) .. +5 (k-steps 16, 17 are k_pe)
+template <int B, int I = 0>
+__device__ __forceinline__ void mla512_k_issue(u32x4 (&dst)[6], const unsigned (&kav)[4], const unsigned (&kbv)[2]) {
+  constexpr int t = B / 3, ks = 6 * (B % 3) + I;
+  if constexpr (ks < 16)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kav[ks & 3]), "i"(t * 16384 + (ks >> 2) * 256) : "memory");
+  else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kbv[ks - 16]), "i"(t * 2048) : "memory");
+  if constexpr (I + 1 < 6) mla512_k_issue<B, I + 1>(dst, kav, kbv);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // DeepSeek-V3 geometry (r = 512, rope = 64): dedicated kernel.
 //   * 4 waves x 16 heads = 64 heads per workgroup (two workgroups per token for H = 128, placed on one XCD so the
@@ -414,6 +425,7 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
   };
   auto page_of = [&](int key) { return key >> a.page_shift; };   // power-of-two pages only (dispatch guarantees it)
   fill_window(page_of(k_begin));
+  const unsigned table_u32 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_m*)smem_generic)) + 2 * TILE;
 
   const int head0 = hb * HPB + wave * 16;
   const bool active = head0 < a.heads;
@@ -426,57 +438,73 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
     const T* qr = static_cast<const T*>(a.q_rope) + qrow * a.q_rope_stride + grp * 8;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) qf[ks] = *reinterpret_cast<const frag*>(ks * 32 < R ? qp + ks * 32 : qr + (ks * 32 - R));
+    // Retire the query loads HERE, in a way the compiler's wait-count pass can see: otherwise it carries them as
+    // "maybe still pending" into the main loop and drains vmcnt(0) — i.e. the next tile's LDS-DMA — at the first
+    // use of a query register in every iteration.
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
 
   // ---- staging ----------------------------------------------------------------------------------------------
   const T* ckv = static_cast<const T*>(a.ckv);
   const T* kpe = static_cast<const T*>(a.kpe);
-  auto stage = [&](int kt, int buf) {
-    const int k_first = k_begin + kt * MLA_KEYS;
+  // Staging of one tile is cut into 18 pieces per wave (16 c_kv rows + 2 k_pe row blocks).  stage_prep() does the
+  // page lookups (one LDS round trip, before any DMA of this tile is in flight); stage_piece(i) issues ONE LDS-DMA
+  // instruction.  The main loop spreads the pieces between the QK^T MFMA batches so the vector-memory queue never
+  // backs up into the issuing wave.
+  struct StagePlan { int my_phys, phys_b[2], k_first, buf; };
+  auto stage_prep = [&](int kt, int buf) {
+    StagePlan sp;
+    sp.k_first = k_begin + kt * MLA_KEYS;
+    sp.buf = buf;
     {
-      const int p_last = page_of(min(k_first + MLA_KEYS - 1, k_end - 1));
+      const int p_last = page_of(min(sp.k_first + MLA_KEYS - 1, k_end - 1));
       if (p_last >= win_base + TABLE_ENTRIES) {
         __syncthreads();
-        fill_window(page_of(k_first));
+        fill_window(page_of(sp.k_first));
       }
     }
-    lds_m* ta = smem + buf * TILE;
-    lds_m* tb = ta + A_BYTES;
-    // region A: wave w stages rows w, w+4, ...: one instruction per row.  Lane i < 16 looks up the page of row
-    // w + 4i (ONE LDS round trip for all 16 rows); each row's page id then comes out of that vector with
-    // v_readlane, so page id, slot and row address are wave-uniform scalars.  Page sizes are powers of two here
-    // (other sizes take the generic kernel).
+    // Lane i < 16 looks up the page of row w + 4i; each row's page id then comes out of that vector with
+    // v_readlane, so page id, slot and row address are wave-uniform scalars.
+    // (table reads from inline asm: a C++ LDS load here makes hipcc drain vmcnt(0) whenever a DMA may be in flight)
+    const int key_l = min(sp.k_first + wave + 4 * (lane & 15), k_end - 1);
+    const int key_b0 = min(sp.k_first + (wave * 2 + 0) * 8 + (lane >> 3), k_end - 1);
+    const int key_b1 = min(sp.k_first + (wave * 2 + 1) * 8 + (lane >> 3), k_end - 1);
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(sp.my_phys), "=&v"(sp.phys_b[0]), "=&v"(sp.phys_b[1])
+                 : "v"(table_u32 + 4 * ((key_l >> a.page_shift) - win_base)), "v"(table_u32 + 4 * ((key_b0 >> a.page_shift) - win_base)),
+                   "v"(table_u32 + 4 * ((key_b1 >> a.page_shift) - win_base))
+                 : "memory");
+    sp.my_phys = max(sp.my_phys, 0);
+    sp.phys_b[0] = max(sp.phys_b[0], 0);
+    sp.phys_b[1] = max(sp.phys_b[1], 0);
+    return sp;
+  };
+  auto stage_piece = [&](const StagePlan& sp, int i) {      // i is a compile-time constant after unrolling
     const int mask = a.page - 1;
-    int my_phys;
-    {
-      const int key_l = min(k_first + wave + 4 * (lane & 15), k_end - 1);
-      my_phys = s_table[(key_l >> a.page_shift) - win_base];
-      if (my_phys < 0) my_phys = 0;
-    }
-#pragma unroll
-    for (int i = 0; i < MLA_KEYS / WAVES; ++i) {
+    lds_m* ta = smem + sp.buf * TILE;
+    if (i < MLA_KEYS / WAVES) {
+      // region A: wave w stages rows w, w+4, ...: one instruction per 1 KiB row
       const int row = i * WAVES + wave;
-      const int key = min(k_first + row, k_end - 1);
-      const int phys = __builtin_amdgcn_readlane(my_phys, i);
+      const int key = min(sp.k_first + row, k_end - 1);
+      const int phys = __builtin_amdgcn_readlane(sp.my_phys, i);
       const T* src = ckv + static_cast<int64_t>(phys) * a.ckv_blk + static_cast<int64_t>(key & mask) * a.ckv_tok;
       const int cs = lane ^ ((row & 7) << 1);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + cs * 8),
                                        (__attribute__((address_space(3))) void*)(ta + row * 1024), 16, 0, 0);
-    }
-    // region B: two instructions per wave, each 8 rows x 8 chunks
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    } else {
+      // region B: two instructions per wave, each 8 rows x 8 chunks
+      const int j = i - MLA_KEYS / WAVES;
       const int rb = (wave * 2 + j) * 8;
       const int row = rb + (lane >> 3);
-      const int key = min(k_first + row, k_end - 1);
-      int phys = s_table[(key >> a.page_shift) - win_base];
-      if (phys < 0) phys = 0;
+      const int key = min(sp.k_first + row, k_end - 1);
       const int cs = (lane & 7) ^ (row & 7);
-      const T* src = kpe + static_cast<int64_t>(phys) * a.kpe_blk + static_cast<int64_t>(key & mask) * a.kpe_tok + cs * 8;
+      const T* src = kpe + static_cast<int64_t>(sp.phys_b[j]) * a.kpe_blk + static_cast<int64_t>(key & mask) * a.kpe_tok + cs * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(tb + rb * 128), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(ta + A_BYTES + rb * 128), 16, 0, 0);
     }
   };
+  constexpr int PIECES = MLA_KEYS / WAVES + 2;
 
   // ---- per-lane read offsets ----------------------------------------------------------------------------------
   const int x2 = (l15 & 7) << 1;
@@ -498,31 +526,52 @@ __global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
   float m = -INFINITY, lsum = 0.f;
 
   if (n_kt > 0) {
-    stage(0, 0);
+    const StagePlan sp0 = stage_prep(0, 0);
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) stage_piece(sp0, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
   for (int kt = 0; kt < n_kt; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < n_kt && ABL != 3) stage(kt + 1, buf ^ 1);
+    const bool prefetch = kt + 1 < n_kt && ABL != 3;
+    StagePlan sp{};
+    if (prefetch) sp = stage_prep(kt + 1, buf ^ 1);
+    if (prefetch) {
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) stage_piece(sp, i);
+    }
     if (active) {
       const lds_m* tl = smem + buf * TILE;
       // ---- S^T = K_lat Q_lat^T -------------------------------------------------------------------------------
+      // The 72 K-fragment reads are issued from inline asm in batches of 6 through two register buffers
+      // (one batch in flight while the other feeds the MFMAs).  Plain C++ LDS loads would do, except that
+      // hipcc then drains vmcnt(0) in front of the first one — i.e. waits for the NEXT tile's LDS-DMA every tile.
       f32x4 s[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (ABL == 2) { s[t][0] = qf[t][0]; continue; }
+      for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (ABL == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-          const frag kf = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(tl + ka[ks & 3] + t * 16384 + (ks >> 2) * 256);
-          s[t] = mla_mfma<T>::run(kf, qf[ks], s[t]);
-        }
+        for (int t = 0; t < 4; ++t) s[t][0] = qf[t][0];
+      } else {
+        unsigned kav[4], kbv[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const frag kf = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(tl + kb2[ks] + t * 2048);
-          s[t] = mla_mfma<T>::run(kf, qf[16 + ks], s[t]);
-        }
+        for (int v = 0; v < 4; ++v) kav[v] = smem_u32 + buf * TILE + ka[v];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) kbv[v] = smem_u32 + buf * TILE + kb2[v];
+        u32x4 kr[2][6];
+        mla512_k_issue<0>(kr[0], kav, kbv);
+        static_for<12>([&](auto BC) {
+          constexpr int B = decltype(BC)::value, t = B / 3, c = B % 3;
+          if constexpr (B + 1 < 12) mla512_k_issue<B + 1>(kr[(B + 1) & 1], kav, kbv);
+          u32x4 (&cur)[6] = kr[B & 1];
+          if constexpr (B + 1 < 12)
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) : : "memory");
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) : : "memory");
+#pragma unroll
+          for (int i = 0; i < 6; ++i) s[t] = mla_mfma<T>::run(__builtin_bit_cast(frag, cur[i]), qf[6 * c + i], s[t]);
+        });
       }
       // ---- online softmax (raw-score maximum, scale folded into the exponent) -----------------------------------
       const int key0 = k_begin + kt * MLA_KEYS + 4 * grp;
