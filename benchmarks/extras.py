@@ -4,6 +4,8 @@ MFMA 2.5 PFLOP/s dense, int8 5 POP/s).  Timing: HIP events on the launch stream,
 With world > 1 every rank runs the GEMM + collective cases together (they contain collectives)."""
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -129,6 +131,8 @@ def bench_mla_decode(device):
     ckv = torch.randn(total, 1, page, r, device=device, dtype=torch.bfloat16)
     kpe = torch.randn(total, 1, page, rope, device=device, dtype=torch.bfloat16)
     table = torch.randperm(total, dtype=torch.int32)[: b * pages].view(b, pages).to(device)
+    if os.environ.get("MOJO_BENCH_MLA_SEQ"):          # diagnostic: physically sequential pages
+        table = torch.arange(b * pages, dtype=torch.int32).view(b, pages).to(device)
     lens = torch.full((b,), ctx, dtype=torch.int32, device=device)
     q = torch.randn(b, h, nope + rope, device=device, dtype=torch.bfloat16)
     t = _time(lambda: op(q, ckv, kpe, lens, table))

@@ -44,6 +44,7 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> str:
     headers = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(os.path.dirname(PKG), "include", "mojo_hip.h")]
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc", "-ffp-contract=on"]
+    flags += os.environ.get("MOJO_HIP_EXTRA_CXXFLAGS", "").split()   # e.g. -DMLA_DBG_TIMERS for kernel phase timers
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")

@@ -344,353 +344,9 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
   }
 }
 
-// K-fragment batch B of the r = 512 kernel's QK^T: key tile B/3, k-steps 6*(B%3) .. +5 (k-steps 16, 17 are k_pe)
-template <int B, int I = 0>
-__device__ __forceinline__ void mla512_k_issue(u32x4 (&dst)[6], const unsigned (&kav)[4], const unsigned (&kbv)[2]) {
-  constexpr int t = B / 3, ks = 6 * (B % 3) + I;
-  if constexpr (ks < 16)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kav[ks & 3]), "i"(t * 16384 + (ks >> 2) * 256) : "memory");
-  else
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kbv[ks - 16]), "i"(t * 2048) : "memory");
-  if constexpr (I + 1 < 6) mla512_k_issue<B, I + 1>(dst, kav, kbv);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// DeepSeek-V3 geometry (r = 512, rope = 64): dedicated kernel.
-//   * 4 waves x 16 heads = 64 heads per workgroup (two workgroups per token for H = 128, placed on one XCD so the
-//     second one finds the tile in L2); ONE wave per SIMD with the whole 512-register file: the 128 accumulator
-//     registers of O^T live in AGPRs, which leaves room for the 72 query registers AND two batches of transposed
-//     V reads in flight (the generic 8-wave kernel above has to wait for every d tile's reads on the spot).
-//   * LDS tile = region A [64 keys][64 chunks] (c_kv, 1 KiB rows) + region B [64 keys][8 chunks] (k_pe, 128 B rows):
-//     one LDS-DMA instruction stages exactly one c_kv row (page id and row address are wave-uniform scalars),
-//     one more stages the k_pe of 8 rows.  Chunk c of key s is stored at c ^ ((s & 7) << 1) in A and at
-//     c ^ (s & 7) in B — conflict-free for the ds_read_b128 row reads and the ds_read_b64_tr_b16 transposed reads.
-//   * PV is software-pipelined in batches of 4 d tiles (16 transposed reads per asm statement): batch b+1 is in
-//     flight while the 8 MFMAs of batch b run; the counted lgkmcnt wait is safe because the loop body contains no
-//     scalar loads (checked in the generated ISA: tests/test_isa_invariants.py).
-// ABL: timing-only ablations (wrong results): 1 = no PV, 2 = no QK^T, 3 = stage only the first tile
-template <typename T, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void mla512_kernel(MlaArgs a) {
-  typedef typename mla_mfma<T>::frag frag;
-  constexpr int R = 512, ROPE = 64, NK = 18, ND = 32, WAVES = 4, HPB = 64;
-  constexpr int A_BYTES = MLA_KEYS * 1024, B_BYTES = MLA_KEYS * 128, TILE = A_BYTES + B_BYTES;   // 72 KiB
-  constexpr int TABLE_ENTRIES = 2048;
-  extern __shared__ __attribute__((aligned(1024))) char smem_generic[];
-  lds_m* smem = (lds_m*)smem_generic;
-
-  const int tile = blockIdx.x % a.n_tiles, hb = blockIdx.x / a.n_tiles, split = blockIdx.y;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int grp = lane >> 4, l15 = lane & 15;
-
-  int b, n_vis;
-  if (a.cu_q == nullptr) {
-    b = tile;
-    n_vis = a.seq_lens[b];
-  } else {
-    if (tile < a.cu_q[0] || tile >= a.cu_q[a.batch]) return;
-    int lo = 0, hi = a.batch;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (a.cu_q[mid] <= tile) lo = mid; else hi = mid;
-    }
-    b = lo;
-    const int q_len = a.cu_q[b + 1] - a.cu_q[b];
-    const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
-    n_vis = min(kv_len, kv_len - q_len + (tile - a.cu_q[b]) + 1);
-  }
-  const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
-  if (n_vis > 0) {
-    int p1 = (n_vis + a.page - 1) / a.page;
-    int fn = -1;
-    if (p1 > a.max_pages) { fn = a.max_pages; p1 = a.max_pages; }
-    for (int base = 0; base < p1; base += 64) {
-      const int idx = base + lane;
-      const int v = idx < p1 ? table[idx] : 0;
-      const unsigned long long neg = __ballot(v < 0);
-      if (neg) { fn = base + __builtin_ctzll(neg); break; }
-    }
-    if (fn >= 0) n_vis = min(n_vis, fn * a.page);
-  }
-  const int k_begin = split * a.split_keys;
-  const int k_end = min(n_vis, k_begin + a.split_keys);
-  const int n_kt = k_end > k_begin ? (k_end - k_begin + MLA_KEYS - 1) / MLA_KEYS : 0;
-
-  int* s_table = reinterpret_cast<int*>(smem_generic + 2 * TILE);
-  int win_base = 0;
-  auto fill_window = [&](int p0) {
-    for (int i = threadIdx.x; i < TABLE_ENTRIES; i += 256) s_table[i] = (p0 + i < a.max_pages) ? table[p0 + i] : -1;
-    win_base = p0;
-    __syncthreads();
-  };
-  auto page_of = [&](int key) { return key >> a.page_shift; };   // power-of-two pages only (dispatch guarantees it)
-  fill_window(page_of(k_begin));
-  const unsigned table_u32 = static_cast<unsigned>(reinterpret_cast<size_t>((lds_m*)smem_generic)) + 2 * TILE;
-
-  const int head0 = hb * HPB + wave * 16;
-  const bool active = head0 < a.heads;
-  const int head = min(head0 + l15, a.heads - 1);
-
-  frag qf[NK];
-  {
-    const int64_t qrow = static_cast<int64_t>(tile) * a.heads + head;
-    const T* qp = static_cast<const T*>(a.q_lat) + qrow * a.q_stride + grp * 8;
-    const T* qr = static_cast<const T*>(a.q_rope) + qrow * a.q_rope_stride + grp * 8;
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) qf[ks] = *reinterpret_cast<const frag*>(ks * 32 < R ? qp + ks * 32 : qr + (ks * 32 - R));
-    // Retire the query loads HERE, in a way the compiler's wait-count pass can see: otherwise it carries them as
-    // "maybe still pending" into the main loop and drains vmcnt(0) — i.e. the next tile's LDS-DMA — at the first
-    // use of a query register in every iteration.
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) asm volatile("" : "+v"(qf[ks]));
-  }
-
-  // ---- staging ----------------------------------------------------------------------------------------------
-  const T* ckv = static_cast<const T*>(a.ckv);
-  const T* kpe = static_cast<const T*>(a.kpe);
-  // Staging of one tile is cut into 18 pieces per wave (16 c_kv rows + 2 k_pe row blocks).  stage_prep() does the
-  // page lookups (one LDS round trip, before any DMA of this tile is in flight); stage_piece(i) issues ONE LDS-DMA
-  // instruction.  The main loop spreads the pieces between the QK^T MFMA batches so the vector-memory queue never
-  // backs up into the issuing wave.
-  struct StagePlan { int my_phys, phys_b[2], k_first, buf; };
-  auto stage_prep = [&](int kt, int buf) {
-    StagePlan sp;
-    sp.k_first = k_begin + kt * MLA_KEYS;
-    sp.buf = buf;
-    {
-      const int p_last = page_of(min(sp.k_first + MLA_KEYS - 1, k_end - 1));
-      if (p_last >= win_base + TABLE_ENTRIES) {
-        __syncthreads();
-        fill_window(page_of(sp.k_first));
-      }
-    }
-    // Lane i < 16 looks up the page of row w + 4i; each row's page id then comes out of that vector with
-    // v_readlane, so page id, slot and row address are wave-uniform scalars.
-    // (table reads from inline asm: a C++ LDS load here makes hipcc drain vmcnt(0) whenever a DMA may be in flight)
-    const int key_l = min(sp.k_first + wave + 4 * (lane & 15), k_end - 1);
-    const int key_b0 = min(sp.k_first + (wave * 2 + 0) * 8 + (lane >> 3), k_end - 1);
-    const int key_b1 = min(sp.k_first + (wave * 2 + 1) * 8 + (lane >> 3), k_end - 1);
-    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(sp.my_phys), "=&v"(sp.phys_b[0]), "=&v"(sp.phys_b[1])
-                 : "v"(table_u32 + 4 * ((key_l >> a.page_shift) - win_base)), "v"(table_u32 + 4 * ((key_b0 >> a.page_shift) - win_base)),
-                   "v"(table_u32 + 4 * ((key_b1 >> a.page_shift) - win_base))
-                 : "memory");
-    sp.my_phys = max(sp.my_phys, 0);
-    sp.phys_b[0] = max(sp.phys_b[0], 0);
-    sp.phys_b[1] = max(sp.phys_b[1], 0);
-    return sp;
-  };
-  auto stage_piece = [&](const StagePlan& sp, int i) {      // i is a compile-time constant after unrolling
-    const int mask = a.page - 1;
-    lds_m* ta = smem + sp.buf * TILE;
-    if (i < MLA_KEYS / WAVES) {
-      // region A: wave w stages rows w, w+4, ...: one instruction per 1 KiB row
-      const int row = i * WAVES + wave;
-      const int key = min(sp.k_first + row, k_end - 1);
-      const int phys = __builtin_amdgcn_readlane(sp.my_phys, i);
-      const T* src = ckv + static_cast<int64_t>(phys) * a.ckv_blk + static_cast<int64_t>(key & mask) * a.ckv_tok;
-      const int cs = lane ^ ((row & 7) << 1);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + cs * 8),
-                                       (__attribute__((address_space(3))) void*)(ta + row * 1024), 16, 0, 0);
-    } else {
-      // region B: two instructions per wave, each 8 rows x 8 chunks
-      const int j = i - MLA_KEYS / WAVES;
-      const int rb = (wave * 2 + j) * 8;
-      const int row = rb + (lane >> 3);
-      const int key = min(sp.k_first + row, k_end - 1);
-      const int cs = (lane & 7) ^ (row & 7);
-      const T* src = kpe + static_cast<int64_t>(sp.phys_b[j]) * a.kpe_blk + static_cast<int64_t>(key & mask) * a.kpe_tok + cs * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(ta + A_BYTES + rb * 128), 16, 0, 0);
-    }
-  };
-  constexpr int PIECES = MLA_KEYS / WAVES + 2;
-
-  // ---- per-lane read offsets ----------------------------------------------------------------------------------
-  const int x2 = (l15 & 7) << 1;
-  int ka[4], kb2[2];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) ka[v] = l15 * 1024 + (((4 * v) | grp) ^ x2) * 16;        // k-step ks: v = ks & 3, + (ks>>2)*256
-#pragma unroll
-  for (int v = 0; v < 2; ++v) kb2[v] = A_BYTES + l15 * 128 + (((4 * v + grp) ^ (l15 & 7)) * 16);
-  const int tq = l15 >> 2, tp = l15 & 3;
-  const int trow = 4 * grp + tq;
-  unsigned tr8[8];                                                                    // d tile dt: v = dt & 7, + (dt>>3)*256
-#pragma unroll
-  for (int v = 0; v < 8; ++v) tr8[v] = trow * 1024 + ((((2 * v) | (tp >> 1)) ^ ((trow & 7) << 1)) * 16) + (tp & 1) * 8;
-  const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
-
-  f32x4 o[ND];
-#pragma unroll
-  for (int dt = 0; dt < ND; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, lsum = 0.f;
-
-  if (n_kt > 0) {
-    const StagePlan sp0 = stage_prep(0, 0);
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) stage_piece(sp0, i);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  for (int kt = 0; kt < n_kt; ++kt) {
-    const int buf = kt & 1;
-    const bool prefetch = kt + 1 < n_kt && ABL != 3;
-    StagePlan sp{};
-    if (prefetch) sp = stage_prep(kt + 1, buf ^ 1);
-    if (prefetch) {
-#pragma unroll
-      for (int i = 0; i < PIECES; ++i) stage_piece(sp, i);
-    }
-    if (active) {
-      const lds_m* tl = smem + buf * TILE;
-      // ---- S^T = K_lat Q_lat^T -------------------------------------------------------------------------------
-      // The 72 K-fragment reads are issued from inline asm in batches of 6 through two register buffers
-      // (one batch in flight while the other feeds the MFMAs).  Plain C++ LDS loads would do, except that
-      // hipcc then drains vmcnt(0) in front of the first one — i.e. waits for the NEXT tile's LDS-DMA every tile.
-      f32x4 s[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (ABL == 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s[t][0] = qf[t][0];
-      } else {
-        unsigned kav[4], kbv[2];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) kav[v] = smem_u32 + buf * TILE + ka[v];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) kbv[v] = smem_u32 + buf * TILE + kb2[v];
-        u32x4 kr[2][6];
-        mla512_k_issue<0>(kr[0], kav, kbv);
-        static_for<12>([&](auto BC) {
-          constexpr int B = decltype(BC)::value, t = B / 3, c = B % 3;
-          if constexpr (B + 1 < 12) mla512_k_issue<B + 1>(kr[(B + 1) & 1], kav, kbv);
-          u32x4 (&cur)[6] = kr[B & 1];
-          if constexpr (B + 1 < 12)
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) : : "memory");
-          else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]) : : "memory");
-#pragma unroll
-          for (int i = 0; i < 6; ++i) s[t] = mla_mfma<T>::run(__builtin_bit_cast(frag, cur[i]), qf[6 * c + i], s[t]);
-        });
-      }
-      // ---- online softmax (raw-score maximum, scale folded into the exponent) -----------------------------------
-      const int key0 = k_begin + kt * MLA_KEYS + 4 * grp;
-      if (k_begin + (kt + 1) * MLA_KEYS > k_end) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (key0 + 16 * t + r >= k_end) s[t][r] = -INFINITY;
-      }
-      float mx = m;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float ms = (mx == -INFINITY ? 0.f : mx) * a.scale_log2;
-      const float alpha = fast_exp2(m * a.scale_log2 - ms);
-      m = mx;
-      float ps = 0.f;
-      frag pf[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        frag f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p0 = fast_exp2(fmaf(s[2 * kk][r], a.scale_log2, -ms));
-          const float p1 = fast_exp2(fmaf(s[2 * kk + 1][r], a.scale_log2, -ms));
-          ps += p0 + p1;
-          f[r] = static_cast<T>(p0);
-          f[4 + r] = static_cast<T>(p1);
-        }
-        pf[kk] = f;
-      }
-      lsum = lsum * alpha + ps;
-      if (!__all(alpha == 1.0f)) {
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt) o[dt] *= alpha;
-      }
-      // ---- O^T += C_kv^T P^T, batches of 4 d tiles, double-buffered -------------------------------------------------
-      const unsigned vt = smem_u32 + buf * TILE;
-      // batches of 2 d tiles = 8 transposed reads (lgkmcnt is a 4-bit counter: at most 15 may stay outstanding)
-      s16x4 va[8], vb[8];
-#define MLA512_ISSUE(dst, J)                                                                                          \
-      asm volatile(                                                                                                   \
-          "ds_read_b64_tr_b16 %0, %8 offset:%10\n\tds_read_b64_tr_b16 %1, %8 offset:%11\n\t"                          \
-          "ds_read_b64_tr_b16 %2, %8 offset:%12\n\tds_read_b64_tr_b16 %3, %8 offset:%13\n\t"                          \
-          "ds_read_b64_tr_b16 %4, %9 offset:%10\n\tds_read_b64_tr_b16 %5, %9 offset:%11\n\t"                          \
-          "ds_read_b64_tr_b16 %6, %9 offset:%12\n\tds_read_b64_tr_b16 %7, %9 offset:%13"                              \
-          : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]), "=&v"(dst[4]), "=&v"(dst[5]), "=&v"(dst[6]),  \
-            "=&v"(dst[7])                                                                                             \
-          : "v"(vt + tr8[((J) * 2 + 0) & 7]), "v"(vt + tr8[((J) * 2 + 1) & 7]), "i"(((J) >> 2) * 256),               \
-            "i"(((J) >> 2) * 256 + 16384), "i"(((J) >> 2) * 256 + 32768), "i"(((J) >> 2) * 256 + 49152)              \
-          : "memory")
-#define MLA512_RETIRE(dst, N)                                                                                         \
-      asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                        \
-                   : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "+v"(dst[5]), "+v"(dst[6]),  \
-                     "+v"(dst[7])                                                                                       \
-                   : : "memory")
-#define MLA512_PV(src, J)                                                                                             \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                \
-        const s16x4 lo = src[i * 4 + kk * 2], hi = src[i * 4 + kk * 2 + 1];                                            \
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                   \
-        o[(J) * 2 + i] = mla_mfma<T>::run(__builtin_bit_cast(frag, both), pf[kk], o[(J) * 2 + i]);                     \
-      }
-#define MLA512_STEP2(J)                                                                                               \
-      MLA512_ISSUE(vb, (J) + 1); MLA512_RETIRE(va, 8); MLA512_PV(va, (J));                                            \
-      MLA512_ISSUE(va, (J) + 2); MLA512_RETIRE(vb, 8); MLA512_PV(vb, (J) + 1);
-      if constexpr (ABL != 1) {
-      MLA512_ISSUE(va, 0);
-      MLA512_STEP2(0) MLA512_STEP2(2) MLA512_STEP2(4) MLA512_STEP2(6) MLA512_STEP2(8) MLA512_STEP2(10) MLA512_STEP2(12)
-      MLA512_ISSUE(vb, 15); MLA512_RETIRE(va, 8); MLA512_PV(va, 14);
-      MLA512_RETIRE(vb, 0); MLA512_PV(vb, 15);
-      } else { o[0][0] += pf[0][0] + pf[1][1]; }
-#undef MLA512_STEP2
-#undef MLA512_ISSUE
-#undef MLA512_RETIRE
-#undef MLA512_PV
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  if (!active) return;
-  lsum += __shfl_xor(lsum, 16);
-  lsum += __shfl_xor(lsum, 32);
-  if (head0 + l15 >= a.heads) return;
-  if (a.n_splits == 1) {
-    float den = lsum;
-    float w = 1.f;
-    const float ml2 = m * a.scale_log2;                       // running max in log2 units
-    if (a.sink) {
-      const float sk = a.sink[head] * 1.4426950408889634f;
-      const float M = fmaxf(ml2, sk);
-      w = (m == -INFINITY) ? 0.f : fast_exp2(ml2 - M);
-      den = lsum * w + fast_exp2(sk - M);
-    }
-    const float inv = den > 0.f ? w / den : 0.f;
-    T* dst = static_cast<T*>(a.o_lat) + (static_cast<int64_t>(tile) * a.heads + head) * R;
-    typedef typename vec_of<T, 4>::type V4;
-#pragma unroll
-    for (int dt = 0; dt < ND; ++dt) {
-      V4 ov;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ov[r] = static_cast<T>(o[dt][r] * inv);
-      *reinterpret_cast<V4*>(dst + dt * 16 + grp * 4) = ov;
-    }
-  } else {
-    const int64_t slot = (static_cast<int64_t>(tile) * a.n_splits + split) * a.heads + head;
-    float* po = a.part_o + slot * R;
-#pragma unroll
-    for (int dt = 0; dt < ND; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16 + grp * 4) = o[dt];
-    if (grp == 0) {
-      a.part_ml[slot * 2] = m * a.scale_log2;                 // partials carry the max in log2 units (as the generic kernel)
-      a.part_ml[slot * 2 + 1] = lsum;
-    }
-  }
-}
+}  // namespace mojo
+#include "mla512_pair.h"
+namespace mojo {
 
 // merge the splits of one (token, head): grid = (Tq, H), R/4 threads
 template <typename T>
@@ -742,12 +398,10 @@ static int launch_mla(const MlaArgs& a, hipStream_t s) {
 template <typename T>
 static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
   if (r == 512 && rope == 64 && a.page_shift >= 0) {
-    constexpr int LDS = 2 * (MLA_KEYS * 1024 + MLA_KEYS * 128) + 2048 * 4;
-    static const int abl = [] { const char* e = getenv("MOJO_HIP_MLA_ABLATE"); return e ? atoi(e) : 0; }();
-    void (*fn)(MlaArgs) = abl == 1 ? mla512_kernel<T, 1> : abl == 2 ? mla512_kernel<T, 2> : abl == 3 ? mla512_kernel<T, 3> : mla512_kernel<T, 0>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int head_blocks = (a.heads + 63) / 64;
-    hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), LDS, s, a);
+    void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
+    hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
     MOJO_CHECK_LAUNCH("mla512");
     if (a.n_splits > 1) {
       hipLaunchKernelGGL(mla_merge_kernel<T>, dim3(a.n_tiles, a.heads), dim3(128), 0, s, a, 512);
@@ -839,3 +493,4 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride,
   const int r = static_cast<int>(kv_lora_rank), rope = static_cast<int>(rope_dim);
   return dtype == MOJO_BF16 ? dispatch_mla<bf16_t>(a, r, rope, s) : dispatch_mla<f16_t>(a, r, rope, s);
 }
+
