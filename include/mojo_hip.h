@@ -139,7 +139,8 @@ int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const 
  *      element (g,k,n) at weight + g*w_group_stride + k*w_k_stride + n*w_n_stride, and optional row maps
  *      {rc, ml, off, mul} (NULL = identity): logical row m reads input row (m/rc)*ml + off + (m%rc)*mul and
  *      writes the output row given by c_map.  Used by the MLA ops to multiply by the two halves of kv_b_proj in
- *      place, one group per head, reading/writing token-major [T,H,*] tensors directly (rc=T, ml=1, mul=H).  */
+ *      place, one group per head, reading/writing token-major [T,H,*] tensors directly (rc=T, ml=1, mul=H).
+ *      group_list == NULL means num_groups equal groups of m_total / num_groups rows (no prefix pass).      */
 int mojo_hip_group_gemm_strided(const void* input, const void* weight, void* out, const void* group_list,
                                 int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
                                 int64_t num_groups, int64_t lda, int64_t ldc, int64_t w_group_stride,

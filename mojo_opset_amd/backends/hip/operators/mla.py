@@ -11,30 +11,16 @@ from .. import lib as L
 _ROCM = ["rocm"]
 
 
-_COUNTS = {}
-
-
-def _uniform_counts(heads: int, rows: int, device) -> torch.Tensor:
-    key = (heads, rows, str(device))
-    t = _COUNTS.get(key)
-    if t is None:
-        if len(_COUNTS) > 64:
-            _COUNTS.clear()
-        t = _COUNTS[key] = torch.full((heads,), rows, dtype=torch.int32, device=device)
-    return t
-
-
 def _per_head_gemm(x: torch.Tensor, lda: int, out: torch.Tensor, proj: torch.Tensor, heads: int, rows: int, k: int,
                    n: int, w_off: int, w_group: int, w_k: int, w_n: int) -> None:
     """``out[t, h, :n] = x[t, h, :k] @ W[h]`` for token-major ``x`` / ``out`` and W[h] a strided sub-block of
     ``proj``: one GEMM group per head, whose logical row h*rows + t is mapped onto storage row t*heads + h, so neither
     operand is transposed in memory."""
     lib = L.load()
-    counts = _uniform_counts(heads, rows, x.device)
     ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(heads), dtype=torch.uint8, device=x.device)
     w_ptr = L.c_void_p(proj.data_ptr() + w_off * proj.element_size())
     row_map = L.ints4(rows, 1, 0, heads)
-    L.check(lib.mojo_hip_group_gemm_strided(L.ptr(x), w_ptr, L.ptr(out), L.ptr(counts), 0, heads * rows, k, n, heads,
+    L.check(lib.mojo_hip_group_gemm_strided(L.ptr(x), w_ptr, L.ptr(out), None, 0, heads * rows, k, n, heads,
                                             lda, n, w_group, w_k, w_n, row_map, row_map, L.dtype_code(x.dtype),
                                             L.ptr(ws), ws.numel(), L.stream_of(x)), "hip mla projection")
 

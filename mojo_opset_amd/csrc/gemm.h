@@ -16,8 +16,10 @@ struct GemmArgs {
   const void* bias;          // optional [N], same dtype as C; added after rounding (golden: two ops)
   int64_t lda, ldc, w_group, w_k, w_n;
   int K, N, G;
-  const int32_t* row_start;  // [G+1]
+  const int32_t* row_start;  // [G+1]   (unused when uniform_rows > 0)
   const int32_t* tile_start; // [G+1] prefix of ceil(rows_g / BM)
+  int uniform_rows = 0;      // > 0: every group has exactly this many rows; the prefix arrays are not read (and no
+                             // prefix kernel is launched): dense GEMMs (G = 1) and the MLA per-head projections
   // Optional row maps (rc == 0 means identity).  Logical row m of the product reads
   // A row  (m / a_rc) * a_ml + a_off + (m % a_rc) * a_mul   and writes the C row given by the c_* quadruple.
   // They let one launch consume / produce the "every rank's c-th sub-chunk" view that the chunked reduce-scatter
@@ -33,6 +35,29 @@ struct GemmArgs {
   void* slab = nullptr;
   int slab_rows = 0;
 };
+
+// number of M tiles of height bm over all groups
+__device__ inline int gemm_m_tiles(const GemmArgs& a, int bm) {
+  return a.uniform_rows > 0 ? a.G * ((a.uniform_rows + bm - 1) / bm) : a.tile_start[a.G];
+}
+// group, first row and end row (exclusive) of M tile mi
+__device__ inline void gemm_locate_tile(const GemmArgs& a, int mi, int bm, int& g, int& m0, int& m_end) {
+  if (a.uniform_rows > 0) {
+    const int tpg = (a.uniform_rows + bm - 1) / bm;
+    g = mi / tpg;
+    m0 = g * a.uniform_rows + (mi - g * tpg) * bm;
+    m_end = (g + 1) * a.uniform_rows;
+    return;
+  }
+  int lo = 0, hi = a.G;                      // largest g with tile_start[g] <= mi
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.tile_start[mid] <= mi) lo = mid; else hi = mid;
+  }
+  g = lo;
+  m0 = a.row_start[g] + (mi - a.tile_start[g]) * bm;
+  m_end = a.row_start[g + 1];
+}
 
 __host__ __device__ inline int map_row(int m, int rc, int ml, int off, int mul = 1) { return rc ? (m / rc) * ml + off + (m % rc) * mul : m; }
 

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
 
   // ---- which tile ------------------------------------------------------------------------------------
   const int n_tiles = (a.N + BN - 1) / BN;
-  const int m_tiles = a.tile_start[a.G];
+  const int m_tiles = gemm_m_tiles(a, BM);
   const int tiles_mn = m_tiles * n_tiles;
   const int total = tiles_mn * a.splitk;
   const int bid = blockIdx.x;
@@ -147,17 +147,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
       ni = full_panels * PANEL + (t - mi * rem);
     }
   }
-  int g;
-  {
-    int lo = 0, hi = a.G;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (a.tile_start[mid] <= mi) lo = mid; else hi = mid;
-    }
-    g = lo;
-  }
-  const int m0 = a.row_start[g] + (mi - a.tile_start[g]) * BM;
-  const int m_end = a.row_start[g + 1];              // exclusive; m0 < m_end by construction
+  int g, m0, m_end;                                  // m_end exclusive; m0 < m_end by construction
+  gemm_locate_tile(a, mi, BM, g, m0, m_end);
   const int n0 = ni * BN;
   const int nkt_all = a.K / BK;
   const int kt0 = static_cast<int>(static_cast<int64_t>(nkt_all) * kslice / a.splitk);

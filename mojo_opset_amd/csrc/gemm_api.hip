@@ -1,16 +1,9 @@
-// C ABI of the grouped and dense GEMM entry points: argument checks, kernel choice, prefix launch.
+// C ABI of the grouped and dense GEMM entry points: argument checks, kernel choice, prefix launch (ragged groups only).
 #include <stdlib.h>
 
 #include "gemm.h"
 
 namespace mojo {
-
-__global__ void dense_prefix_kernel(int m, int bm, int32_t* row_start, int32_t* tile_start) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    row_start[0] = 0; row_start[1] = m;
-    tile_start[0] = 0; tile_start[1] = (m + bm - 1) / bm;
-  }
-}
 
 static int run_gemm(GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
   static const int abl = [] { const char* e = getenv("MOJO_HIP_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
@@ -35,7 +28,10 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
                                            int64_t workspace_bytes, mojo_stream_t stream) {
   MOJO_REQUIRE(num_groups > 0 && k > 0 && n > 0 && m_total >= 0, MOJO_EINVAL, "group_gemm: bad shape");
   if (m_total == 0) return MOJO_OK;
-  MOJO_REQUIRE(input && weight && out && group_list, MOJO_EINVAL, "group_gemm: null pointer");
+  MOJO_REQUIRE(input && weight && out, MOJO_EINVAL, "group_gemm: null pointer");
+  MOJO_REQUIRE(group_list || m_total % num_groups == 0, MOJO_EINVAL,
+               "group_gemm: group_list == NULL means equal groups, but %lld rows do not divide into %lld groups",
+               (long long)m_total, (long long)num_groups);
   MOJO_REQUIRE(dtype == MOJO_F32 || dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED,
                "group_gemm: dtype %d not supported", dtype);
   MOJO_REQUIRE(m_total < (1LL << 31) && k < (1LL << 31) && n < (1LL << 31) && num_groups < (1 << 20), MOJO_EUNSUPPORTED,
@@ -52,9 +48,13 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + (num_groups + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
-  int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s);
-  if (rc) return rc;
+  if (!group_list) {
+    a.uniform_rows = static_cast<int>(m_total / num_groups);
+  } else {
+    const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
+    int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s);
+    if (rc) return rc;
+  }
   return run_gemm(a, dtype, m_total, s);
 }
 
@@ -95,9 +95,7 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
-  hipLaunchKernelGGL(dense_prefix_kernel, dim3(1), dim3(64), 0, s, static_cast<int>(m), bm, ws, ws + 2);
-  MOJO_CHECK_LAUNCH("gemm(prefix)");
+  a.uniform_rows = static_cast<int>(m);
   return run_gemm(a, dtype, m, s);
 }
 

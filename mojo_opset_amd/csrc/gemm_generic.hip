@@ -84,20 +84,11 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs a) {
   __shared__ float sa[GK][GT + 4];
   __shared__ float sb[GK][GT + 4];
   const int n_tiles = (a.N + GT - 1) / GT;
-  const int total = a.tile_start[a.G] * n_tiles;
+  const int total = gemm_m_tiles(a, GT) * n_tiles;
   for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
     const int mi = tile / n_tiles, ni = tile - mi * n_tiles;
-    int g = 0;
-    {
-      int lo = 0, hi = a.G;                      // largest g with tile_start[g] <= mi
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.tile_start[mid] <= mi) lo = mid; else hi = mid;
-      }
-      g = lo;
-    }
-    const int m0 = a.row_start[g] + (mi - a.tile_start[g]) * GT;
-    const int m_end = a.row_start[g + 1];
+    int g, m0, m_end;
+    gemm_locate_tile(a, mi, GT, g, m0, m_end);
     const int n0 = ni * GT;
     const T* A = static_cast<const T*>(a.A);
     const T* W = static_cast<const T*>(a.W) + static_cast<int64_t>(g) * a.w_group;

@@ -459,7 +459,9 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride,
                MOJO_EUNSUPPORTED, "mla_latent_attn: tensors must be 16-byte aligned with 16-byte row strides");
   MOJO_REQUIRE(q_tokens < (1 << 30), MOJO_EUNSUPPORTED, "mla_latent_attn: too many query tokens");
   const int64_t eb = 2;
-  if (hipMemsetAsync(o_lat, 0, static_cast<size_t>(q_tokens * heads * kv_lora_rank * eb), s) != hipSuccess) {
+  // prefill: query tokens outside [cu_q[0], cu_q[batch]) are never visited by a workgroup — zero them up front.
+  // Decode visits every token (an empty sequence writes zeros itself), so the fill would only cost a launch.
+  if (cu_q_lens && hipMemsetAsync(o_lat, 0, static_cast<size_t>(q_tokens * heads * kv_lora_rank * eb), s) != hipSuccess) {
     set_error("mla_latent_attn: memset failed");
     return MOJO_ELAUNCH;
   }

@@ -119,13 +119,6 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
   return MOJO_OK;
 }
 
-__global__ void quant_prefix_kernel(int m, int32_t* row_start, int32_t* tile_start) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    row_start[0] = 0; row_start[1] = m;
-    tile_start[0] = 0; tile_start[1] = (m + 255) / 256;
-  }
-}
-
 }  // namespace mojo
 
 using namespace mojo;
@@ -157,8 +150,7 @@ extern "C" int mojo_hip_quant_gemm(const void* input, const void* weight, const 
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(quant_prefix_kernel, dim3(1), dim3(64), 0, s, static_cast<int>(m), ws, ws + 2);
-  MOJO_CHECK_LAUNCH("quant_gemm(prefix)");
+  a.uniform_rows = static_cast<int>(m);
   const bf16_t* cs = static_cast<const bf16_t*>(weight_scale);
   void* slab_ws = static_cast<char*>(workspace) + 64;
   switch (out_dtype) {
