@@ -27,7 +27,9 @@ struct RopeArgs {
 
 // A "row" is one (b, t, head) vector of head_dim elements.  Work items per row: nope/VEC pass-through
 // vectors + (rope_dim/2)/VEC rotation pairs.  TPRW threads (a power of two >= items) serve one row.
-template <typename T, int VEC>
+// CV: the cos/sin rows may be read with 16-byte loads (VEC % 4 == 0, rows 16-byte aligned): 8 float4 loads per work item
+// instead of 4*VEC scalar ones.
+template <typename T, int VEC, bool CV>
 __global__ __launch_bounds__(256) void apply_rope_kernel(RopeArgs a, int items_nope, int items_rot, int tprw_log2) {
   typedef typename vec_of<T, VEC>::type V;
   const int tprw = 1 << tprw_log2;
@@ -56,6 +58,19 @@ __global__ __launch_bounds__(256) void apply_rope_kernel(RopeArgs a, int items_n
     const float* s = a.sin + b * a.cos_b + t * a.cos_t;
     const V x1 = load_vec<T, VEC>(src + nope + i0);
     const V x2 = load_vec<T, VEC>(src + nope + half + i0);
+    float c1[VEC], c2[VEC], s1[VEC], s2[VEC];
+    if constexpr (CV) {
+#pragma unroll
+      for (int q = 0; q < VEC / 4; ++q) {
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(c + i0 + 4 * q), a2 = *reinterpret_cast<const f32x4*>(c + half + i0 + 4 * q);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(s + i0 + 4 * q), b2 = *reinterpret_cast<const f32x4*>(s + half + i0 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c1[4 * q + e] = a1[e]; c2[4 * q + e] = a2[e]; s1[4 * q + e] = b1[e]; s2[4 * q + e] = b2[e]; }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { c1[j] = c[i0 + j]; c2[j] = c[half + i0 + j]; s1[j] = s[i0 + j]; s2[j] = s[half + i0 + j]; }
+    }
     V o1, o2;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -63,8 +78,8 @@ __global__ __launch_bounds__(256) void apply_rope_kernel(RopeArgs a, int items_n
       const float f2 = elt<T>::to_f(vget<T, VEC>(x2, j));
       // out[i]      = x1*cos[i]      + (-x2)*sin[i]
       // out[half+i] = x2*cos[half+i] + ( x1)*sin[half+i]
-      const float r1 = __fadd_rn(__fmul_rn(f1, c[i0 + j]), __fmul_rn(-f2, s[i0 + j]));
-      const float r2 = __fadd_rn(__fmul_rn(f2, c[half + i0 + j]), __fmul_rn(f1, s[half + i0 + j]));
+      const float r1 = __fadd_rn(__fmul_rn(f1, c1[j]), __fmul_rn(-f2, s1[j]));
+      const float r2 = __fadd_rn(__fmul_rn(f2, c2[j]), __fmul_rn(f1, s2[j]));
       vset<T, VEC>(o1, j, elt<T>::from_f(r1));
       vset<T, VEC>(o2, j, elt<T>::from_f(r2));
     }
@@ -97,11 +112,16 @@ static int dispatch_rope(const RopeArgs& a, hipStream_t s) {
   const int64_t n_rows = a.batch * a.tokens * (a.heads[0] + a.heads[1]);
   int64_t blocks = ceil_div(n_rows, 256 >> lg);
   if (blocks > 256 * 32) blocks = 256 * 32;
-#define LAUNCH(V) hipLaunchKernelGGL((apply_rope_kernel<T, V>), dim3(blocks), dim3(256), 0, s, a, items_nope, items_rot, lg)
-  if (vec == 16 / sizeof(T)) LAUNCH(16 / sizeof(T));
-  else if (vec == 8 / sizeof(T)) LAUNCH(8 / sizeof(T));
-  else if (vec == 2) LAUNCH(2);
-  else LAUNCH(1);
+  const bool cos_vec = vec % 4 == 0 && half % 4 == 0 && aligned_to(a.cos, 16) && aligned_to(a.sin, 16) && a.cos_b % 4 == 0 && a.cos_t % 4 == 0;
+#define LAUNCH(V, CV) hipLaunchKernelGGL((apply_rope_kernel<T, V, CV>), dim3(blocks), dim3(256), 0, s, a, items_nope, items_rot, lg)
+  if (vec == 16 / sizeof(T)) {
+    if constexpr ((16 / sizeof(T)) % 4 == 0) { if (cos_vec) LAUNCH(16 / sizeof(T), true); else LAUNCH(16 / sizeof(T), false); }
+    else LAUNCH(16 / sizeof(T), false);
+  } else if (vec == 8 / sizeof(T)) {
+    if constexpr ((8 / sizeof(T)) % 4 == 0) { if (cos_vec) LAUNCH(8 / sizeof(T), true); else LAUNCH(8 / sizeof(T), false); }
+    else LAUNCH(8 / sizeof(T), false);
+  } else if (vec == 2) LAUNCH(2, false);
+  else LAUNCH(1, false);
 #undef LAUNCH
   MOJO_CHECK_LAUNCH("apply_rope");
   return MOJO_OK;

@@ -15,26 +15,48 @@ __device__ __forceinline__ float silu_f(float x) {
 }
 
 template <typename T, int VEC>
+__device__ __forceinline__ typename vec_of<T, VEC>::type swiglu_vec(const typename vec_of<T, VEC>::type& g,
+                                                                   const typename vec_of<T, VEC>::type& u, float limit) {
+  typename vec_of<T, VEC>::type o;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float gf = elt<T>::to_f(vget<T, VEC>(g, j));
+    float uf = elt<T>::to_f(vget<T, VEC>(u, j));
+    if (limit > 0.f) {
+      uf = fminf(fmaxf(uf, -limit), limit);
+      gf = fminf(gf, limit);
+    }
+    const float s = elt<T>::to_f(elt<T>::from_f(silu_f(gf)));   // round like the golden's F.silu
+    vset<T, VEC>(o, j, elt<T>::from_f(s * uf));
+  }
+  return o;
+}
+
+// Each thread takes UNROLL vectors per trip, all 2*UNROLL loads issued before the first use: with one vector per trip
+// a wave has 2 KiB in flight, too little to cover HBM latency at 8 resident waves per SIMD.
+template <typename T, int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gate, const T* __restrict__ up,
                                                      T* __restrict__ out, int64_t n_vec, float limit) {
   typedef typename vec_of<T, VEC>::type V;
-  const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
-    const V g = load_vec<T, VEC>(gate + i * VEC);
-    const V u = load_vec<T, VEC>(up + i * VEC);
-    V o;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * (256 * UNROLL);
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * (256 * UNROLL); base < n_vec; base += stride) {
+    V g[UNROLL], u[UNROLL];
+    if (base + 256 * UNROLL <= n_vec) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float gf = elt<T>::to_f(vget<T, VEC>(g, j));
-      float uf = elt<T>::to_f(vget<T, VEC>(u, j));
-      if (limit > 0.f) {
-        uf = fminf(fmaxf(uf, -limit), limit);
-        gf = fminf(gf, limit);
+      for (int k = 0; k < UNROLL; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        g[k] = load_vec<T, VEC>(gate + i * VEC);
+        u[k] = load_vec<T, VEC>(up + i * VEC);
       }
-      const float s = elt<T>::to_f(elt<T>::from_f(silu_f(gf)));   // round like the golden's F.silu
-      vset<T, VEC>(o, j, elt<T>::from_f(s * uf));
+#pragma unroll
+      for (int k = 0; k < UNROLL; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        store_vec<T, VEC>(out + i * VEC, swiglu_vec<T, VEC>(g[k], u[k], limit));
+      }
+    } else {
+      for (int64_t i = base + threadIdx.x; i < n_vec; i += 256)
+        store_vec<T, VEC>(out + i * VEC, swiglu_vec<T, VEC>(load_vec<T, VEC>(gate + i * VEC), load_vec<T, VEC>(up + i * VEC), limit));
     }
-    store_vec<T, VEC>(out + i * VEC, o);
   }
 }
 
@@ -43,13 +65,14 @@ static int launch_swiglu(const void* gate, const void* up, void* out, int64_t n,
   constexpr int WIDE = 16 / sizeof(T);
   const bool wide = n % WIDE == 0 && aligned_to(gate, 16) && aligned_to(up, 16) && aligned_to(out, 16);
   const int64_t n_vec = wide ? n / WIDE : n;
-  int64_t blocks = ceil_div(n_vec, 256);
+  constexpr int UNROLL = 4;
+  int64_t blocks = ceil_div(n_vec, 256 * UNROLL);
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (wide)
-    hipLaunchKernelGGL((swiglu_kernel<T, WIDE>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+    hipLaunchKernelGGL((swiglu_kernel<T, WIDE, UNROLL>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
                        static_cast<const T*>(up), static_cast<T*>(out), n_vec, limit);
   else
-    hipLaunchKernelGGL((swiglu_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+    hipLaunchKernelGGL((swiglu_kernel<T, 1, UNROLL>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
                        static_cast<const T*>(up), static_cast<T*>(out), n_vec, limit);
   MOJO_CHECK_LAUNCH("swiglu");
   return MOJO_OK;

@@ -1,6 +1,6 @@
 # Round-1 profiling pass (run through gpurun).  Outputs under gpurun_out/prof_r1/*; summaries are copied to profiles/.
 mkdir -p gpurun_out/prof_r1; cd /root/repo; export TMPDIR=/tmp
-B="python bench.py --steps 50 --warmup 5 --no-extras --no-cpu-baseline"
+B="python bench.py --steps 200 --warmup 20 --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1/decode_stats -- $B > gpurun_out/prof_r1/decode_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_r1/decode_fetch -- $B > gpurun_out/prof_r1/decode_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_r1/decode_write -- $B > gpurun_out/prof_r1/decode_write.log 2>&1

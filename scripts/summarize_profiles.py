@@ -29,7 +29,7 @@ def kernel_avg_ns(path, kernel_substr):
 
 
 out = {}
-for tag in ("decode", "gg"):
+for tag in ("decode", "gg", "mla", "prefill"):
     f = one(f"{tag}_stats/**/*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(DST, f"r1_{tag}_kernel_stats.csv"))
