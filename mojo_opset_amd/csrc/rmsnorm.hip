@@ -3,9 +3,9 @@
 //   normed = round_T(sum * rsqrt(mean(sum^2) + eps) * weight)     -- fp32 math, ONE rounding,
 // which is what torch's F.rms_norm does on CPU, not the Triton "llama" double rounding.
 //
-// One row per TPR threads (one wave for rows of up to 8 16-byte vectors per lane, else 256 threads); the row lives in
-// registers between the reduction and the scale pass, so every input byte is read once.  Rows too long for the
-// register cache are re-read in the second pass.
+// One row per TPR threads (64 for short rows, 256 otherwise); the row lives in registers between the
+// reduction and the scale pass, so every input byte is read once.  Rows too long for the register
+// cache are recomputed in a second pass.
 //
 // Algorithmic bytes per row (pre, with residual): 2 reads + 2 writes of D x elt, + weight once.
 #include "common.h"
@@ -29,38 +29,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
        row += static_cast<int64_t>(gridDim.x) * ROWS_PER_BLOCK) {
     const T* h = hidden + row * dim;
     const T* r = residual ? residual + row * dim : nullptr;
-    V cache[CACHE], rc[CACHE];
+    V cache[CACHE];
     float ss = 0.f;
-    // pass 1: sum (rounded to T), square-accumulate.  The first CACHE vectors of a thread are loaded up front (all the
-    // loads of a row are in flight together) and stay in registers for pass 2.
-#pragma unroll
-    for (int c = 0; c < CACHE; ++c) {
-      const int v = tid + c * TPR;
-      if (v < n_vec) {
-        cache[c] = load_vec<T, VEC>(h + v * VEC);
-        if (r) rc[c] = load_vec<T, VEC>(r + v * VEC);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CACHE; ++c) {
-      const int v = tid + c * TPR;
-      if (v < n_vec) {
-        V x = cache[c];
-        if (r) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j)
-            vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(rc[c], j))));
-          if (summed) store_vec<T, VEC>(summed + row * dim + v * VEC, x);
-          cache[c] = x;
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          const float f = elt<T>::to_f(vget<T, VEC>(x, j));
-          ss += f * f;
-        }
-      }
-    }
-    for (int v = tid + CACHE * TPR; v < n_vec; v += TPR) {          // rows longer than the register cache
+    // pass 1: sum (rounded to T), square-accumulate; keep the first CACHE vectors in registers
+    int c = 0;
+    for (int v = tid; v < n_vec; v += TPR, ++c) {
       V x = load_vec<T, VEC>(h + v * VEC);
       if (r) {
         const V y = load_vec<T, VEC>(r + v * VEC);
@@ -74,6 +47,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
         const float f = elt<T>::to_f(vget<T, VEC>(x, j));
         ss += f * f;
       }
+      if (c < CACHE) cache[c] = x;   // c is uniform across the unrolled prefix; see below
     }
     if constexpr (ROWS_PER_BLOCK == 1) {
       ss = block_sum<NW>(ss, red);
@@ -83,28 +57,26 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
     }
     const float rstd = rsqrtf(ss * inv_dim + eps);
     // pass 2
-    auto scale_store = [&](const V& x, int v) {
+    c = 0;
+    for (int v = tid; v < n_vec; v += TPR, ++c) {
+      V x;
+      if (c < CACHE) {
+        x = cache[c];
+      } else {
+        x = load_vec<T, VEC>(h + v * VEC);
+        if (r) {
+          const V y = load_vec<T, VEC>(r + v * VEC);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(y, j))));
+        }
+      }
       const V w = load_vec<T, VEC>(weight + v * VEC);
       V o;
 #pragma unroll
       for (int j = 0; j < VEC; ++j)
         vset<T, VEC>(o, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) * rstd * elt<T>::to_f(vget<T, VEC>(w, j))));
       store_vec<T, VEC>(normed + row * dim + v * VEC, o);
-    };
-#pragma unroll
-    for (int c = 0; c < CACHE; ++c) {
-      const int v = tid + c * TPR;
-      if (v < n_vec) scale_store(cache[c], v);
-    }
-    for (int v = tid + CACHE * TPR; v < n_vec; v += TPR) {
-      V x = load_vec<T, VEC>(h + v * VEC);
-      if (r) {
-        const V y = load_vec<T, VEC>(r + v * VEC);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-          vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(y, j))));
-      }
-      scale_store(x, v);
     }
   }
 }
@@ -118,16 +90,11 @@ static void launch_rms(const void* hidden, const void* residual, const void* wei
   const T* w = static_cast<const T*>(weight);
   T* o = static_cast<T*>(normed);
   T* so = static_cast<T*>(summed);
-  // rows of up to 4 (fp32) / 8 (16-bit types) vectors per lane: one wave per row (no LDS, no barrier), 4 rows per block
-  if (n_vec <= 64 * 4 || (sizeof(T) == 2 && n_vec <= 64 * 8)) {
+  if (n_vec <= 64 * 4) {   // short rows: one wave per row, 4 rows per block
     int64_t blocks = ceil_div(rows, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
-    if (n_vec <= 64 * 4)
-      hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 64, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
-                         static_cast<int>(dim), eps);
-    else
-      hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 64, 8>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
-                         static_cast<int>(dim), eps);
+    hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 64, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
+                       static_cast<int>(dim), eps);
   } else {
     int64_t blocks = rows > 256 * 32 ? 256 * 32 : rows;
     hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 256, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,

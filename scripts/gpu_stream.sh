@@ -1,0 +1,8 @@
+cd /root/repo; export TMPDIR=/tmp
+python -m pytest tests/test_hip_streaming.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error" gpurun_out/t.log | tail -5
+python - <<'PY'
+import json, torch, sys
+sys.path.insert(0, '.')
+from benchmarks.extras import bench_streaming
+print(json.dumps(bench_streaming(torch.device('cuda', 0)), indent=1))
+PY
