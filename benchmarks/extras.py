@@ -233,11 +233,43 @@ def bench_compute_comm(device, world, rank):
     return out
 
 
+def bench_moe(device):
+    """Mixtral routing: T = 8192 tokens, 8 experts, top-2, hidden 4096, inter 14336."""
+    out = {}
+    t_, e_, k_, h_, i_ = 8192, 8, 2, 4096, 14336
+    x = torch.rand(t_, h_, device=device, dtype=torch.bfloat16)
+    gating = hip("MojoMoEGating")(hidden_size=h_, num_experts=e_, top_k=k_).to(device)
+    with torch.no_grad():
+        gating.gate_weight.copy_(torch.randn(h_, e_) * 0.02)
+    out["gating_T8192_E8_k2_H4096"] = _hbm(_time(lambda: gating(x), 20, 3), t_ * h_ * 2 + h_ * e_ * 4 + t_ * k_ * 8)
+    idx, gates = gating(x)
+    dispatch = hip("MojoMoEDispatch")(num_experts=e_)
+    out["dispatch_T8192_E8_k2_H4096"] = _hbm(_time(lambda: dispatch(x, gates, idx), 20, 3), t_ * h_ * 2 + t_ * k_ * (h_ * 2 + 16))
+    sh, counts, sg, tok = dispatch(x, gates, idx)
+    combine = hip("MojoMoECombine")()
+    buf = torch.empty_like(x)
+    out["combine_T8192_k2_H4096"] = _hbm(_time(lambda: combine(buf, sh, sg, tok), 20, 3), t_ * k_ * (h_ * 2 + 8) + t_ * h_ * 2)
+    experts = hip("MojoExperts")(num_experts=e_, hidden_size=h_, intermediate_size=i_).to(torch.bfloat16).to(device)
+    with torch.no_grad():
+        experts.up_proj_weight.normal_(std=0.02)
+        experts.down_proj_weight.normal_(std=0.02)
+    flops = 2.0 * t_ * k_ * h_ * (2 * i_) + 2.0 * t_ * k_ * i_ * h_
+    out["experts_T8192x2_E8_H4096_I14336"] = _mfma(_time(lambda: experts(sh, counts), 5, 1), flops)
+
+    def layer():
+        i2, g2 = gating(x)
+        a, c, b, d = dispatch(x, g2, i2)
+        return combine(buf, experts(a, c), b, d)
+    out["moe_layer_T8192_E8_k2"] = _mfma(_time(layer, 5, 1), flops)
+    del experts
+    return out
+
+
 def run_extras(device, world, rank=0):
     out = {}
     for name, fn in (("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
-                     ("streaming_ops", bench_streaming)):
+                     ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe)):
         try:
             out[name] = fn(device)
         except Exception as e:  # one failing extra must not hide the others

@@ -70,6 +70,11 @@ int mojo_hip_store_paged_kv_layout(const void* key_states, const void* value_sta
  *      backends/ttx/operators/activation.py).  Flat contiguous tensors of n elements.           */
 int mojo_hip_swiglu(const void* gate, const void* up, void* out, int64_t n, int dtype,
                     float swiglu_limit, mojo_stream_t stream);
+/*      Row-strided form: gate / up / out are [rows, cols] views with row strides in elements (the two halves of a fused
+ *      [rows, 2*cols] projection, core/operators/moe.py:441-445).                                              */
+int mojo_hip_swiglu_rows(const void* gate, const void* up, void* out, int64_t rows, int64_t cols,
+                         int64_t ld_gate, int64_t ld_up, int64_t ld_out, int dtype, float swiglu_limit,
+                         mojo_stream_t stream);
 
 /* ---- MojoResidualAddRMSNorm / MojoRMSNorm (core/operators/normalization.py:308-362, :71-111;
  *      replaces fused_add_rmsnorm / rmsnorm launchers, backends/ttx/operators/normalization.py:35-47).
@@ -213,6 +218,30 @@ int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const v
                                int64_t cache_head_stride, int64_t cache_token_stride,
                                int64_t max_q_len_hint, float softmax_scale, int layout_abab,
                                int dtype, mojo_stream_t stream);
+
+/* ---- MoE routing either side of the grouped GEMM (core/operators/moe.py).
+ *      gating (:299-316): softmax(hidden.float() @ gate_weight [hidden, E] fp32) over all experts, top-k in descending
+ *      order (ties: lowest expert id), gates renormalised to sum 1.  top_k <= min(E, 64), E <= 1024.
+ *      dispatch (:344-400): stable counting sort of the tokens*top_k routing slots by expert id (the reference leaves
+ *      the order inside a bucket undefined; this one keeps flat-slot order, so the op is deterministic).  Outputs:
+ *      sorted_hidden [slots, H], tokens_per_expert int32 [E], sorted_gates fp32 [slots] (viewed [slots,1]),
+ *      token_indices int32 [slots].  Ids outside [0, E) are dropped.
+ *      combine (:687-716): out[t] = sum of expert_outputs[j] (* sorted_gates[j]; NULL = no gates) over the rows j with
+ *      token_indices[j] == t, fp32 from zero in ascending j, product and sum rounded separately — bit-identical to the
+ *      reference's fp32 scatter-add.  Tokens nobody routes to are zero.                                         */
+int mojo_hip_moe_gating(const void* hidden, const float* gate_weight, int32_t* top_k_indices, float* top_k_gates,
+                        int64_t tokens, int64_t hidden_size, int64_t num_experts, int64_t top_k, int dtype,
+                        mojo_stream_t stream);
+int64_t mojo_hip_moe_dispatch_workspace_bytes(int64_t slots, int64_t num_experts);
+int mojo_hip_moe_dispatch(const void* hidden, const float* top_k_gates, const int32_t* top_k_indices,
+                          void* sorted_hidden, int32_t* tokens_per_expert, float* sorted_gates,
+                          int32_t* token_indices, int64_t tokens, int64_t hidden_size, int64_t top_k,
+                          int64_t num_experts, int dtype, void* workspace, int64_t workspace_bytes,
+                          mojo_stream_t stream);
+int64_t mojo_hip_moe_combine_workspace_bytes(int64_t tokens, int64_t rows);
+int mojo_hip_moe_combine(const void* expert_outputs, const float* sorted_gates, const int32_t* token_indices,
+                         void* out, int64_t tokens, int64_t rows, int64_t hidden_size, int dtype,
+                         void* workspace, int64_t workspace_bytes, mojo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,12 @@ SIGNATURES = {
     "mojo_hip_store_paged_kv_layout": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                                _I, _I, _I, _P]),
     "mojo_hip_swiglu": (c_int, [_P, _P, _P, _I, c_int, c_float, _P]),
+    "mojo_hip_swiglu_rows": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, c_int, c_float, _P]),
+    "mojo_hip_moe_gating": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, c_int, _P]),
+    "mojo_hip_moe_dispatch_workspace_bytes": (c_int64, [_I, _I]),
+    "mojo_hip_moe_dispatch": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, c_int, _P, _I, _P]),
+    "mojo_hip_moe_combine_workspace_bytes": (c_int64, [_I, _I]),
+    "mojo_hip_moe_combine": (c_int, [_P, _P, _P, _P, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_residual_add_rmsnorm": (c_int, [_P, _P, _P, _P, _P, _I, _I, c_int, c_float, _P]),
     "mojo_hip_apply_rope": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I64x3, _I64x3, _I64x3, _I64x3,
                                     _I, _I, c_int, _P]),

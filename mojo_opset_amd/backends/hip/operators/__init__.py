@@ -3,3 +3,4 @@ from .gemm import HIPGroupGemm, HIPQuantGemm  # noqa: F401
 from .streaming import *  # noqa: F401,F403
 from .mla import *  # noqa: F401,F403
 from .compute_with_comm import *  # noqa: F401,F403
+from .moe import *  # noqa: F401,F403

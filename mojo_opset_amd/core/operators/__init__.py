@@ -4,6 +4,7 @@ from .compute_with_comm import MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllRe
 from .gemm import MojoGroupGemm, MojoQuantGemm
 from .kv_cache import MojoStorePagedKVCache, build_paged_kv_chunk_metadata
 from .mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
+from .moe import MojoExperts, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
 from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm
 from .position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
 
@@ -11,5 +12,6 @@ __all__ = [
     "MojoSwiGLU", "MojoPagedDecodeGQA", "MojoPagedPrefillGQA", "MojoAllGatherGemm", "MojoGemmAll2All",
     "MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoGroupGemm", "MojoQuantGemm", "MojoStorePagedKVCache",
     "build_paged_kv_chunk_metadata", "MojoPagedDecodeMLA", "MojoPagedPrefillMLA", "MojoResidualAddRMSNorm",
-    "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding",
+    "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding", "MojoMoEGating", "MojoMoEDispatch", "MojoExperts",
+    "MojoMoECombine",
 ]

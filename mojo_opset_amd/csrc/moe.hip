@@ -1,0 +1,502 @@
+// MoE routing either side of the grouped GEMM: MojoMoEGating, MojoMoEDispatch, MojoMoECombine.
+// Reference semantics: mojo_opset/core/operators/moe.py:299-316 (gating), :344-400 (dispatch), :687-716 (combine).
+//
+// All three are HBM-bound byte/integer work (the gate matmul has E <= a few hundred columns):
+//   gating   reads T x hidden x elt once, writes 2 x T x k x 4 B;
+//   dispatch reads T x H x elt (each row k times, from L2 after the first) and writes T x k x H x elt;
+//   combine  reads N x H x elt and writes T x H x elt.
+// Nothing here syncs with the host; dispatch and combine are deterministic (no atomics decide an order).
+#include <math.h>
+
+#include "common.h"
+
+namespace mojo {
+
+// ---------------------------------------------------------------------------------------------------------
+// gating: logits = x.float() @ W (fp32), softmax over E, top-k (descending), gates / sum(selected)
+// ---------------------------------------------------------------------------------------------------------
+// A wave serves TPW = (64 / EP) * TT tokens, EP = min(pow2ceil(E), 64) lanes per token, each lane owning experts
+// lane%EP + EP*i (EI of them) for TT tokens: a weight element is loaded once per TT tokens, the activation vector is a
+// broadcast load.  Logits then go through LDS so that one token's E values sit on consecutive lanes for the softmax
+// and the k rounds of wave-wide arg-max.
+constexpr int GATE_MAX_E = 1024;
+
+template <typename T, int TT, int EI>
+__global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_gate,
+                                                         int64_t tokens, int hidden, int experts, int top_k, int ep_log2) {
+  extern __shared__ float s_logits[];                 // [4 waves][TPW][E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int EP = 1 << ep_log2;
+  const int sub = lane >> ep_log2, e0 = lane & (EP - 1);
+  const int subs = 64 >> ep_log2;
+  const int tpw = subs * TT;
+  const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+  const int64_t tok0 = wave_id * tpw;
+  float* my_logits = s_logits + static_cast<size_t>(wave) * tpw * experts;
+  if (tok0 < tokens) {
+    float acc[TT][EI];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int i = 0; i < EI; ++i) acc[t][i] = 0.f;
+    int64_t tok[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) tok[t] = min(tok0 + sub * TT + t, tokens - 1);     // clamped rows are computed, not stored
+    constexpr int VEC = 16 / sizeof(T);
+    typedef typename vec_of<T, VEC>::type V;
+    if (hidden % VEC == 0) {
+      for (int h = 0; h < hidden; h += VEC) {
+        V xv[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) xv[t] = load_vec<T, VEC>(x + tok[t] * hidden + h);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+#pragma unroll
+          for (int i = 0; i < EI; ++i) {
+            const int e = e0 + i * EP;
+            const float wv = e < experts ? w[static_cast<int64_t>(h + j) * experts + e] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[t][i] = fmaf(elt<T>::to_f(vget<T, VEC>(xv[t], j)), wv, acc[t][i]);
+          }
+        }
+      }
+    } else {
+      for (int h = 0; h < hidden; ++h) {
+#pragma unroll
+        for (int i = 0; i < EI; ++i) {
+          const int e = e0 + i * EP;
+          const float wv = e < experts ? w[static_cast<int64_t>(h) * experts + e] : 0.f;
+#pragma unroll
+          for (int t = 0; t < TT; ++t) acc[t][i] = fmaf(elt<T>::to_f(x[tok[t] * hidden + h]), wv, acc[t][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+      for (int i = 0; i < EI; ++i) {
+        const int e = e0 + i * EP;
+        if (e < experts) my_logits[(sub * TT + t) * experts + e] = acc[t][i];
+      }
+  }
+  __syncthreads();
+  if (tok0 >= tokens) return;
+  // softmax + top-k, one token at a time per wave; lane l holds experts l, l+64, ...
+  constexpr int PER = GATE_MAX_E / 64;
+  const int per = (experts + 63) >> 6;
+  for (int t = 0; t < tpw; ++t) {
+    const int64_t token = tok0 + t;
+    if (token >= tokens) break;
+    float v[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = lane + 64 * i;
+      v[i] = (i < per && e < experts) ? my_logits[t * experts + e] : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      v[i] = v[i] == -INFINITY ? 0.f : __expf(v[i] - mx);
+      sum += v[i];
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = (lane + 64 * i < experts) ? v[i] / sum : -1.f;      // -1: not a candidate
+    float sel_sum = 0.f, my_val = 0.f;
+    int my_idx = 0;
+    for (int r = 0; r < top_k; ++r) {
+      float best = -1.f;
+      int best_e = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (v[i] > best) { best = v[i]; best_e = lane + 64 * i; }     // ascending e inside a lane: first maximum wins
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oe = __shfl_xor(best_e, o);
+        if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        if (lane + 64 * i == best_e) v[i] = -1.f;
+      sel_sum += best;
+      if (lane == r) { my_val = best; my_idx = best_e; }           // top_k <= 64 results, one per lane
+    }
+    if (lane < top_k) {
+      out_idx[token * top_k + lane] = my_idx;
+      out_gate[token * top_k + lane] = my_val / sel_sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dispatch: stable counting sort of the T*k routing slots by expert id
+// ---------------------------------------------------------------------------------------------------------
+constexpr int DISP_MAX_E = 4096;
+
+__global__ __launch_bounds__(256) void moe_hist_kernel(const int32_t* __restrict__ ids, int64_t n, int experts,
+                                                       int32_t* __restrict__ block_hist) {
+  extern __shared__ int s_hist[];
+  for (int e = threadIdx.x; e < experts; e += 256) s_hist[e] = 0;
+  __syncthreads();
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) {
+    const int e = ids[i];
+    if (e >= 0 && e < experts) atomicAdd(&s_hist[e], 1);           // counts only: the order of the adds is irrelevant
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < experts; e += 256) block_hist[static_cast<int64_t>(blockIdx.x) * experts + e] = s_hist[e];
+}
+
+// one block: per expert, exclusive prefix over the blocks (in place), totals -> tokens_per_expert, exclusive scan -> start
+__global__ __launch_bounds__(256) void moe_scan_kernel(int32_t* __restrict__ block_hist, int blocks, int experts,
+                                                       int32_t* __restrict__ tokens_per_expert, int32_t* __restrict__ expert_start) {
+  __shared__ int s_part[256];
+  for (int e = threadIdx.x; e < experts; e += 256) {
+    int run = 0;
+    for (int b = 0; b < blocks; ++b) {
+      const int64_t at = static_cast<int64_t>(b) * experts + e;
+      const int c = block_hist[at];
+      block_hist[at] = run;
+      run += c;
+    }
+    tokens_per_expert[e] = run;
+  }
+  __syncthreads();
+  // exclusive scan of tokens_per_expert: thread t owns the contiguous chunk [t*chunk, (t+1)*chunk)
+  const int chunk = (experts + 255) / 256;
+  int local = 0;
+  for (int j = 0; j < chunk; ++j) {
+    const int e = threadIdx.x * chunk + j;
+    if (e < experts) local += tokens_per_expert[e];
+  }
+  s_part[threadIdx.x] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int c = s_part[t]; s_part[t] = run; run += c; }
+  }
+  __syncthreads();
+  int run = s_part[threadIdx.x];
+  for (int j = 0; j < chunk; ++j) {
+    const int e = threadIdx.x * chunk + j;
+    if (e < experts) { expert_start[e] = run; run += tokens_per_expert[e]; }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void moe_scatter_kernel(const T* __restrict__ hidden, const float* __restrict__ gates,
+                                                          const int32_t* __restrict__ ids, const int32_t* __restrict__ block_hist,
+                                                          const int32_t* __restrict__ expert_start, T* __restrict__ sorted_hidden,
+                                                          float* __restrict__ sorted_gates, int32_t* __restrict__ token_indices,
+                                                          int64_t n, int top_k, int hidden_size, int experts) {
+  extern __shared__ int s_mem[];
+  int* s_wave_cnt = s_mem;                    // [4][experts]
+  int* s_pos = s_mem + 4 * experts;           // [256] destination row of each slot of this block (-1: none)
+  int* s_tok = s_pos + 256;                   // [256] source token
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < 4 * experts; e += 256) s_wave_cnt[e] = 0;
+  __syncthreads();
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  int e = -1;
+  if (i < n) {
+    e = ids[i];
+    if (e < 0 || e >= experts) e = -1;        // out-of-range ids are dropped (the golden's bincount would raise)
+  }
+  // rank among the lower lanes of this wave that route to the same expert (stable inside the wave)
+  int rank = 0;
+  for (int j = 0; j < 64; ++j) {
+    const int ej = __builtin_amdgcn_readlane(e, j);
+    rank += (ej == e && j < lane) ? 1 : 0;
+  }
+  if (e >= 0) atomicAdd(&s_wave_cnt[wave * experts + e], 1);
+  __syncthreads();
+  int pos = -1;
+  if (e >= 0) {
+    int base = expert_start[e] + block_hist[static_cast<int64_t>(blockIdx.x) * experts + e];
+    for (int wv = 0; wv < wave; ++wv) base += s_wave_cnt[wv * experts + e];
+    pos = base + rank;
+    token_indices[pos] = static_cast<int32_t>(i / top_k);
+    sorted_gates[pos] = gates[i];
+  }
+  s_pos[threadIdx.x] = pos;
+  s_tok[threadIdx.x] = static_cast<int>(i / top_k);
+  __syncthreads();
+  // row copies: wave w moves the rows of slots w, w+4, ...; 16 B per lane
+  constexpr int VEC = 16 / sizeof(T);
+  const bool wide = hidden_size % VEC == 0 && (reinterpret_cast<uintptr_t>(hidden) % 16 == 0) &&
+                    (reinterpret_cast<uintptr_t>(sorted_hidden) % 16 == 0);
+  for (int s = wave; s < 256; s += 4) {
+    const int p = s_pos[s];
+    if (p < 0) continue;
+    const T* src = hidden + static_cast<int64_t>(s_tok[s]) * hidden_size;
+    T* dst = sorted_hidden + static_cast<int64_t>(p) * hidden_size;
+    if (wide) {
+      for (int c = lane * VEC; c < hidden_size; c += 64 * VEC) store_vec<T, VEC>(dst + c, load_vec<T, VEC>(src + c));
+    } else {
+      for (int c = lane; c < hidden_size; c += 64) dst[c] = src[c];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// combine: out[t] = sum over the rows routed from token t, in ascending row order (= the golden's scatter order),
+// fp32 from zero, product and sum rounded separately (no FMA) -> bit-identical to the golden
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moe_count_kernel(const int32_t* __restrict__ tok, int64_t n, int64_t tokens,
+                                                        int32_t* __restrict__ cnt) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (j < n) {
+    const int t = tok[j];
+    if (t >= 0 && t < tokens) atomicAdd(&cnt[t], 1);
+  }
+}
+
+// exclusive scan of cnt[0..tokens) into start[0..tokens], one block of 1024 threads
+__global__ __launch_bounds__(1024) void moe_token_scan_kernel(const int32_t* __restrict__ cnt, int64_t tokens,
+                                                              int32_t* __restrict__ start) {
+  __shared__ int s_part[1024];
+  const int64_t chunk = (tokens + 1023) / 1024;
+  const int64_t lo = threadIdx.x * chunk, hi = min(lo + chunk, tokens);
+  int local = 0;
+  for (int64_t t = lo; t < hi; ++t) local += cnt[t];
+  s_part[threadIdx.x] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 1024; ++t) { const int c = s_part[t]; s_part[t] = run; run += c; }
+  }
+  __syncthreads();
+  int run = s_part[threadIdx.x];
+  for (int64_t t = lo; t < hi; ++t) { start[t] = run; run += cnt[t]; }
+  if (threadIdx.x == 1023) start[tokens] = run;            // the last thread's chunk ends the array (empty chunks carry the total)
+}
+
+__global__ __launch_bounds__(256) void moe_fill_kernel(const int32_t* __restrict__ tok, int64_t n, int64_t tokens,
+                                                       const int32_t* __restrict__ start, int32_t* __restrict__ cursor,
+                                                       int32_t* __restrict__ list) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  if (j < n) {
+    const int t = tok[j];
+    if (t >= 0 && t < tokens) list[start[t] + atomicAdd(&cursor[t], 1)] = static_cast<int32_t>(j);   // sorted below
+  }
+}
+
+constexpr int COMB_MAX_LIST = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void moe_combine_kernel(const T* __restrict__ rows, const float* __restrict__ gates,
+                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ list,
+                                                          T* __restrict__ out, int hidden_size) {
+  __shared__ int s_list[COMB_MAX_LIST];
+  const int64_t t = blockIdx.x;
+  const int s0 = start[t];
+  int n = start[t + 1] - s0;
+  const bool sortable = n <= COMB_MAX_LIST;
+  if (sortable) {
+    // rank sort by row id (ids are distinct): s_list[rank] = id
+    for (int a = threadIdx.x; a < n; a += 256) {
+      const int id = list[s0 + a];
+      int rank = 0;
+      for (int b = 0; b < n; ++b) rank += list[s0 + b] < id ? 1 : 0;
+      s_list[rank] = id;
+    }
+    __syncthreads();
+  }
+  constexpr int VEC = 16 / sizeof(T);
+  typedef typename vec_of<T, VEC>::type V;
+  const bool wide = hidden_size % VEC == 0 && (reinterpret_cast<uintptr_t>(rows) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
+  T* dst = out + t * hidden_size;
+  if (wide) {
+    for (int c = threadIdx.x * VEC; c < hidden_size; c += 256 * VEC) {
+      float acc[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+      for (int a = 0; a < n; ++a) {
+        const int id = sortable ? s_list[a] : list[s0 + a];
+        const V r = load_vec<T, VEC>(rows + static_cast<int64_t>(id) * hidden_size + c);
+        const float g = gates ? gates[id] : 1.f;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const float f = elt<T>::to_f(vget<T, VEC>(r, q));
+          acc[q] = __fadd_rn(acc[q], gates ? __fmul_rn(f, g) : f);
+        }
+      }
+      V o;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) vset<T, VEC>(o, q, elt<T>::from_f(acc[q]));
+      store_vec<T, VEC>(dst + c, o);
+    }
+  } else {
+    for (int c = threadIdx.x; c < hidden_size; c += 256) {
+      float acc = 0.f;
+      for (int a = 0; a < n; ++a) {
+        const int id = sortable ? s_list[a] : list[s0 + a];
+        const float f = elt<T>::to_f(rows[static_cast<int64_t>(id) * hidden_size + c]);
+        acc = __fadd_rn(acc, gates ? __fmul_rn(f, gates[id]) : f);
+      }
+      dst[c] = elt<T>::from_f(acc);
+    }
+  }
+}
+
+static int pow2ceil_log2(int v) {
+  int lg = 0;
+  while ((1 << lg) < v) ++lg;
+  return lg;
+}
+
+template <typename T>
+static int launch_gating(const void* x, const float* w, int32_t* idx, float* gate, int64_t tokens, int hidden, int experts,
+                         int top_k, hipStream_t s) {
+  const int ep_log2 = pow2ceil_log2(experts < 64 ? experts : 64);
+  const int ep = 1 << ep_log2, subs = 64 / ep;
+  const int ei = (experts + ep - 1) / ep;                       // experts per lane
+  // tokens per wave = subs * TT: take the largest TT that still leaves >= 1024 waves (4 per SIMD), else TT = 1
+  int tt = 4;
+  while (tt > 1 && ceil_div(tokens, static_cast<int64_t>(subs) * tt) < 1024) tt >>= 1;
+  if (ei > 4 && tt > 2) tt = 2;                                 // register budget: TT * EI accumulators
+  const int tpw = subs * tt;
+  const int64_t waves = ceil_div(tokens, tpw), blocks = ceil_div(waves, 4);
+  const size_t lds = static_cast<size_t>(4) * tpw * experts * sizeof(float);
+  MOJO_REQUIRE(lds <= 64 * 1024, MOJO_EUNSUPPORTED, "moe_gating: %d experts need %zu B of LDS", experts, lds);
+  const T* xp = static_cast<const T*>(x);
+#define GATE_LAUNCH(TT_, EI_)                                                                                          \
+  hipLaunchKernelGGL((moe_gating_kernel<T, TT_, EI_>), dim3(static_cast<unsigned>(blocks)), dim3(256), lds, s, xp, w, idx, \
+                     gate, tokens, hidden, experts, top_k, ep_log2)
+#define GATE_EI(TT_)                                                                                                   \
+  do {                                                                                                                 \
+    if (ei <= 1) GATE_LAUNCH(TT_, 1); else if (ei <= 2) GATE_LAUNCH(TT_, 2); else if (ei <= 4) GATE_LAUNCH(TT_, 4);      \
+    else if (ei <= 8) GATE_LAUNCH(TT_, 8); else GATE_LAUNCH(TT_, 16);                                                   \
+  } while (0)
+  if (tt == 4) GATE_EI(4); else if (tt == 2) GATE_EI(2); else GATE_EI(1);
+#undef GATE_EI
+#undef GATE_LAUNCH
+  MOJO_CHECK_LAUNCH("moe_gating");
+  return MOJO_OK;
+}
+
+}  // namespace mojo
+
+using namespace mojo;
+
+extern "C" int mojo_hip_moe_gating(const void* hidden, const float* gate_weight, int32_t* top_k_indices,
+                                   float* top_k_gates, int64_t tokens, int64_t hidden_size, int64_t num_experts,
+                                   int64_t top_k, int dtype, mojo_stream_t stream) {
+  if (tokens == 0) return MOJO_OK;
+  MOJO_REQUIRE(hidden && gate_weight && top_k_indices && top_k_gates, MOJO_EINVAL, "moe_gating: null pointer");
+  MOJO_REQUIRE(tokens > 0 && hidden_size > 0 && hidden_size < (1LL << 30), MOJO_EINVAL, "moe_gating: bad shape");
+  MOJO_REQUIRE(num_experts >= 1 && num_experts <= GATE_MAX_E, MOJO_EUNSUPPORTED, "moe_gating: %lld experts (1..%d)",
+               (long long)num_experts, GATE_MAX_E);
+  MOJO_REQUIRE(top_k >= 1 && top_k <= num_experts && top_k <= 64, MOJO_EUNSUPPORTED, "moe_gating: top_k %lld (1..min(E,64))",
+               (long long)top_k);
+  MOJO_REQUIRE(aligned_to(hidden, 16), MOJO_EUNSUPPORTED, "moe_gating: hidden_states must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int h = static_cast<int>(hidden_size), e = static_cast<int>(num_experts), k = static_cast<int>(top_k);
+  switch (dtype) {
+    case MOJO_F32: return launch_gating<float>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, s);
+    case MOJO_F16: return launch_gating<f16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, s);
+    case MOJO_BF16: return launch_gating<bf16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, s);
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "moe_gating: dtype %d not supported", dtype);
+  }
+}
+
+extern "C" int64_t mojo_hip_moe_dispatch_workspace_bytes(int64_t slots, int64_t num_experts) {
+  const int64_t blocks = ceil_div(slots > 0 ? slots : 1, 256);
+  return (blocks * num_experts + num_experts) * static_cast<int64_t>(sizeof(int32_t)) + 64;
+}
+
+extern "C" int mojo_hip_moe_dispatch(const void* hidden, const float* top_k_gates, const int32_t* top_k_indices,
+                                     void* sorted_hidden, int32_t* tokens_per_expert, float* sorted_gates,
+                                     int32_t* token_indices, int64_t tokens, int64_t hidden_size, int64_t top_k,
+                                     int64_t num_experts, int dtype, void* workspace, int64_t workspace_bytes,
+                                     mojo_stream_t stream) {
+  MOJO_REQUIRE(tokens >= 0 && hidden_size > 0 && top_k >= 1 && num_experts >= 1, MOJO_EINVAL, "moe_dispatch: bad shape");
+  MOJO_REQUIRE(num_experts <= DISP_MAX_E, MOJO_EUNSUPPORTED, "moe_dispatch: %lld experts (<= %d)", (long long)num_experts, DISP_MAX_E);
+  MOJO_REQUIRE(tokens_per_expert, MOJO_EINVAL, "moe_dispatch: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t n = tokens * top_k;
+  if (n == 0) {
+    if (hipMemsetAsync(tokens_per_expert, 0, static_cast<size_t>(num_experts) * sizeof(int32_t), s) != hipSuccess) {
+      set_error("moe_dispatch: memset failed");
+      return MOJO_ELAUNCH;
+    }
+    return MOJO_OK;
+  }
+  MOJO_REQUIRE(hidden && top_k_gates && top_k_indices && sorted_hidden && sorted_gates && token_indices, MOJO_EINVAL,
+               "moe_dispatch: null pointer");
+  MOJO_REQUIRE(n < (1LL << 31) && hidden_size < (1LL << 31), MOJO_EUNSUPPORTED, "moe_dispatch: too many routing slots");
+  MOJO_REQUIRE(dtype == MOJO_F32 || dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED, "moe_dispatch: dtype %d", dtype);
+  MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_moe_dispatch_workspace_bytes(n, num_experts) && aligned_to(workspace, 4),
+               MOJO_EWORKSPACE, "moe_dispatch: workspace too small");
+  const int e = static_cast<int>(num_experts);
+  const int blocks = static_cast<int>(ceil_div(n, 256));
+  int32_t* block_hist = static_cast<int32_t*>(workspace);
+  int32_t* expert_start = block_hist + static_cast<int64_t>(blocks) * e;
+  hipLaunchKernelGGL(moe_hist_kernel, dim3(blocks), dim3(256), e * sizeof(int), s, top_k_indices, n, e, block_hist);
+  MOJO_CHECK_LAUNCH("moe_dispatch(hist)");
+  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(256), 0, s, block_hist, blocks, e, tokens_per_expert, expert_start);
+  MOJO_CHECK_LAUNCH("moe_dispatch(scan)");
+  const size_t lds = (static_cast<size_t>(4) * e + 512) * sizeof(int);
+  const int k = static_cast<int>(top_k), h = static_cast<int>(hidden_size);
+#define SCATTER(TY)                                                                                                    \
+  hipLaunchKernelGGL(moe_scatter_kernel<TY>, dim3(blocks), dim3(256), lds, s, static_cast<const TY*>(hidden), top_k_gates, \
+                     top_k_indices, block_hist, expert_start, static_cast<TY*>(sorted_hidden), sorted_gates, token_indices, \
+                     n, k, h, e)
+  if (dtype == MOJO_F32) SCATTER(float); else if (dtype == MOJO_F16) SCATTER(f16_t); else SCATTER(bf16_t);
+#undef SCATTER
+  MOJO_CHECK_LAUNCH("moe_dispatch(scatter)");
+  return MOJO_OK;
+}
+
+extern "C" int64_t mojo_hip_moe_combine_workspace_bytes(int64_t tokens, int64_t rows) {
+  return (2 * tokens + 1 + rows) * static_cast<int64_t>(sizeof(int32_t)) + 64;
+}
+
+extern "C" int mojo_hip_moe_combine(const void* expert_outputs, const float* sorted_gates, const int32_t* token_indices,
+                                    void* out, int64_t tokens, int64_t rows, int64_t hidden_size, int dtype,
+                                    void* workspace, int64_t workspace_bytes, mojo_stream_t stream) {
+  MOJO_REQUIRE(tokens >= 0 && rows >= 0 && hidden_size > 0 && hidden_size < (1LL << 31), MOJO_EINVAL, "moe_combine: bad shape");
+  if (tokens == 0) return MOJO_OK;
+  MOJO_REQUIRE(out && (rows == 0 || (expert_outputs && token_indices)), MOJO_EINVAL, "moe_combine: null pointer");
+  MOJO_REQUIRE(tokens < (1LL << 31) && rows < (1LL << 31), MOJO_EUNSUPPORTED, "moe_combine: too many rows");
+  MOJO_REQUIRE(dtype == MOJO_F32 || dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED, "moe_combine: dtype %d", dtype);
+  MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_moe_combine_workspace_bytes(tokens, rows) && aligned_to(workspace, 4),
+               MOJO_EWORKSPACE, "moe_combine: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int32_t* cnt = static_cast<int32_t*>(workspace);      // [tokens]   (reused as the fill cursor)
+  int32_t* start = cnt + tokens;                        // [tokens + 1]
+  int32_t* list = start + tokens + 1;                   // [rows]
+  if (hipMemsetAsync(cnt, 0, static_cast<size_t>(tokens) * sizeof(int32_t), s) != hipSuccess) {
+    set_error("moe_combine: memset failed");
+    return MOJO_ELAUNCH;
+  }
+  const int row_blocks = static_cast<int>(ceil_div(rows > 0 ? rows : 1, 256));
+  if (rows > 0) {
+    hipLaunchKernelGGL(moe_count_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, cnt);
+    MOJO_CHECK_LAUNCH("moe_combine(count)");
+  }
+  hipLaunchKernelGGL(moe_token_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, tokens, start);
+  MOJO_CHECK_LAUNCH("moe_combine(scan)");
+  if (rows > 0) {
+    if (hipMemsetAsync(cnt, 0, static_cast<size_t>(tokens) * sizeof(int32_t), s) != hipSuccess) {
+      set_error("moe_combine: memset failed");
+      return MOJO_ELAUNCH;
+    }
+    hipLaunchKernelGGL(moe_fill_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, start, cnt, list);
+    MOJO_CHECK_LAUNCH("moe_combine(fill)");
+  }
+  const int h = static_cast<int>(hidden_size);
+#define COMBINE(TY)                                                                                                    \
+  hipLaunchKernelGGL(moe_combine_kernel<TY>, dim3(static_cast<unsigned>(tokens)), dim3(256), 0, s,                       \
+                     static_cast<const TY*>(expert_outputs), sorted_gates, start, list, static_cast<TY*>(out), h)
+  if (dtype == MOJO_F32) COMBINE(float); else if (dtype == MOJO_F16) COMBINE(f16_t); else COMBINE(bf16_t);
+#undef COMBINE
+  MOJO_CHECK_LAUNCH("moe_combine");
+  return MOJO_OK;
+}

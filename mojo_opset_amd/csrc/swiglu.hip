@@ -60,6 +60,45 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gate,
   }
 }
 
+// row-strided variant: gate / up / out are [rows, cols] views with their own row strides (the two halves of a fused
+// [rows, 2*cols] projection output, MojoExperts)
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void swiglu_rows_kernel(const T* __restrict__ gate, const T* __restrict__ up,
+                                                          T* __restrict__ out, int64_t rows, int cols_vec, int64_t ld_gate,
+                                                          int64_t ld_up, int64_t ld_out, float limit) {
+  typedef typename vec_of<T, VEC>::type V;
+  const int64_t total = rows * cols_vec;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / cols_vec;
+    const int c = static_cast<int>(i - r * cols_vec) * VEC;
+    const V g = load_vec<T, VEC>(gate + r * ld_gate + c);
+    const V u = load_vec<T, VEC>(up + r * ld_up + c);
+    store_vec<T, VEC>(out + r * ld_out + c, swiglu_vec<T, VEC>(g, u, limit));
+  }
+}
+
+template <typename T>
+static int launch_swiglu_rows(const void* gate, const void* up, void* out, int64_t rows, int64_t cols, int64_t ld_gate,
+                              int64_t ld_up, int64_t ld_out, float limit, hipStream_t s) {
+  constexpr int WIDE = 16 / sizeof(T);
+  const bool wide = cols % WIDE == 0 && ld_gate % WIDE == 0 && ld_up % WIDE == 0 && ld_out % WIDE == 0 &&
+                    aligned_to(gate, 16) && aligned_to(up, 16) && aligned_to(out, 16);
+  const int64_t total = wide ? rows * (cols / WIDE) : rows * cols;
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (wide)
+    hipLaunchKernelGGL((swiglu_rows_kernel<T, WIDE>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+                       static_cast<const T*>(up), static_cast<T*>(out), rows, static_cast<int>(cols / WIDE), ld_gate, ld_up,
+                       ld_out, limit);
+  else
+    hipLaunchKernelGGL((swiglu_rows_kernel<T, 1>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+                       static_cast<const T*>(up), static_cast<T*>(out), rows, static_cast<int>(cols), ld_gate, ld_up, ld_out,
+                       limit);
+  MOJO_CHECK_LAUNCH("swiglu_rows");
+  return MOJO_OK;
+}
+
 template <typename T>
 static int launch_swiglu(const void* gate, const void* up, void* out, int64_t n, float limit, hipStream_t s) {
   constexpr int WIDE = 16 / sizeof(T);
@@ -92,5 +131,20 @@ extern "C" int mojo_hip_swiglu(const void* gate, const void* up, void* out, int6
     case MOJO_F16: return launch_swiglu<f16_t>(gate, up, out, n, swiglu_limit, s);
     case MOJO_BF16: return launch_swiglu<bf16_t>(gate, up, out, n, swiglu_limit, s);
     default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "swiglu: dtype %d not supported", dtype);
+  }
+}
+
+extern "C" int mojo_hip_swiglu_rows(const void* gate, const void* up, void* out, int64_t rows, int64_t cols,
+                                    int64_t ld_gate, int64_t ld_up, int64_t ld_out, int dtype, float swiglu_limit,
+                                    mojo_stream_t stream) {
+  if (rows == 0 || cols == 0) return MOJO_OK;
+  MOJO_REQUIRE(gate && up && out && rows > 0 && cols > 0 && cols < (1LL << 31), MOJO_EINVAL, "swiglu_rows: bad arguments");
+  MOJO_REQUIRE(ld_gate >= cols && ld_up >= cols && ld_out >= cols, MOJO_EINVAL, "swiglu_rows: row stride smaller than the row");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case MOJO_F32: return launch_swiglu_rows<float>(gate, up, out, rows, cols, ld_gate, ld_up, ld_out, swiglu_limit, s);
+    case MOJO_F16: return launch_swiglu_rows<f16_t>(gate, up, out, rows, cols, ld_gate, ld_up, ld_out, swiglu_limit, s);
+    case MOJO_BF16: return launch_swiglu_rows<bf16_t>(gate, up, out, rows, cols, ld_gate, ld_up, ld_out, swiglu_limit, s);
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "swiglu_rows: dtype %d not supported", dtype);
   }
 }

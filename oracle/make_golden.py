@@ -330,6 +330,50 @@ def gen_group_gemm():
     return recs
 
 
+def gen_moe():
+    """Gating / dispatch / experts / combine on the reference's own small shapes (tests/accuracy/operators/test_moe.py)
+    plus ragged and empty-bucket cases."""
+    recs = []
+    for ci, (experts, k, hidden, tokens, std) in enumerate([(16, 4, 1024, 64, 0.02), (8, 2, 256, 37, 0.02), (64, 8, 512, 48, 0.05),
+                                                            (384, 8, 128, 16, 0.5)]):
+        torch.manual_seed(1300 + ci)
+        w = torch.randn(hidden, experts) * std
+        x = torch.rand(tokens, hidden, dtype=torch.bfloat16)
+        probs = torch.softmax(x.float() @ w, dim=-1).sort(dim=-1, descending=True).values
+        assert float((probs[:, :k] - probs[:, 1: k + 1]).min()) > 1e-5, "near-tie in the gating vector: pick another seed"
+        recs.append(run_case("MojoMoEGating", {"kwargs": {"hidden_size": hidden, "num_experts": experts, "top_k": k}},
+                             {"gate_weight": w}, (x,), {}))
+    for ci, (experts, k, hidden, tokens) in enumerate([(16, 4, 256, 64), (8, 2, 128, 37), (64, 8, 64, 48), (384, 8, 96, 16), (4, 1, 64, 0)]):
+        torch.manual_seed(1320 + ci)
+        x = torch.rand(tokens, hidden, dtype=torch.bfloat16)
+        probs = torch.softmax(torch.randn(tokens, experts), dim=-1)
+        gates, idx = torch.topk(probs, k, dim=-1)
+        gates = (gates / gates.sum(dim=-1, keepdim=True)).contiguous()
+        recs.append(run_case("MojoMoEDispatch", {"kwargs": {"num_experts": experts}}, {},
+                             (x, gates, idx.to(torch.int32).contiguous()), {}))
+    for ci, (experts, hidden, inter, counts) in enumerate([(4, 256, 512, [3, 0, 5, 4]), (8, 128, 64, [2, 1, 0, 3, 4, 0, 5, 2])]):
+        torch.manual_seed(1340 + ci)
+        up = (torch.randn(experts, 2 * inter, hidden) * 0.02).to(torch.bfloat16)
+        down = (torch.randn(experts, hidden, inter) * 0.02).to(torch.bfloat16)
+        x = torch.rand(sum(counts), hidden, dtype=torch.bfloat16)
+        recs.append(run_case("MojoExperts", {"kwargs": {"num_experts": experts, "hidden_size": hidden, "intermediate_size": inter}},
+                             {"up_proj_weight": up, "down_proj_weight": down},
+                             (x, torch.tensor(counts, dtype=torch.int32)), {}, cast=torch.bfloat16))
+    for ci, (tokens, k, hidden, by_gates, dtype) in enumerate([(64, 4, 256, True, torch.bfloat16), (33, 2, 96, True, torch.float16),
+                                                               (16, 8, 128, False, torch.bfloat16), (5, 3, 64, True, torch.float32)]):
+        torch.manual_seed(1360 + ci)
+        n = tokens * k
+        perm = torch.randperm(n)
+        outs = torch.randn(n, hidden, dtype=dtype)[perm].contiguous()
+        gates = torch.rand(n, 1)[perm].contiguous()
+        tok = torch.arange(tokens, dtype=torch.int32).unsqueeze(1).expand(-1, k).reshape(-1)[perm].contiguous()
+        if ci == 1:                      # an EP-style slice: not every token appears, some appear once
+            outs, gates, tok = outs[: n // 2], gates[: n // 2], tok[: n // 2]
+        recs.append(run_case("MojoMoECombine", {"kwargs": {"multiply_by_gates": by_gates}}, {},
+                             (torch.zeros(tokens, hidden, dtype=dtype), outs, gates, tok), {}))
+    return recs
+
+
 def quantize_rows(x):
     scale = x.abs().amax(dim=-1).clamp_min(1e-8) / 127.0
     return torch.clamp(torch.round(x / scale.unsqueeze(-1)), -128, 127).to(torch.int8), scale
@@ -432,6 +476,7 @@ def main():
         "rope": gen_rope(),
         "group_gemm": gen_group_gemm(),
         "quant_gemm": gen_quant_gemm(),
+        "moe": gen_moe(),
     }
     store, plans = gen_store_kv()
     groups["store_paged_kv"] = store

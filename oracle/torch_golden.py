@@ -17,6 +17,7 @@ from mojo_opset_amd.core.operators import compute_with_comm as _cc
 from mojo_opset_amd.core.operators import gemm as _gemm_api
 from mojo_opset_amd.core.operators import kv_cache as _kv
 from mojo_opset_amd.core.operators import mla as _mla
+from mojo_opset_amd.core.operators import moe as _moe
 from mojo_opset_amd.core.operators import normalization as _norm
 from mojo_opset_amd.core.operators import position_embedding as _pe
 
@@ -27,6 +28,7 @@ __all__ = [
     "TorchRMSNorm", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
     "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
     "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
+    "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine",
     "gather_pages", "quant_gemm_formula",
 ]
 
@@ -489,3 +491,64 @@ class TorchGemmReduceScatter(_cc.MojoGemmReduceScatter):
             dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
             mine = total.chunk(ws, dim=self.scatter_dim)[rank].contiguous()
         return mine
+
+
+# ----------------------------------------------------------------------------------------------
+# MoE routing
+# ----------------------------------------------------------------------------------------------
+class TorchMoEGating(_moe.MojoMoEGating):
+    """`core/operators/moe.py:299-316`: fp32 logits, softmax over all experts, top-k, renormalise."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_states):
+        assert self.gate_weight.dtype == torch.float32
+        probs = torch.softmax(torch.matmul(hidden_states.float(), self.gate_weight), dim=-1)
+        top_vals, top_idx = torch.topk(probs, self.top_k, dim=-1)
+        return top_idx.to(torch.int32), top_vals / torch.sum(top_vals, dim=-1, keepdim=True)
+
+
+class TorchMoEDispatch(_moe.MojoMoEDispatch):
+    """`core/operators/moe.py:344-400`: (non-stable) sort of the flat expert ids, gather rows / gates / token ids."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_states, top_k_gates, top_k_indices):
+        self.check_call_contract(hidden_states, top_k_gates, top_k_indices)
+        k = top_k_indices.shape[-1]
+        token_of_slot = (torch.arange(0, hidden_states.shape[0], device=hidden_states.device, dtype=top_k_indices.dtype)
+                         .unsqueeze(1).repeat(1, k).flatten())
+        flat_ids = top_k_indices.flatten()
+        _, order = flat_ids.sort()
+        token_indices = token_of_slot[order]
+        tokens_per_expert = _moe.count_expert_tokens(flat_ids, self.num_experts)
+        sorted_gates = top_k_gates.reshape(-1, 1)[order, :]
+        return hidden_states[token_indices].squeeze(1), tokens_per_expert, sorted_gates, token_indices
+
+
+class TorchExperts(_moe.MojoExperts):
+    """`core/operators/moe.py:432-449`: per expert, everything in fp32, one cast at the end."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, sorted_hidden_states, tokens_per_expert):
+        pieces = torch.split(sorted_hidden_states, tokens_per_expert.tolist(), dim=0)
+        outs = []
+        for e, x in enumerate(pieces):
+            gate, up = F.linear(x.float(), self.up_proj_weight[e].float()).chunk(2, dim=-1)
+            outs.append(F.linear(F.silu(gate) * up, self.down_proj_weight[e].float()))
+        return torch.cat(outs, dim=0).to(sorted_hidden_states.dtype)
+
+
+class TorchMoECombine(_moe.MojoMoECombine):
+    """`core/operators/moe.py:687-716`: fp32 scatter-add from zero, cast to the expert-output dtype."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, output_buffer, expert_outputs, sorted_gates, token_indices):
+        rows = expert_outputs.float()
+        if self.multiply_by_gates:
+            rows = rows * sorted_gates.float()
+        index = token_indices.to(torch.int64).unsqueeze(-1).expand(-1, output_buffer.size(1))
+        acc = torch.zeros_like(output_buffer, dtype=torch.float32)
+        return acc.scatter_reduce(0, index, rows, reduce="sum", include_self=True).to(expert_outputs.dtype)
