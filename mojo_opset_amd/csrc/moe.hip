@@ -15,10 +15,10 @@ namespace mojo {
 // ---------------------------------------------------------------------------------------------------------
 // gating: logits = x.float() @ W (fp32), softmax over E, top-k (descending), gates / sum(selected)
 // ---------------------------------------------------------------------------------------------------------
-// A wave serves TPW = (64 / EP) * TT tokens, EP = min(pow2ceil(E), 64) lanes per token, each lane owning experts
+// A block serves TPW = (64 / EP) * TT tokens, EP = min(pow2ceil(E), 64) lanes per token, each lane owning experts
 // lane%EP + EP*i (EI of them) for TT tokens: a weight element is loaded once per TT tokens, the activation vector is a
-// broadcast load.  Logits then go through LDS so that one token's E values sit on consecutive lanes for the softmax
-// and the k rounds of wave-wide arg-max.
+// broadcast load.  The four waves of the block split the hidden dimension; their partial logits meet in LDS, where one
+// token's E values then sit on consecutive lanes for the softmax and the k rounds of wave-wide arg-max.
 constexpr int GATE_MAX_E = 1024;
 
 template <typename T, int TT, int EI>
@@ -31,10 +31,9 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
   const int sub = lane >> ep_log2, e0 = lane & (EP - 1);
   const int subs = 64 >> ep_log2;
   const int tpw = subs * TT;
-  const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * 4 + wave;
-  const int64_t tok0 = wave_id * tpw;
+  const int64_t tok0 = static_cast<int64_t>(blockIdx.x) * tpw;
   float* my_logits = s_logits + static_cast<size_t>(wave) * tpw * experts;
-  if (tok0 < tokens) {
+  {
     float acc[TT][EI];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -46,7 +45,9 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
     constexpr int VEC = 16 / sizeof(T);
     typedef typename vec_of<T, VEC>::type V;
     if (hidden % VEC == 0) {
-      for (int h = 0; h < hidden; h += VEC) {
+      const int per_wave = ((hidden / VEC + 3) / 4) * VEC;              // this wave's slice of the hidden dimension
+      const int h_end = min(hidden, (wave + 1) * per_wave);
+      for (int h = wave * per_wave; h < h_end; h += VEC) {
         V xv[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) xv[t] = load_vec<T, VEC>(x + tok[t] * hidden + h);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
         }
       }
     } else {
-      for (int h = 0; h < hidden; ++h) {
+      for (int h = wave; h < hidden; h += 4) {
 #pragma unroll
         for (int i = 0; i < EI; ++i) {
           const int e = e0 + i * EP;
@@ -81,11 +82,11 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
       }
   }
   __syncthreads();
-  if (tok0 >= tokens) return;
-  // softmax + top-k, one token at a time per wave; lane l holds experts l, l+64, ...
+  // softmax + top-k: wave w takes tokens w, w+4, ... of the block; lane l holds experts l, l+64, ...
   constexpr int PER = GATE_MAX_E / 64;
   const int per = (experts + 63) >> 6;
-  for (int t = 0; t < tpw; ++t) {
+  const int part = tpw * experts;                                       // stride between the waves' partial logits
+  for (int t = wave; t < tpw; t += 4) {
     const int64_t token = tok0 + t;
     if (token >= tokens) break;
     float v[PER];
@@ -93,7 +94,12 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = lane + 64 * i;
-      v[i] = (i < per && e < experts) ? my_logits[t * experts + e] : -INFINITY;
+      if (i < per && e < experts) {
+        const float* l = s_logits + t * experts + e;
+        v[i] = (l[0] + l[part]) + (l[2 * part] + l[3 * part]);
+      } else {
+        v[i] = -INFINITY;
+      }
       mx = fmaxf(mx, v[i]);
     }
 #pragma unroll
@@ -189,16 +195,12 @@ __global__ __launch_bounds__(256) void moe_scan_kernel(int32_t* __restrict__ blo
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void moe_scatter_kernel(const T* __restrict__ hidden, const float* __restrict__ gates,
-                                                          const int32_t* __restrict__ ids, const int32_t* __restrict__ block_hist,
-                                                          const int32_t* __restrict__ expert_start, T* __restrict__ sorted_hidden,
+__global__ __launch_bounds__(256) void moe_scatter_kernel(const float* __restrict__ gates, const int32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ block_hist,
+                                                          const int32_t* __restrict__ expert_start,
                                                           float* __restrict__ sorted_gates, int32_t* __restrict__ token_indices,
-                                                          int64_t n, int top_k, int hidden_size, int experts) {
-  extern __shared__ int s_mem[];
-  int* s_wave_cnt = s_mem;                    // [4][experts]
-  int* s_pos = s_mem + 4 * experts;           // [256] destination row of each slot of this block (-1: none)
-  int* s_tok = s_pos + 256;                   // [256] source token
+                                                          int64_t n, int top_k, int experts) {
+  extern __shared__ int s_wave_cnt[];         // [4][experts]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int e = threadIdx.x; e < 4 * experts; e += 256) s_wave_cnt[e] = 0;
   __syncthreads();
@@ -216,31 +218,35 @@ __global__ __launch_bounds__(256) void moe_scatter_kernel(const T* __restrict__ 
   }
   if (e >= 0) atomicAdd(&s_wave_cnt[wave * experts + e], 1);
   __syncthreads();
-  int pos = -1;
   if (e >= 0) {
     int base = expert_start[e] + block_hist[static_cast<int64_t>(blockIdx.x) * experts + e];
     for (int wv = 0; wv < wave; ++wv) base += s_wave_cnt[wv * experts + e];
-    pos = base + rank;
+    const int pos = base + rank;
     token_indices[pos] = static_cast<int32_t>(i / top_k);
     sorted_gates[pos] = gates[i];
   }
-  s_pos[threadIdx.x] = pos;
-  s_tok[threadIdx.x] = static_cast<int>(i / top_k);
-  __syncthreads();
-  // row copies: wave w moves the rows of slots w, w+4, ...; 16 B per lane
+}
+
+// sorted_hidden[p] = hidden[token_indices[p]]: one wave per destination row, 16 B per lane.  (A separate launch: the
+// scatter kernel has one block per 256 slots — 64 blocks for Mixtral's 16K slots — far too few to move 2 x 134 MB.)
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gather_rows_kernel(const T* __restrict__ hidden, const int32_t* __restrict__ token_indices,
+                                                              T* __restrict__ sorted_hidden, int64_t n, int hidden_size,
+                                                              int64_t tokens) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  // (rows past the routed total — only possible when ids were dropped — hold an unwritten index: clamp it)
+  const int64_t t = min(max(static_cast<int64_t>(token_indices[p]), static_cast<int64_t>(0)), tokens - 1);
+  const T* src = hidden + t * hidden_size;
+  T* dst = sorted_hidden + p * hidden_size;
   constexpr int VEC = 16 / sizeof(T);
   const bool wide = hidden_size % VEC == 0 && (reinterpret_cast<uintptr_t>(hidden) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(sorted_hidden) % 16 == 0);
-  for (int s = wave; s < 256; s += 4) {
-    const int p = s_pos[s];
-    if (p < 0) continue;
-    const T* src = hidden + static_cast<int64_t>(s_tok[s]) * hidden_size;
-    T* dst = sorted_hidden + static_cast<int64_t>(p) * hidden_size;
-    if (wide) {
-      for (int c = lane * VEC; c < hidden_size; c += 64 * VEC) store_vec<T, VEC>(dst + c, load_vec<T, VEC>(src + c));
-    } else {
-      for (int c = lane; c < hidden_size; c += 64) dst[c] = src[c];
-    }
+  if (wide) {
+    for (int c = lane * VEC; c < hidden_size; c += 64 * VEC) store_vec<T, VEC>(dst + c, load_vec<T, VEC>(src + c));
+  } else {
+    for (int c = lane; c < hidden_size; c += 64) dst[c] = src[c];
   }
 }
 
@@ -357,12 +363,12 @@ static int launch_gating(const void* x, const float* w, int32_t* idx, float* gat
   const int ep_log2 = pow2ceil_log2(experts < 64 ? experts : 64);
   const int ep = 1 << ep_log2, subs = 64 / ep;
   const int ei = (experts + ep - 1) / ep;                       // experts per lane
-  // tokens per wave = subs * TT: take the largest TT that still leaves >= 1024 waves (4 per SIMD), else TT = 1
+  // tokens per block = subs * TT: take the largest TT that still leaves >= 512 blocks (2 per CU), else TT = 1
   int tt = 4;
-  while (tt > 1 && ceil_div(tokens, static_cast<int64_t>(subs) * tt) < 1024) tt >>= 1;
+  while (tt > 1 && ceil_div(tokens, static_cast<int64_t>(subs) * tt) < 512) tt >>= 1;
   if (ei > 4 && tt > 2) tt = 2;                                 // register budget: TT * EI accumulators
   const int tpw = subs * tt;
-  const int64_t waves = ceil_div(tokens, tpw), blocks = ceil_div(waves, 4);
+  const int64_t blocks = ceil_div(tokens, tpw);
   const size_t lds = static_cast<size_t>(4) * tpw * experts * sizeof(float);
   MOJO_REQUIRE(lds <= 64 * 1024, MOJO_EUNSUPPORTED, "moe_gating: %d experts need %zu B of LDS", experts, lds);
   const T* xp = static_cast<const T*>(x);
@@ -442,15 +448,18 @@ extern "C" int mojo_hip_moe_dispatch(const void* hidden, const float* top_k_gate
   MOJO_CHECK_LAUNCH("moe_dispatch(hist)");
   hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(256), 0, s, block_hist, blocks, e, tokens_per_expert, expert_start);
   MOJO_CHECK_LAUNCH("moe_dispatch(scan)");
-  const size_t lds = (static_cast<size_t>(4) * e + 512) * sizeof(int);
+  const size_t lds = static_cast<size_t>(4) * e * sizeof(int);
   const int k = static_cast<int>(top_k), h = static_cast<int>(hidden_size);
-#define SCATTER(TY)                                                                                                    \
-  hipLaunchKernelGGL(moe_scatter_kernel<TY>, dim3(blocks), dim3(256), lds, s, static_cast<const TY*>(hidden), top_k_gates, \
-                     top_k_indices, block_hist, expert_start, static_cast<TY*>(sorted_hidden), sorted_gates, token_indices, \
-                     n, k, h, e)
-  if (dtype == MOJO_F32) SCATTER(float); else if (dtype == MOJO_F16) SCATTER(f16_t); else SCATTER(bf16_t);
-#undef SCATTER
+  hipLaunchKernelGGL(moe_scatter_kernel, dim3(blocks), dim3(256), lds, s, top_k_gates, top_k_indices, block_hist, expert_start,
+                     sorted_gates, token_indices, n, k, e);
   MOJO_CHECK_LAUNCH("moe_dispatch(scatter)");
+  const unsigned row_blocks = static_cast<unsigned>(ceil_div(n, 4));
+#define GATHER(TY)                                                                                                     \
+  hipLaunchKernelGGL(moe_gather_rows_kernel<TY>, dim3(row_blocks), dim3(256), 0, s, static_cast<const TY*>(hidden),      \
+                     token_indices, static_cast<TY*>(sorted_hidden), n, h, tokens)
+  if (dtype == MOJO_F32) GATHER(float); else if (dtype == MOJO_F16) GATHER(f16_t); else GATHER(bf16_t);
+#undef GATHER
+  MOJO_CHECK_LAUNCH("moe_dispatch(gather)");
   return MOJO_OK;
 }
 

@@ -1,4 +1,5 @@
 cd /root/repo; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_hip_moe.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|^E " gpurun_out/t.log | head -30
 python - <<'PY'
 import json, torch, sys
 sys.path.insert(0, '.')
