@@ -164,6 +164,16 @@ def bench_streaming(device):
     out["residual_add_rmsnorm_bf16_65536x4096"] = _hbm(_time(lambda: norm(x, r), 20, 3), 4 * rows * d * 2)
     out["swiglu_bf16_65536x4096"] = _hbm(_time(lambda: hip("MojoSwiGLU")()(x, r), 20, 3), 3 * rows * d * 2)
     del x, r
+    # per-token activation quantisers (DeepSeek-V3 hidden 7168)
+    rows, d = 8192, 7168
+    x, r = torch.randn(rows, d, device=device, dtype=torch.bfloat16), torch.randn(rows, d, device=device, dtype=torch.bfloat16)
+    dq = hip("MojoDynamicQuant")()
+    out["dynamic_quant_bf16_8192x7168"] = _hbm(_time(lambda: dq(x), 20, 3), rows * d * 3 + rows * 4)
+    nq = hip("MojoResidualAddRMSNormQuant")(norm_size=d).to(device)
+    with torch.no_grad():
+        nq.weight.copy_(torch.randn(d))
+    out["residual_add_rmsnorm_quant_bf16_8192x7168"] = _hbm(_time(lambda: nq(x, r), 20, 3), rows * d * 7 + d * 4 + rows * 4)
+    del x, r
     # RoPE: q [1,32,8192,128] + k [1,8,8192,128] head-first bf16 (the reference's published case)
     q = torch.randn(1, 32, 8192, 128, device=device, dtype=torch.bfloat16)
     k = torch.randn(1, 8, 8192, 128, device=device, dtype=torch.bfloat16)

@@ -243,6 +243,21 @@ int mojo_hip_moe_combine(const void* expert_outputs, const float* sorted_gates, 
                          void* out, int64_t tokens, int64_t rows, int64_t hidden_size, int dtype,
                          void* workspace, int64_t workspace_bytes, mojo_stream_t stream);
 
+/* ---- Per-token activation quantisers feeding MojoQuantGemm.
+ *      dynamic_quant (core/operators/quantize.py:153-169): y = x.float() [* inv_smooth_scale[K] fp32, nullable];
+ *      scale = max(amax|y|, 1e-12) / 127, 1.0 where that is < 1e-6; q = clamp(round_half_even(y / scale), -128, 127).
+ *      residual_add_rmsnorm_quant (core/operators/normalization.py:493-526): s = hidden + residual (rounded to the
+ *      input dtype; residual nullable), y = rms_norm(s.float(), weight fp32, eps) [* smooth_scale fp32, nullable] kept
+ *      in fp32, scale = max(amax|y|, 1e-12) / q_max (127 or 448), q = clamp(round_half_even(y / scale), q_min, q_max)
+ *      as int8 or as float8_e4m3fn of that integer value.  out_sum (T, nullable) receives s (norm_pos = "pre"),
+ *      out_normed (fp32, nullable) the normed tensor before smoothing (norm_pos = "post").  out_scale is fp32 [rows]. */
+int mojo_hip_dynamic_quant(const void* input, const float* inv_smooth_scale, void* out_q, float* out_scale,
+                           int64_t rows, int64_t dim, int dtype, mojo_stream_t stream);
+int mojo_hip_residual_add_rmsnorm_quant(const void* hidden, const void* residual, const float* weight,
+                                        const float* smooth_scale, void* out_q, void* out_sum, float* out_normed,
+                                        float* out_scale, int64_t rows, int64_t dim, int dtype, int quant_dtype,
+                                        float q_min, float eps, mojo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,11 +7,12 @@ from .mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
 from .moe import MojoExperts, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
 from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm
 from .position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
+from .quantize import MojoDynamicQuant, MojoResidualAddRMSNormQuant
 
 __all__ = [
     "MojoSwiGLU", "MojoPagedDecodeGQA", "MojoPagedPrefillGQA", "MojoAllGatherGemm", "MojoGemmAll2All",
     "MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoGroupGemm", "MojoQuantGemm", "MojoStorePagedKVCache",
     "build_paged_kv_chunk_metadata", "MojoPagedDecodeMLA", "MojoPagedPrefillMLA", "MojoResidualAddRMSNorm",
     "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding", "MojoMoEGating", "MojoMoEDispatch", "MojoExperts",
-    "MojoMoECombine",
+    "MojoMoECombine", "MojoDynamicQuant", "MojoResidualAddRMSNormQuant",
 ]

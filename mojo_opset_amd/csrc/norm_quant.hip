@@ -1,0 +1,241 @@
+// Per-token activation quantisers that feed MojoQuantGemm:
+//   MojoDynamicQuant            mojo_opset/core/operators/quantize.py:153-169
+//   MojoResidualAddRMSNormQuant mojo_opset/core/operators/normalization.py:493-526
+//
+//   y     = x.float() [* inv_smooth]                                   (dynamic quant)
+//   y     = rms_norm((h + r rounded to T).float(), w, eps) [* smooth]  (norm + quant; fp32 all the way, never rounded to T)
+//   scale = max(amax_row |y|, 1e-12) / q_max        (dynamic quant only: 1.0 where that is < 1e-6)
+//   q     = clamp(round_half_even(y / scale), q_min, q_max)  -> int8, or float8_e4m3fn of that INTEGER value
+//
+// One row per 256-thread block; the row's y values stay in registers between the two reductions (sum of squares, row
+// maximum) and the quantisation, so every input byte is read once.  Products and the division are the IEEE single
+// operations (no FMA contraction, no reciprocal): with the same row statistics the quantised bytes equal the golden's.
+//
+// Algorithmic bytes per element: dynamic quant elt + 1; norm+quant (pre) 3*elt + 1 (+ weight, smooth once).
+#include <math.h>
+
+#include "common.h"
+
+namespace mojo {
+
+struct NormQuantArgs {
+  const void* hidden;        // [rows, dim] T
+  const void* residual;      // [rows, dim] T or nullptr
+  const float* weight;       // [dim] fp32 or nullptr (no normalisation: dynamic quant)
+  const float* smooth;       // [dim] fp32 or nullptr
+  void* out_q;               // [rows, dim] int8 / fp8
+  void* out_sum;             // [rows, dim] T or nullptr      (norm_pos = pre: hidden + residual)
+  float* out_normed;         // [rows, dim] fp32 or nullptr   (norm_pos = post: the normed tensor before smoothing)
+  float* out_scale;          // [rows]
+  int64_t rows;
+  int dim;
+  float eps, q_max, q_min;
+  int fp8;                   // 0: int8, 1: float8_e4m3fn
+  int tiny_scale_is_one;     // MojoDynamicQuant's `where(scale < 1e-6, 1.0, scale)`
+};
+
+__device__ __forceinline__ float block_max256(float x, float* smem) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem[wave] = x;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(smem[0], smem[1]), fmaxf(smem[2], smem[3]));
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ unsigned char to_fp8_e4m3(float v) {
+  // v_cvt_pk_fp8_f32: OCP e4m3 (the "fn" format) on gfx950, round to nearest even
+  const int packed = __builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false);
+  return static_cast<unsigned char>(packed & 0xff);
+}
+
+template <typename T, int VEC, int CACHE>
+__global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
+  typedef typename vec_of<T, VEC>::type V;
+  __shared__ float red[4];
+  const int n_vec = a.dim / VEC;
+  const T* hidden = static_cast<const T*>(a.hidden);
+  const T* residual = static_cast<const T*>(a.residual);
+  T* out_sum = static_cast<T*>(a.out_sum);
+  unsigned char* out_q = static_cast<unsigned char*>(a.out_q);
+
+  for (int64_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
+    const int64_t base = row * a.dim;
+    // y of element (v, j); `from_cache` rows only ever take the first branch
+    float y[CACHE][VEC];
+    float ss = 0.f;
+    auto load_sum = [&](int v, float (&f)[VEC]) {
+      V x = load_vec<T, VEC>(hidden + base + v * VEC);
+      if (residual) {
+        const V r = load_vec<T, VEC>(residual + base + v * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(r, j))));
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) f[j] = elt<T>::to_f(vget<T, VEC>(x, j));
+      return x;
+    };
+    // ---- pass 1: sums, sum of squares ---------------------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < CACHE; ++c) {
+      const int v = threadIdx.x + c * 256;
+      if (v < n_vec) {
+        const V x = load_sum(v, y[c]);
+        if (out_sum) store_vec<T, VEC>(out_sum + base + v * VEC, x);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ss = fmaf(y[c][j], y[c][j], ss);
+      }
+    }
+    for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
+      float f[VEC];
+      const V x = load_sum(v, f);
+      if (out_sum) store_vec<T, VEC>(out_sum + base + v * VEC, x);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) ss = fmaf(f[j], f[j], ss);
+    }
+    float rstd = 1.f;
+    if (a.weight) {
+      ss = block_sum<4>(ss, red);
+      __syncthreads();
+      rstd = rsqrtf(ss / static_cast<float>(a.dim) + a.eps);
+    }
+    // y = ((f * rstd) * w) [* smooth]: single IEEE multiplies, the golden's order
+    auto finish = [&](int v, float (&f)[VEC]) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = f[j];
+        if (a.weight) {
+          t = __fmul_rn(__fmul_rn(t, rstd), a.weight[v * VEC + j]);
+          if (a.out_normed) a.out_normed[base + v * VEC + j] = t;
+        }
+        if (a.smooth) t = __fmul_rn(t, a.smooth[v * VEC + j]);
+        f[j] = t;
+      }
+    };
+    // ---- pass 2: y, row maximum ----------------------------------------------------------------------------------
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < CACHE; ++c) {
+      const int v = threadIdx.x + c * 256;
+      if (v < n_vec) {
+        finish(v, y[c]);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(y[c][j]));
+      }
+    }
+    for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
+      float f[VEC];
+      load_sum(v, f);
+      finish(v, f);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
+    }
+    amax = block_max256(amax, red);
+    float scale = __fdiv_rn(fmaxf(amax, 1e-12f), a.q_max);
+    if (a.tiny_scale_is_one && scale < 1e-6f) scale = 1.0f;
+    if (threadIdx.x == 0) a.out_scale[row] = scale;
+    // ---- pass 3: quantise ------------------------------------------------------------------------------------------
+    auto emit = [&](int v, const float (&f)[VEC]) {
+      unsigned char q[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float r = fminf(fmaxf(rintf(__fdiv_rn(f[j], scale)), a.q_min), a.q_max);
+        q[j] = a.fp8 ? to_fp8_e4m3(r) : static_cast<unsigned char>(static_cast<signed char>(static_cast<int>(r)));
+      }
+      unsigned char* dst = out_q + base + v * VEC;
+      if constexpr (VEC == 8) {
+        u32x2 w;
+        w[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (static_cast<unsigned>(q[3]) << 24);
+        w[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (static_cast<unsigned>(q[7]) << 24);
+        *reinterpret_cast<u32x2*>(dst) = w;
+      } else if constexpr (VEC == 4) {
+        *reinterpret_cast<unsigned*>(dst) = q[0] | (q[1] << 8) | (q[2] << 16) | (static_cast<unsigned>(q[3]) << 24);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = q[j];
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < CACHE; ++c) {
+      const int v = threadIdx.x + c * 256;
+      if (v < n_vec) emit(v, y[c]);
+    }
+    for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
+      float f[VEC];
+      load_sum(v, f);
+      // (the stored normed tensor was written in pass 2; write it again is harmless but wasteful: skip it)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float t = f[j];
+        if (a.weight) t = __fmul_rn(__fmul_rn(t, rstd), a.weight[v * VEC + j]);
+        if (a.smooth) t = __fmul_rn(t, a.smooth[v * VEC + j]);
+        f[j] = t;
+      }
+      emit(v, f);
+    }
+  }
+}
+
+template <typename T>
+static int launch_norm_quant(const NormQuantArgs& a, hipStream_t s) {
+  constexpr int WIDE = 16 / sizeof(T);
+  const size_t al = WIDE * sizeof(T);
+  const bool wide = a.dim % WIDE == 0 && aligned_to(a.hidden, al) && (!a.residual || aligned_to(a.residual, al)) &&
+                    (!a.out_sum || aligned_to(a.out_sum, al)) && aligned_to(a.out_q, WIDE);
+  int64_t blocks = a.rows > 256 * 32 ? 256 * 32 : a.rows;
+  if (wide) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((norm_quant_kernel<T, 1, 8>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  MOJO_CHECK_LAUNCH("norm_quant");
+  return MOJO_OK;
+}
+
+static int dispatch_norm_quant(const NormQuantArgs& a, int dtype, hipStream_t s) {
+  switch (dtype) {
+    case MOJO_F32: return launch_norm_quant<float>(a, s);
+    case MOJO_F16: return launch_norm_quant<f16_t>(a, s);
+    case MOJO_BF16: return launch_norm_quant<bf16_t>(a, s);
+    default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "norm_quant: dtype %d not supported", dtype);
+  }
+}
+
+}  // namespace mojo
+
+using namespace mojo;
+
+extern "C" int mojo_hip_dynamic_quant(const void* input, const float* inv_smooth_scale, void* out_q, float* out_scale,
+                                      int64_t rows, int64_t dim, int dtype, mojo_stream_t stream) {
+  if (rows == 0) return MOJO_OK;
+  MOJO_REQUIRE(input && out_q && out_scale, MOJO_EINVAL, "dynamic_quant: null pointer");
+  MOJO_REQUIRE(rows > 0 && dim > 0 && dim < (1LL << 30), MOJO_EINVAL, "dynamic_quant: bad shape rows=%lld dim=%lld",
+               (long long)rows, (long long)dim);
+  NormQuantArgs a{};
+  a.hidden = input; a.smooth = inv_smooth_scale; a.out_q = out_q; a.out_scale = out_scale;
+  a.rows = rows; a.dim = static_cast<int>(dim);
+  a.eps = 0.f; a.q_max = 127.f; a.q_min = -128.f; a.fp8 = 0; a.tiny_scale_is_one = 1;
+  return dispatch_norm_quant(a, dtype, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mojo_hip_residual_add_rmsnorm_quant(const void* hidden, const void* residual, const float* weight,
+                                                   const float* smooth_scale, void* out_q, void* out_sum,
+                                                   float* out_normed, float* out_scale, int64_t rows, int64_t dim,
+                                                   int dtype, int quant_dtype, float q_min, float eps,
+                                                   mojo_stream_t stream) {
+  if (rows == 0) return MOJO_OK;
+  MOJO_REQUIRE(hidden && weight && out_q && out_scale, MOJO_EINVAL, "rmsnorm_quant: null pointer");
+  MOJO_REQUIRE(rows > 0 && dim > 0 && dim < (1LL << 30), MOJO_EINVAL, "rmsnorm_quant: bad shape rows=%lld dim=%lld",
+               (long long)rows, (long long)dim);
+  MOJO_REQUIRE(quant_dtype == MOJO_I8 || quant_dtype == MOJO_F8E4M3, MOJO_EUNSUPPORTED,
+               "rmsnorm_quant: quant dtype %d (int8 / fp8-e4m3 only)", quant_dtype);
+  NormQuantArgs a{};
+  a.hidden = hidden; a.residual = residual; a.weight = weight; a.smooth = smooth_scale;
+  a.out_q = out_q; a.out_sum = out_sum; a.out_normed = out_normed; a.out_scale = out_scale;
+  a.rows = rows; a.dim = static_cast<int>(dim);
+  a.eps = eps; a.fp8 = quant_dtype == MOJO_F8E4M3;
+  a.q_max = a.fp8 ? 448.f : 127.f;
+  a.q_min = q_min;
+  a.tiny_scale_is_one = 0;
+  return dispatch_norm_quant(a, dtype, static_cast<hipStream_t>(stream));
+}

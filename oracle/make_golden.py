@@ -374,6 +374,31 @@ def gen_moe():
     return recs
 
 
+def gen_quantizers():
+    """MojoDynamicQuant and MojoResidualAddRMSNormQuant on the reference's test shapes (test_quantize.py:41-50,
+    test_normalization.py:442-446) plus zero rows, a non-multiple-of-8 width and the fp8 branch."""
+    recs = []
+    for ci, (shape, dtype, smooth) in enumerate([((1, 128), torch.bfloat16, True), ((17, 320), torch.float16, True),
+                                                 ((3, 129), torch.bfloat16, True), ((7, 257), torch.float16, False),
+                                                 ((2, 5, 512), torch.bfloat16, True), ((48, 1536), torch.float32, False)]):
+        torch.manual_seed(1400 + ci)
+        x = torch.randn(shape, dtype=dtype)
+        x.view(-1, shape[-1])[0].zero_()                       # an all-zero token: scale falls back to 1.0
+        state = {"inv_smooth_scale": 1.0 / (torch.rand(shape[-1]) + 0.1)} if smooth else {}
+        recs.append(run_case("MojoDynamicQuant", {"kwargs": {"input_size": shape[-1] if smooth else None}}, state, (x,), {}))
+    for ci, (shape, dtype, pos, qd, smooth) in enumerate([
+            ((32, 1024), torch.bfloat16, "pre", torch.int8, False), ((32, 1024), torch.float16, "post", torch.int8, False),
+            ((2, 256), torch.bfloat16, "pre", torch.int8, True), ((5, 3, 200), torch.float16, "pre", torch.int8, False),
+            ((8, 1024), torch.bfloat16, "pre", torch.float8_e4m3fn, False), ((8, 1024), torch.float16, "post", torch.float8_e4m3fn, True)]):
+        torch.manual_seed(1420 + ci)
+        x, r = torch.randn(shape, dtype=dtype), torch.randn(shape, dtype=dtype)
+        w = torch.randn(shape[-1])
+        kwargs = {"smooth_scale": torch.rand(shape[-1]) + 0.5} if smooth else {}
+        recs.append(run_case("MojoResidualAddRMSNormQuant",
+                             {"kwargs": {"norm_size": shape[-1], "norm_pos": pos, "quant_dtype": qd}}, {"weight": w}, (x, r), kwargs))
+    return recs
+
+
 def quantize_rows(x):
     scale = x.abs().amax(dim=-1).clamp_min(1e-8) / 127.0
     return torch.clamp(torch.round(x / scale.unsqueeze(-1)), -128, 127).to(torch.int8), scale
@@ -477,6 +502,7 @@ def main():
         "group_gemm": gen_group_gemm(),
         "quant_gemm": gen_quant_gemm(),
         "moe": gen_moe(),
+        "quantizers": gen_quantizers(),
     }
     store, plans = gen_store_kv()
     groups["store_paged_kv"] = store

@@ -20,6 +20,7 @@ from mojo_opset_amd.core.operators import mla as _mla
 from mojo_opset_amd.core.operators import moe as _moe
 from mojo_opset_amd.core.operators import normalization as _norm
 from mojo_opset_amd.core.operators import position_embedding as _pe
+from mojo_opset_amd.core.operators import quantize as _quant
 
 _CPU = ["rocm", "cpu"]
 
@@ -28,7 +29,8 @@ __all__ = [
     "TorchRMSNorm", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
     "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
     "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
-    "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine",
+    "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine", "TorchDynamicQuant",
+    "TorchResidualAddRMSNormQuant",
     "gather_pages", "quant_gemm_formula",
 ]
 
@@ -552,3 +554,42 @@ class TorchMoECombine(_moe.MojoMoECombine):
         index = token_indices.to(torch.int64).unsqueeze(-1).expand(-1, output_buffer.size(1))
         acc = torch.zeros_like(output_buffer, dtype=torch.float32)
         return acc.scatter_reduce(0, index, rows, reduce="sum", include_self=True).to(expert_outputs.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# activation quantisers
+# ----------------------------------------------------------------------------------------------
+class TorchDynamicQuant(_quant.MojoDynamicQuant):
+    """`core/operators/quantize.py:153-169`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input):
+        if input.dim() < 1:
+            raise ValueError("input must have at least one dimension.")
+        x = input.float()
+        if self.inv_smooth_scale is not None:
+            x = x * self.inv_smooth_scale
+        scale = x.abs().amax(dim=-1, keepdim=True).clamp(min=1e-12) / self.q_max
+        scale = torch.where(scale < 1e-6, 1.0, scale)
+        return torch.clamp(torch.round(x / scale), self.q_min, self.q_max).to(self.quant_dtype), scale
+
+
+class TorchResidualAddRMSNormQuant(_quant.MojoResidualAddRMSNormQuant):
+    """`core/operators/normalization.py:493-526` (+ `_apply_optional_smooth_scale` :9-16)."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_state, residual, smooth_scale=None):
+        summed = hidden_state + residual
+        normed = F.rms_norm(summed.float(), (summed.shape[-1],), weight=self.weight, eps=self.variance_epsilon)
+        residual_out = summed if self.norm_pos == "pre" else normed
+        x = normed
+        if smooth_scale is not None:
+            s = smooth_scale.float()
+            while s.dim() < x.dim():
+                s = s.unsqueeze(0)
+            x = x * s
+        scale = x.abs().amax(dim=-1, keepdim=True).clamp(min=1e-12) / self.q_max
+        out = torch.clamp(torch.round(x / scale), self.q_min, self.q_max)
+        return out.to(self.quant_dtype), residual_out, scale
