@@ -258,6 +258,20 @@ int mojo_hip_residual_add_rmsnorm_quant(const void* hidden, const void* residual
                                         float* out_scale, int64_t rows, int64_t dim, int dtype, int quant_dtype,
                                         float q_min, float eps, mojo_stream_t stream);
 
+/* ---- MojoStorePagedMLAKVCache (experimental/operators/kv_cache.py:13-106): bit-exact copy of the new latent
+ *      tokens compressed_kv_states [T, r] and k_pe_states [T, rope] into compressed_kv_cache [N,1,page,r] and
+ *      k_pe_cache [N,1,page,rope] at positions context_kv_lens[b].. (cu_q_lens == NULL: one token per sequence).
+ *      Per sequence the reference stops at the first negative page id and skips sequences whose first table entry or
+ *      context length is negative; evaluated per token on the device, no host sync.  Strides in elements.        */
+int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_pe_states,
+                                void* compressed_kv_cache, void* k_pe_cache, const int32_t* block_table,
+                                int64_t block_table_stride, int64_t max_blocks_per_seq,
+                                const int32_t* cu_q_lens, const int32_t* context_kv_lens, int64_t batch,
+                                int64_t num_tokens, int64_t kv_lora_rank, int64_t rope_dim, int64_t num_blocks,
+                                int64_t block_size, int64_t elt_bytes, int64_t ckv_src_token_stride,
+                                int64_t kpe_src_token_stride, int64_t ckv_block_stride, int64_t ckv_token_stride,
+                                int64_t kpe_block_stride, int64_t kpe_token_stride, mojo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

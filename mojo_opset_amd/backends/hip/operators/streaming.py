@@ -6,7 +6,8 @@ from typing import Optional
 import torch
 
 from ....core.operators.activation import MojoSwiGLU
-from ....core.operators.kv_cache import MojoStorePagedKVCache, assert_paged_kv_layout_contract
+from ....core.operators.kv_cache import (MojoStorePagedKVCache, MojoStorePagedMLAKVCache,
+                                           assert_paged_kv_layout_contract)
 from ....core.operators.normalization import MojoResidualAddRMSNorm, MojoRMSNorm
 from ....core.operators.position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
 from .. import lib as L
@@ -185,3 +186,40 @@ class HIPStorePagedKVCache(MojoStorePagedKVCache):
                 table.stride(0), table.shape[1], L.ptr(None if cu_q_lens is None else _dense(cu_q_lens)),
                 L.ptr(_dense(context_kv_lens)), batch, *common), "HIPStorePagedKVCache")
         return key_cache, value_cache
+
+
+class HIPStorePagedMLAKVCache(MojoStorePagedMLAKVCache):
+    supported_platforms_list = _ROCM
+
+    def forward(self, compressed_kv_states, k_pe_states, compressed_kv_cache, k_pe_cache, block_table, cu_q_lens,
+                context_kv_lens):
+        assert_paged_kv_layout_contract(block_table, cu_q_lens, context_kv_lens)
+        L.require_cuda(compressed_kv_states, k_pe_states, compressed_kv_cache, k_pe_cache, block_table, cu_q_lens,
+                       context_kv_lens)
+        if context_kv_lens is None:
+            return compressed_kv_cache, k_pe_cache
+        assert compressed_kv_cache.dim() == 4 and k_pe_cache.dim() == 4 and compressed_kv_cache.shape[1] == 1
+        assert compressed_kv_cache.shape[:3] == k_pe_cache.shape[:3]
+        n_blocks, _, page, r = compressed_kv_cache.shape
+        rope = k_pe_cache.shape[3]
+        assert compressed_kv_states.dim() == 2 and compressed_kv_states.shape[1] == r
+        assert k_pe_states.dim() == 2 and k_pe_states.shape[1] == rope
+        assert compressed_kv_states.shape[0] == k_pe_states.shape[0]
+        dt = compressed_kv_cache.dtype
+        if not (dt == k_pe_cache.dtype == compressed_kv_states.dtype == k_pe_states.dtype):
+            raise NotImplementedError("HIPStorePagedMLAKVCache: states and caches must share one dtype")
+        if compressed_kv_cache.stride(3) != 1 or k_pe_cache.stride(3) != 1:
+            raise NotImplementedError("HIPStorePagedMLAKVCache: caches must be dense in their last dimension")
+        ckv = compressed_kv_states if compressed_kv_states.stride(1) == 1 else compressed_kv_states.contiguous()
+        kpe = k_pe_states if k_pe_states.stride(1) == 1 else k_pe_states.contiguous()
+        batch = context_kv_lens.shape[0]
+        if cu_q_lens is not None:
+            assert cu_q_lens.shape[0] == batch + 1
+        table = block_table if block_table.stride(1) == 1 else block_table.contiguous()
+        L.check(L.load().mojo_hip_store_paged_mla_kv(
+            L.ptr(ckv), L.ptr(kpe), L.ptr(compressed_kv_cache), L.ptr(k_pe_cache), L.ptr(table), table.stride(0),
+            table.shape[1], L.ptr(None if cu_q_lens is None else _dense(cu_q_lens)), L.ptr(_dense(context_kv_lens)), batch,
+            ckv.shape[0], r, rope, n_blocks, page, dt.itemsize, ckv.stride(0), kpe.stride(0),
+            compressed_kv_cache.stride(0), compressed_kv_cache.stride(2), k_pe_cache.stride(0), k_pe_cache.stride(2),
+            L.stream_of(compressed_kv_cache)), "HIPStorePagedMLAKVCache")
+        return compressed_kv_cache, k_pe_cache

@@ -2,7 +2,7 @@ from .activation import MojoSwiGLU
 from .attention import MojoPagedDecodeGQA, MojoPagedPrefillGQA
 from .compute_with_comm import MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllReduce, MojoGemmReduceScatter
 from .gemm import MojoGroupGemm, MojoQuantGemm
-from .kv_cache import MojoStorePagedKVCache, build_paged_kv_chunk_metadata
+from .kv_cache import MojoStorePagedKVCache, MojoStorePagedMLAKVCache, build_paged_kv_chunk_metadata
 from .mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
 from .moe import MojoExperts, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
 from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm
@@ -14,5 +14,5 @@ __all__ = [
     "MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoGroupGemm", "MojoQuantGemm", "MojoStorePagedKVCache",
     "build_paged_kv_chunk_metadata", "MojoPagedDecodeMLA", "MojoPagedPrefillMLA", "MojoResidualAddRMSNorm",
     "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding", "MojoMoEGating", "MojoMoEDispatch", "MojoExperts",
-    "MojoMoECombine", "MojoDynamicQuant", "MojoResidualAddRMSNormQuant",
+    "MojoMoECombine", "MojoDynamicQuant", "MojoResidualAddRMSNormQuant", "MojoStorePagedMLAKVCache",
 ]

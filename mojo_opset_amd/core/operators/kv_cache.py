@@ -94,3 +94,17 @@ class MojoStorePagedKVCache(MojoOperator):
                 "chunk_metadata path should not be mixed with block_table/cu_q_lens/context_kv_lens."
             )
             assert_paged_kv_store_contract(chunk_metadata)
+
+
+class MojoStorePagedMLAKVCache(MojoOperator):
+    """forward(compressed_kv_states [T, r], k_pe_states [T, rope], compressed_kv_cache [N,1,page,r],
+    k_pe_cache [N,1,page,rope], block_table [B, max_blocks], cu_q_lens [B+1] | None, context_kv_lens [B])
+    -> (compressed_kv_cache, k_pe_cache), written **in place** (SURVEY §8 f3).
+
+    Follows `mojo_opset/experimental/operators/kv_cache.py:13-106`: per sequence the new tokens land at positions
+    ``context_kv_lens[b] ..``; ``cu_q_lens is None`` is decode mode (one token per sequence); a negative context length
+    or a negative first table entry skips the sequence, and the first negative page id met ends its store.
+    """
+
+    def __init__(self):
+        super().__init__()

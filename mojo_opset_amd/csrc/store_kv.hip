@@ -15,6 +15,8 @@ struct StoreArgs {
   int64_t tokens, heads, row_bytes, num_blocks, page;
   int64_t src_tok, src_head;          // bytes
   int64_t c_blk, c_head, c_tok;       // bytes
+  int tensors = 2;                    // 1: only ks -> kc (the MLA latent caches are stored one tensor per launch)
+  int stop_at_hole = 0;               // MLA store: a negative page id ends the sequence's store (and page 0 < 0 skips it)
 };
 
 template <int VB /* bytes per lane access: 16, 8, 4, 2 */>
@@ -61,19 +63,22 @@ __global__ __launch_bounds__(256) void store_layout_kernel(StoreArgs a, const in
                                                            const int32_t* __restrict__ cu_q,
                                                            const int32_t* __restrict__ ctx_lens, int64_t batch) {
   const int pieces = static_cast<int>(a.row_bytes / VB);
-  const int64_t per_token = 2LL * a.heads * pieces;
+  const int64_t per_tensor = a.heads * pieces;
+  const int64_t per_token = a.tensors * per_tensor;
   const int tok_per_block = blockDim.x / 64;                 // one wave per token
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * tok_per_block + wave; t < a.tokens;
        t += static_cast<int64_t>(gridDim.x) * tok_per_block) {
     // which sequence owns token t, and at which absolute position does it land?
     int64_t seq, pos;
+    int64_t first_pos;                                       // where this sequence's new tokens start
     if (cu_q == nullptr) {
       if (t >= batch) continue;
       seq = t;
       const int32_t c = ctx_lens[seq];
       if (c < 0) continue;
       pos = c;
+      first_pos = c;
     } else {
       if (t >= cu_q[batch] || t < cu_q[0]) continue;
       int64_t lo = 0, hi = batch;                            // largest seq with cu_q[seq] <= t
@@ -87,15 +92,29 @@ __global__ __launch_bounds__(256) void store_layout_kernel(StoreArgs a, const in
       const int32_t c = ctx_lens[seq];
       if (c < 0) continue;
       pos = c + (t - cu_q[seq]);
+      first_pos = c;
     }
     const int64_t lp = pos / a.page;
     if (lp >= max_pages) continue;
+    if (a.stop_at_hole) {
+      // experimental/operators/kv_cache.py:80-98: the per-sequence loop skips a sequence whose first table entry is
+      // negative and stops at the first negative page it meets: every page from the first written one up to this
+      // token's must be valid (64 entries per step, one ballot)
+      if (table[seq * table_stride] < 0) continue;
+      bool hole = false;
+      for (int64_t p0 = first_pos / a.page; p0 <= lp && !hole; p0 += 64) {
+        const int64_t idx = p0 + lane;
+        const int32_t v = idx <= lp ? table[seq * table_stride + idx] : 0;
+        hole = __ballot(v < 0) != 0;
+      }
+      if (hole) continue;
+    }
     const int32_t blk = table[seq * table_stride + lp];
     if (blk < 0 || blk >= a.num_blocks) continue;
     const int64_t slot = pos - lp * a.page;
     for (int64_t w = lane; w < per_token; w += 64) {
-      const int which = w >= per_token / 2;
-      int64_t r = which ? w - per_token / 2 : w;
+      const int which = w >= per_tensor;
+      int64_t r = which ? w - per_tensor : w;
       const int p = static_cast<int>(r % pieces);
       const int h = static_cast<int>(r / pieces);
       const char* src = (which ? a.vs : a.ks) + t * a.src_tok + h * a.src_head + p * VB;
@@ -108,8 +127,8 @@ __global__ __launch_bounds__(256) void store_layout_kernel(StoreArgs a, const in
 static int pick_vb(const StoreArgs& a) {
   auto ok = [&](int vb) {
     return a.row_bytes % vb == 0 && a.src_tok % vb == 0 && a.src_head % vb == 0 && a.c_blk % vb == 0 &&
-           a.c_head % vb == 0 && a.c_tok % vb == 0 && aligned_to(a.ks, vb) && aligned_to(a.vs, vb) &&
-           aligned_to(a.kc, vb) && aligned_to(a.vc, vb);
+           a.c_head % vb == 0 && a.c_tok % vb == 0 && aligned_to(a.ks, vb) && aligned_to(a.kc, vb) &&
+           (a.tensors == 1 || (aligned_to(a.vs, vb) && aligned_to(a.vc, vb)));
   };
   for (int vb : {16, 8, 4, 2})
     if (ok(vb)) return vb;
@@ -204,4 +223,59 @@ extern "C" int mojo_hip_store_paged_kv_layout(const void* key_states, const void
 #undef LAUNCH
   MOJO_CHECK_LAUNCH("store_paged_kv_layout");
   return MOJO_OK;
+}
+
+// ---- MojoStorePagedMLAKVCache (experimental/operators/kv_cache.py:13-106): the compressed-KV latent and the positional
+//      key have different widths, so they go out as two single-tensor launches of the layout kernel, with the MLA
+//      store's own hole semantics (a negative page id ends that sequence's store).
+static int store_one_mla(const void* states, void* cache, const int32_t* block_table, int64_t block_table_stride,
+                         int64_t max_blocks_per_seq, const int32_t* cu_q_lens, const int32_t* context_kv_lens,
+                         int64_t batch, int64_t num_tokens, int64_t width, int64_t num_blocks, int64_t block_size,
+                         int64_t elt_bytes, int64_t src_token_stride, int64_t cache_block_stride,
+                         int64_t cache_token_stride, hipStream_t s) {
+  StoreArgs a;
+  int rc = fill_args(a, states, nullptr, cache, nullptr, num_tokens, 1, width, num_blocks, block_size, elt_bytes,
+                     src_token_stride, 0, cache_block_stride, 0, cache_token_stride);
+  if (rc) return rc;
+  a.tensors = 1;
+  a.stop_at_hole = 1;
+  const int vb = pick_vb(a);
+  MOJO_REQUIRE(vb != 0, MOJO_EUNSUPPORTED, "store_paged_mla_kv: rows are not even 2-byte aligned");
+  int64_t gx = ceil_div(num_tokens, 4);
+  if (gx > 8192) gx = 8192;
+  dim3 grid(static_cast<unsigned>(gx));
+#define LAUNCH(VBV)                                                                                        \
+  hipLaunchKernelGGL(store_layout_kernel<VBV>, grid, dim3(256), 0, s, a, block_table, block_table_stride, \
+                     max_blocks_per_seq, cu_q_lens, context_kv_lens, batch)
+  switch (vb) {
+    case 16: LAUNCH(16); break;
+    case 8: LAUNCH(8); break;
+    case 4: LAUNCH(4); break;
+    default: LAUNCH(2); break;
+  }
+#undef LAUNCH
+  MOJO_CHECK_LAUNCH("store_paged_mla_kv");
+  return MOJO_OK;
+}
+
+extern "C" int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_pe_states,
+                                           void* compressed_kv_cache, void* k_pe_cache, const int32_t* block_table,
+                                           int64_t block_table_stride, int64_t max_blocks_per_seq,
+                                           const int32_t* cu_q_lens, const int32_t* context_kv_lens, int64_t batch,
+                                           int64_t num_tokens, int64_t kv_lora_rank, int64_t rope_dim,
+                                           int64_t num_blocks, int64_t block_size, int64_t elt_bytes,
+                                           int64_t ckv_src_token_stride, int64_t kpe_src_token_stride,
+                                           int64_t ckv_block_stride, int64_t ckv_token_stride,
+                                           int64_t kpe_block_stride, int64_t kpe_token_stride, mojo_stream_t stream) {
+  if (num_tokens == 0 || batch == 0 || max_blocks_per_seq == 0) return MOJO_OK;
+  MOJO_REQUIRE(compressed_kv_states && k_pe_states && compressed_kv_cache && k_pe_cache && block_table && context_kv_lens,
+               MOJO_EINVAL, "store_paged_mla_kv: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = store_one_mla(compressed_kv_states, compressed_kv_cache, block_table, block_table_stride, max_blocks_per_seq,
+                         cu_q_lens, context_kv_lens, batch, num_tokens, kv_lora_rank, num_blocks, block_size, elt_bytes,
+                         ckv_src_token_stride, ckv_block_stride, ckv_token_stride, s);
+  if (rc) return rc;
+  return store_one_mla(k_pe_states, k_pe_cache, block_table, block_table_stride, max_blocks_per_seq, cu_q_lens,
+                       context_kv_lens, batch, num_tokens, rope_dim, num_blocks, block_size, elt_bytes,
+                       kpe_src_token_stride, kpe_block_stride, kpe_token_stride, s);
 }

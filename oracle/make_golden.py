@@ -399,6 +399,45 @@ def gen_quantizers():
     return recs
 
 
+def gen_store_mla():
+    """MojoStorePagedMLAKVCache: prefill and decode, ragged, padding (-1 context), a hole in the table (the store of that
+    sequence ends there), a sequence whose first page is missing, tokens running past the table."""
+    recs = []
+    specs = [
+        # (page, r, rope, q_lens | None for decode, ctx, table rows)
+        (16, 64, 32, [5, 0, 40, 17], [3, -1, 0, 30], None),
+        (8, 32, 16, None, [0, 7, 8, -1, 23], None),
+        (16, 128, 64, [33, 20, 9], [10, 0, 15], "holes"),
+        (4, 16, 8, [30], [2], "short"),
+    ]
+    for ci, (page, r, rope, q_lens, ctx, mode) in enumerate(specs):
+        torch.manual_seed(1500 + ci)
+        batch = len(ctx)
+        new = [1] * batch if q_lens is None else q_lens
+        need = [max((max(c, 0) + n + page - 1) // page, 1) for c, n in zip(ctx, new)]
+        width = max(need) + 1
+        total = sum(need) + 4
+        ids = torch.randperm(total, dtype=torch.int32)
+        table = torch.full((batch, width), -1, dtype=torch.int32)
+        at = 0
+        for b, n in enumerate(need):
+            table[b, :n] = ids[at: at + n]
+            at += n
+        if mode == "holes":
+            table[0, 1] = -1                 # sequence 0 stops after its first page
+            table[1, 0] = -1                 # sequence 1 is skipped entirely
+        if mode == "short":
+            table = table[:, :3].contiguous()   # 30 tokens from position 2 need 8 pages of 4: only 3 exist
+        tokens = sum(new)
+        ckv, kpe = torch.randn(tokens, r, dtype=torch.bfloat16), torch.randn(tokens, rope, dtype=torch.bfloat16)
+        ckv_cache = torch.randn(total, 1, page, r, dtype=torch.bfloat16)
+        kpe_cache = torch.randn(total, 1, page, rope, dtype=torch.bfloat16)
+        cu_q = None if q_lens is None else cu(q_lens)
+        recs.append(run_case("MojoStorePagedMLAKVCache", {}, {},
+                             (ckv, kpe, ckv_cache, kpe_cache, table, cu_q, torch.tensor(ctx, dtype=torch.int32)), {}))
+    return recs
+
+
 def quantize_rows(x):
     scale = x.abs().amax(dim=-1).clamp_min(1e-8) / 127.0
     return torch.clamp(torch.round(x / scale.unsqueeze(-1)), -128, 127).to(torch.int8), scale
@@ -503,6 +542,7 @@ def main():
         "quant_gemm": gen_quant_gemm(),
         "moe": gen_moe(),
         "quantizers": gen_quantizers(),
+        "store_paged_mla": gen_store_mla(),
     }
     store, plans = gen_store_kv()
     groups["store_paged_kv"] = store

@@ -30,7 +30,7 @@ __all__ = [
     "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
     "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
     "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine", "TorchDynamicQuant",
-    "TorchResidualAddRMSNormQuant",
+    "TorchResidualAddRMSNormQuant", "TorchStorePagedMLAKVCache",
     "gather_pages", "quant_gemm_formula",
 ]
 
@@ -593,3 +593,35 @@ class TorchResidualAddRMSNormQuant(_quant.MojoResidualAddRMSNormQuant):
         scale = x.abs().amax(dim=-1, keepdim=True).clamp(min=1e-12) / self.q_max
         out = torch.clamp(torch.round(x / scale), self.q_min, self.q_max)
         return out.to(self.quant_dtype), residual_out, scale
+
+
+# ----------------------------------------------------------------------------------------------
+# MLA latent-cache store
+# ----------------------------------------------------------------------------------------------
+class TorchStorePagedMLAKVCache(_kv.MojoStorePagedMLAKVCache):
+    """`experimental/operators/kv_cache.py:57-106`: per sequence, page by page, until a negative page id."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, compressed_kv_states, k_pe_states, compressed_kv_cache, k_pe_cache, block_table, cu_q_lens,
+                context_kv_lens):
+        _kv.assert_paged_kv_layout_contract(block_table, cu_q_lens, context_kv_lens)
+        page = compressed_kv_cache.shape[2]
+        batch = len(context_kv_lens) if context_kv_lens is not None else 0
+        for b in range(batch):
+            first, last = (b, b + 1) if cu_q_lens is None else (int(cu_q_lens[b]), int(cu_q_lens[b + 1]))
+            left = last - first
+            start = int(context_kv_lens[b])
+            row = block_table[b]
+            if left <= 0 or start < 0 or row.numel() == 0 or int(row[0]) < 0:
+                continue
+            logical, slot, src = start // page, start % page, first
+            while left > 0 and logical < row.shape[0]:
+                phys = int(row[logical])
+                if phys < 0:
+                    break
+                n = min(left, page - slot)
+                compressed_kv_cache[phys, 0, slot: slot + n, :] = compressed_kv_states[src: src + n]
+                k_pe_cache[phys, 0, slot: slot + n, :] = k_pe_states[src: src + n]
+                src, left, logical, slot = src + n, left - n, logical + 1, 0
+        return compressed_kv_cache, k_pe_cache
