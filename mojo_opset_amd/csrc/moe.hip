@@ -254,6 +254,11 @@ __global__ __launch_bounds__(256) void moe_gather_rows_kernel(const T* __restric
 // combine: out[t] = sum over the rows routed from token t, in ascending row order (= the golden's scatter order),
 // fp32 from zero, product and sum rounded separately (no FMA) -> bit-identical to the golden
 // ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void moe_zero_kernel(int32_t* __restrict__ p, int64_t n) {
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) p[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void moe_count_kernel(const int32_t* __restrict__ tok, int64_t n, int64_t tokens,
                                                         int32_t* __restrict__ cnt) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
@@ -481,10 +486,11 @@ extern "C" int mojo_hip_moe_combine(const void* expert_outputs, const float* sor
   int32_t* cnt = static_cast<int32_t*>(workspace);      // [tokens]   (reused as the fill cursor)
   int32_t* start = cnt + tokens;                        // [tokens + 1]
   int32_t* list = start + tokens + 1;                   // [rows]
-  if (hipMemsetAsync(cnt, 0, static_cast<size_t>(tokens) * sizeof(int32_t), s) != hipSuccess) {
-    set_error("moe_combine: memset failed");
-    return MOJO_ELAUNCH;
-  }
+  // (zeroed by a kernel, not hipMemsetAsync: a captured graph holding two memset nodes on this buffer between kernel
+  // nodes aborted at replay on ROCm 7.0)
+  const unsigned zero_blocks = static_cast<unsigned>(ceil_div(tokens, 256) > 1024 ? 1024 : ceil_div(tokens, 256));
+  hipLaunchKernelGGL(moe_zero_kernel, dim3(zero_blocks), dim3(256), 0, s, cnt, tokens);
+  MOJO_CHECK_LAUNCH("moe_combine(zero)");
   const int row_blocks = static_cast<int>(ceil_div(rows > 0 ? rows : 1, 256));
   if (rows > 0) {
     hipLaunchKernelGGL(moe_count_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, cnt);
@@ -493,10 +499,8 @@ extern "C" int mojo_hip_moe_combine(const void* expert_outputs, const float* sor
   hipLaunchKernelGGL(moe_token_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, tokens, start);
   MOJO_CHECK_LAUNCH("moe_combine(scan)");
   if (rows > 0) {
-    if (hipMemsetAsync(cnt, 0, static_cast<size_t>(tokens) * sizeof(int32_t), s) != hipSuccess) {
-      set_error("moe_combine: memset failed");
-      return MOJO_ELAUNCH;
-    }
+    hipLaunchKernelGGL(moe_zero_kernel, dim3(zero_blocks), dim3(256), 0, s, cnt, tokens);
+    MOJO_CHECK_LAUNCH("moe_combine(zero)");
     hipLaunchKernelGGL(moe_fill_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, start, cnt, list);
     MOJO_CHECK_LAUNCH("moe_combine(fill)");
   }

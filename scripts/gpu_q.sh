@@ -1,2 +1,2 @@
 cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_hip_store_mla.py tests/test_hip_streaming.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|^E " gpurun_out/t.log | head -30
+timeout 600 python -m pytest tests/test_hip_graph.py tests/test_hip_moe.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|^E " gpurun_out/t.log | head -30
