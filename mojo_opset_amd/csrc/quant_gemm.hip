@@ -8,6 +8,8 @@
 // Algorithmic FLOPs: 2*M*K*N (MFMA-bound for M >= 128); bytes: K*N (weight stream) + M*K + M*N*out.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm256_core.h"
 
 namespace mojo {
@@ -60,6 +62,183 @@ __global__ __launch_bounds__(256) void quant_finalize_kernel(const ACC* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decode-sized M (<= 64) with [N,K] weights: the op is a weight STREAM (K*N bytes from HBM against 2*M*K*N cheap
+// integer ops), so the 256x256 tile shape is the wrong tool — it pads M to 256 and needs 16-way split-K with fp32 slabs
+// larger than the weight itself.  Skinny kernel: one workgroup = 64 output columns x all M rows x one K slice.
+//   * each wave owns 16 columns; its weight fragments go global -> registers (never through LDS).  MFMA does not care
+//     which k a lane supplies as long as both operands agree, so k-step s of a 256-byte K block is "bytes 64s + 16g ..
+//     +15 for lane group g": the four lanes of a column read one contiguous 64-byte segment per instruction (a lane
+//     can only feed its own column, so 64 B is the longest run an instruction can get), and the activation fragments
+//     are read from LDS with the same permutation;
+//   * the activation block [16*MT rows][256 B] is staged through registers into a double-buffered, padded LDS image
+//     shared by the four waves (stride 272 B: conflict-free ds_read_b128);
+//   * the weights of the next three K blocks and the activation block of the next one are in flight while a block is
+//     multiplied;
+//   * grid = (N/64) x splitk with ~256 workgroups (each keeps 48 KiB of weights in flight); split-K slices write raw
+//     accumulators to their own slab, summed in slice order by quant_finalize_kernel (deterministic).
+// Algorithmic bytes: K*N (+ M*K + 4*M*N*splitk*2 of slab traffic when split).
+template <typename TO, bool FP8, int MT>
+__global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
+                                                           const float* __restrict__ rs, const bf16_t* __restrict__ cs,
+                                                           TO* __restrict__ C, void* __restrict__ slab, int M, int K, int N,
+                                                           int splitk) {
+  typedef typename std::conditional<FP8, f32x4, i32x4>::type acc_t;
+  constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
+  __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64 + wave * 16;
+  const int slice = blockIdx.y;
+  const int nkb = K / 256;
+  const int kb0 = static_cast<int>(static_cast<int64_t>(nkb) * slice / splitk);
+  const int kb1 = static_cast<int>(static_cast<int64_t>(nkb) * (slice + 1) / splitk);
+  const uint8_t* wrow = W + static_cast<int64_t>(n0 + l15) * K + g * 16;
+
+  acc_t acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = acc_t{0, 0, 0, 0};
+
+  // K blocks are visited in an order rotated by the column tile: all column tiles of a slice read the SAME activation
+  // lines, and in lock-step they would queue on one L2 channel (measured: 4 us per K block at M = 32).
+  const int nb = kb1 - kb0;
+  const int rot = nb > 0 ? static_cast<int>(blockIdx.x % nb) : 0;
+  auto block_at = [&](int i) { const int j = i + rot; return kb0 + (j >= nb ? j - nb : j); };
+  constexpr int DEPTH = 3;                                   // weight blocks in flight ahead of the multiply
+  u32x4 wreg[DEPTH + 1][4], areg[2][MT];                     // activations: two blocks ahead in registers, one in LDS
+  auto load_w = [&](int i, u32x4 (&wr)[4]) {
+    const uint8_t* wp = wrow + static_cast<int64_t>(block_at(i)) * 256;
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + sx * 64));
+  };
+  auto load_a = [&](int i, u32x4 (&ar)[MT]) {
+    const int64_t k0 = static_cast<int64_t>(block_at(i)) * 256;
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      const int idx = threadIdx.x + 256 * p;                 // 16-byte chunk of the activation block
+      const int row = min(idx >> 4, M - 1);
+      ar[p] = *reinterpret_cast<const u32x4*>(A + static_cast<int64_t>(row) * K + k0 + (idx & 15) * 16);
+    }
+  };
+  auto store_a = [&](int buf, const u32x4 (&ar)[MT]) {
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      const int idx = threadIdx.x + 256 * p;
+      *reinterpret_cast<u32x4*>(&s_a[buf][(idx >> 4) * ROW + (idx & 15) * 16]) = ar[p];
+    }
+  };
+  if (nb > 0) {
+    load_a(0, areg[0]);
+    if (nb > 1) load_a(1, areg[1]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < nb) load_w(d, wreg[d]);
+    store_a(0, areg[0]);
+  }
+  __syncthreads();
+  // The ring index is kept compile-time by unrolling the body DEPTH + 1 times.  The steady-state rounds contain NO
+  // conditional loads: with a branch around a load the compiler's wait-count analysis has to assume the load may not have
+  // been issued, ranks every register of the ring as "possibly the youngest load" and waits vmcnt(0) — which silently
+  // turns the three-deep prefetch into none.  The last rounds (loads that would run past the slice) go through a
+  // guarded copy of the same body.
+  auto body = [&](int i, auto RC, auto GUARD) {
+    constexpr int r = decltype(RC)::value;
+    constexpr bool guarded = decltype(GUARD)::value;
+    const int cur = i & 1;                                   // LDS buffer of block i; areg[cur ^ 1] holds block i + 1
+    // Issue order matters: vmcnt retires in order, so the activation load must be OLDER than the weight loads issued
+    // next to it — waiting for activations at the end of the block then leaves every younger weight block in flight.
+    if (!guarded || i + 2 < nb) { if (r & 1) load_a(i + 2, areg[1]); else load_a(i + 2, areg[0]); }   // slot of block i
+    if (!guarded || i + DEPTH < nb) load_w(i + DEPTH, wreg[(r + DEPTH) % (DEPTH + 1)]);
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(&s_a[r & 1][(mt * 16 + l15) * ROW + sx * 64 + g * 16]);
+        if constexpr (FP8) {
+          typedef long i64x2 __attribute__((ext_vector_type(2)));
+          const i64x2 wl = __builtin_bit_cast(i64x2, wreg[r][sx]), al = __builtin_bit_cast(i64x2, af);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], al[0], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], al[1], acc[mt], 0, 0, 0);
+        } else {
+          acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wreg[r][sx]), __builtin_bit_cast(i32x4, af),
+                                                          acc[mt], 0, 0, 0);
+        }
+      }
+    }
+    if (!guarded || i + 1 < nb) { if (r & 1) store_a(0, areg[0]); else store_a(1, areg[1]); }
+    __syncthreads();
+    (void)cur;
+  };
+  int i0 = 0;
+  for (; i0 + 2 * DEPTH + 1 <= nb; i0 += DEPTH + 1)          // every load of the round stays inside the slice
+    static_for<DEPTH + 1>([&](auto RC) { body(i0 + decltype(RC)::value, RC, std::false_type{}); });
+  for (; i0 < nb; i0 += DEPTH + 1)
+    static_for<DEPTH + 1>([&](auto RC) {
+      constexpr int r = decltype(RC)::value;
+      if (i0 + r < nb) body(i0 + r, RC, std::true_type{});
+    });
+  // lane holds rows m = mt*16 + l15, columns n0 + 4g .. +3
+  const int n = n0 + 4 * g;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + l15;
+    if (m >= M) continue;
+    if (splitk > 1) {
+      acc_t* dst = reinterpret_cast<acc_t*>(static_cast<char*>(slab) + ((static_cast<int64_t>(slice) * M + m) * N + n) * 4);
+      *dst = acc[mt];
+    } else {
+      const float r = rs[m];
+      typedef typename vec_of<TO, 4>::type V4;
+      V4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[mt][q]), r), static_cast<float>(cs[n + q]));
+        asm volatile("" : "+v"(v));
+        o[q] = elt<TO>::from_f(v);
+      }
+      *reinterpret_cast<V4*>(C + static_cast<int64_t>(m) * N + n) = o;
+    }
+  }
+}
+
+static bool quant_skinny_ok(int64_t m, const GemmArgs& a) {
+  return m <= 64 && a.w_k == 1 && a.w_n == a.K && a.K % 256 == 0 && a.N % 64 == 0 && a.lda == a.K && a.ldc == a.N &&
+         aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
+}
+
+static int quant_skinny_splitk(int k, int n) {
+  if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return v; }
+  const int nkb = k / 256, tiles = n / 64;
+  int sk = (256 + tiles - 1) / tiles;                    // one workgroup per CU, three weight blocks in flight each
+  if (sk > nkb / 4) sk = nkb / 4;                        // at least four K blocks per slice
+  if (sk > 64) sk = 64;
+  return sk < 1 ? 1 : sk;
+}
+
+template <typename TO, bool FP8>
+static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t* cs, int64_t m, void* slab_ws, hipStream_t s) {
+  const int sk = quant_skinny_splitk(a.K, a.N);
+  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(sk));
+  const uint8_t* A = static_cast<const uint8_t*>(a.A);
+  const uint8_t* W = static_cast<const uint8_t*>(a.W);
+  TO* C = static_cast<TO*>(a.C);
+  const int M = static_cast<int>(m);
+#define SKINNY(MT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk)
+  if (m <= 16) SKINNY(1); else if (m <= 32) SKINNY(2); else SKINNY(4);
+#undef SKINNY
+  MOJO_CHECK_LAUNCH("quant_gemm(skinny)");
+  if (sk > 1) {
+    int64_t blocks = ceil_div(m * a.N, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (FP8)
+      hipLaunchKernelGGL((quant_finalize_kernel<TO, float>), dim3(blocks), dim3(256), 0, s, static_cast<const float*>(slab_ws), sk, m, a.N, rs, cs, C);
+    else
+      hipLaunchKernelGGL((quant_finalize_kernel<TO, int>), dim3(blocks), dim3(256), 0, s, static_cast<const int*>(slab_ws), sk, m, a.N, rs, cs, C);
+    MOJO_CHECK_LAUNCH("quant_gemm(finalize)");
+  }
+  return MOJO_OK;
+}
+
 // Few output tiles (decode-sized M): cut K so that ~256 workgroups stream the weight concurrently.
 static int quant_splitk(int64_t m, int k, int n) {
   if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return v; }
@@ -76,6 +255,8 @@ template <typename TO>
 static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, int quant_dtype, void* slab_ws,
                      hipStream_t s) {
   const bool fp8 = quant_dtype == MOJO_F8E4M3;
+  if (quant_skinny_ok(m, a))
+    return fp8 ? launch_quant_skinny<TO, true>(a, rs, cs, m, slab_ws, s) : launch_quant_skinny<TO, false>(a, rs, cs, m, slab_ws, s);
   if (g256::gemm256_layout_ok(a, 1)) {
     const int sk = quant_splitk(m, a.K, a.N);
     if (sk > 1) {
@@ -124,7 +305,12 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
 using namespace mojo;
 
 extern "C" int64_t mojo_hip_quant_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
-  const int sk = (k > 0 && k % 128 == 0) ? quant_splitk(m, static_cast<int>(k), static_cast<int>(n)) : 1;
+  // the largest split any path may choose for this shape (the skinny path needs [N,K] weights, which is not known here)
+  int sk = (k > 0 && k % 128 == 0) ? quant_splitk(m, static_cast<int>(k), static_cast<int>(n)) : 1;
+  if (m <= 64 && k > 0 && k % 256 == 0 && n % 64 == 0) {
+    const int s2 = quant_skinny_splitk(static_cast<int>(k), static_cast<int>(n));
+    if (s2 > sk) sk = s2;
+  }
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
 }
 

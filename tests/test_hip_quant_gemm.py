@@ -24,7 +24,11 @@ def test_quant_gemm_vectors_bit_exact(case):
 
 
 @pytest.mark.parametrize("m,k,n", [(1, 4096, 4096), (32, 4096, 11008), (128, 2048, 4096), (64, 4096, 4096),
-                                   (300, 1024, 1000), (257, 128, 264), (5, 96, 40)])
+                                   (300, 1024, 1000), (257, 128, 264), (5, 96, 40),
+                                   # decode-sized M on the weight-streaming kernel ([N,K] weights): every row-tile count,
+                                   # ragged M, one K block per slice, no split, DeepSeek-V3 shapes
+                                   (16, 512, 64), (17, 7168, 4096), (33, 1536, 7168), (48, 256, 128), (64, 18432, 7168),
+                                   (3, 2048, 64)])
 @pytest.mark.parametrize("trans_weight", [False, True])
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16, torch.float32])
 def test_quant_gemm_int8_equals_integer_formula(m, k, n, trans_weight, odt):
@@ -64,7 +68,8 @@ def test_quant_gemm_error_conventions():
         op(torch.zeros(2, 48, dtype=torch.int8, device=DEV), torch.ones(2, device=DEV))
 
 
-@pytest.mark.parametrize("m,k,n", [(128, 7168, 1536), (32, 2048, 7168), (1, 512, 256), (300, 1024, 1000), (7, 96, 40)])
+@pytest.mark.parametrize("m,k,n", [(128, 7168, 1536), (32, 2048, 7168), (1, 512, 256), (300, 1024, 1000), (7, 96, 40),
+                                   (17, 7168, 4096), (64, 1536, 7168)])
 @pytest.mark.parametrize("trans_weight", [False, True])
 def test_quant_gemm_fp8_matches_oracle(m, k, n, trans_weight):
     """Extension dtype — parity unpinned: there is no reference implementation (gemm.py:171-173 asserts int8)."""
