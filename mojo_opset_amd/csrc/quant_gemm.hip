@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void quant_finalize_kernel(const ACC* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Decode-sized M (<= 64) with [N,K] weights: the op is a weight STREAM (K*N bytes from HBM against 2*M*K*N cheap
+// Decode-sized M (<= 128) with [N,K] weights: the op is a weight STREAM (K*N bytes from HBM against 2*M*K*N cheap
 // integer ops), so the 256x256 tile shape is the wrong tool — it pads M to 256 and needs 16-way split-K with fp32 slabs
 // larger than the weight itself.  Skinny kernel: one workgroup = 64 output columns x all M rows x one K slice.
 //   * each wave owns 16 columns; its weight fragments go global -> registers (never through LDS).  MFMA does not care
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
 }
 
 static bool quant_skinny_ok(int64_t m, const GemmArgs& a) {
-  return m <= 64 && a.w_k == 1 && a.w_n == a.K && a.K % 256 == 0 && a.N % 64 == 0 && a.lda == a.K && a.ldc == a.N &&
+  return m <= 128 && a.w_k == 1 && a.w_n == a.K && a.K % 256 == 0 && a.N % 64 == 0 && a.lda == a.K && a.ldc == a.N &&
          aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
 }
 
@@ -224,7 +224,7 @@ static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t*
   TO* C = static_cast<TO*>(a.C);
   const int M = static_cast<int>(m);
 #define SKINNY(MT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk)
-  if (m <= 16) SKINNY(1); else if (m <= 32) SKINNY(2); else SKINNY(4);
+  if (m <= 16) SKINNY(1); else if (m <= 32) SKINNY(2); else if (m <= 64) SKINNY(4); else SKINNY(8);
 #undef SKINNY
   MOJO_CHECK_LAUNCH("quant_gemm(skinny)");
   if (sk > 1) {
@@ -307,7 +307,7 @@ using namespace mojo;
 extern "C" int64_t mojo_hip_quant_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   // the largest split any path may choose for this shape (the skinny path needs [N,K] weights, which is not known here)
   int sk = (k > 0 && k % 128 == 0) ? quant_splitk(m, static_cast<int>(k), static_cast<int>(n)) : 1;
-  if (m <= 64 && k > 0 && k % 256 == 0 && n % 64 == 0) {
+  if (m <= 128 && k > 0 && k % 256 == 0 && n % 64 == 0) {
     const int s2 = quant_skinny_splitk(static_cast<int>(k), static_cast<int>(n));
     if (s2 > sk) sk = s2;
   }

@@ -28,7 +28,7 @@ def test_quant_gemm_vectors_bit_exact(case):
                                    # decode-sized M on the weight-streaming kernel ([N,K] weights): every row-tile count,
                                    # ragged M, one K block per slice, no split, DeepSeek-V3 shapes
                                    (16, 512, 64), (17, 7168, 4096), (33, 1536, 7168), (48, 256, 128), (64, 18432, 7168),
-                                   (3, 2048, 64)])
+                                   (3, 2048, 64), (65, 1024, 128), (128, 7168, 4096), (100, 512, 64)])
 @pytest.mark.parametrize("trans_weight", [False, True])
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16, torch.float32])
 def test_quant_gemm_int8_equals_integer_formula(m, k, n, trans_weight, odt):
