@@ -284,6 +284,13 @@ def bench_moe(device):
     with torch.no_grad():
         gating.gate_weight.copy_(torch.randn(h_, e_) * 0.02)
     out["gating_T8192_E8_k2_H4096"] = _hbm(_time(lambda: gating(x), 20, 3), t_ * h_ * 2 + h_ * e_ * 4 + t_ * k_ * 8)
+    # DeepSeek-V3-sized router: 256 experts, top-8, hidden 7168 (logits on MFMA, hi/lo split of the fp32 gate weight)
+    xd = torch.rand(t_, 7168, device=device, dtype=torch.bfloat16)
+    gd = hip("MojoMoEGating")(hidden_size=7168, num_experts=256, top_k=8).to(device)
+    with torch.no_grad():
+        gd.gate_weight.copy_(torch.randn(7168, 256) * 0.02)
+    out["gating_T8192_E256_k8_H7168"] = _mfma(_time(lambda: gd(xd), 20, 3), 2.0 * t_ * 7168 * 256 * 2)
+    del xd, gd
     idx, gates = gating(x)
     dispatch = hip("MojoMoEDispatch")(num_experts=e_)
     out["dispatch_T8192_E8_k2_H4096"] = _hbm(_time(lambda: dispatch(x, gates, idx), 20, 3), t_ * h_ * 2 + t_ * k_ * (h_ * 2 + 16))

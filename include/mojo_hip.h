@@ -221,7 +221,9 @@ int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const v
 
 /* ---- MoE routing either side of the grouped GEMM (core/operators/moe.py).
  *      gating (:299-316): softmax(hidden.float() @ gate_weight [hidden, E] fp32) over all experts, top-k in descending
- *      order (ties: lowest expert id), gates renormalised to sum 1.  top_k <= min(E, 64), E <= 1024.
+ *      order (ties: lowest expert id), gates renormalised to sum 1.  top_k <= min(E, 64), E <= 1024.  With many
+ *      experts and tokens (16-bit activations) the logits run on MFMA as x @ w_hi + x @ w_lo, w = w_hi + w_lo split
+ *      into the activation dtype (error ~2^-16 relative); that route takes its scratch from the workspace.
  *      dispatch (:344-400): stable counting sort of the tokens*top_k routing slots by expert id (the reference leaves
  *      the order inside a bucket undefined; this one keeps flat-slot order, so the op is deterministic).  Outputs:
  *      sorted_hidden [slots, H], tokens_per_expert int32 [E], sorted_gates fp32 [slots] (viewed [slots,1]),
@@ -229,9 +231,10 @@ int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const v
  *      combine (:687-716): out[t] = sum of expert_outputs[j] (* sorted_gates[j]; NULL = no gates) over the rows j with
  *      token_indices[j] == t, fp32 from zero in ascending j, product and sum rounded separately — bit-identical to the
  *      reference's fp32 scatter-add.  Tokens nobody routes to are zero.                                         */
+int64_t mojo_hip_moe_gating_workspace_bytes(int64_t tokens, int64_t hidden_size, int64_t num_experts, int dtype);
 int mojo_hip_moe_gating(const void* hidden, const float* gate_weight, int32_t* top_k_indices, float* top_k_gates,
                         int64_t tokens, int64_t hidden_size, int64_t num_experts, int64_t top_k, int dtype,
-                        mojo_stream_t stream);
+                        void* workspace, int64_t workspace_bytes, mojo_stream_t stream);
 int64_t mojo_hip_moe_dispatch_workspace_bytes(int64_t slots, int64_t num_experts);
 int mojo_hip_moe_dispatch(const void* hidden, const float* top_k_gates, const int32_t* top_k_indices,
                           void* sorted_hidden, int32_t* tokens_per_expert, float* sorted_gates,

@@ -39,7 +39,8 @@ SIGNATURES = {
     "mojo_hip_store_paged_mla_kv": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P] + [_I] * 13 + [_P]),
     "mojo_hip_dynamic_quant": (c_int, [_P, _P, _P, _P, _I, _I, c_int, _P]),
     "mojo_hip_residual_add_rmsnorm_quant": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, c_int, c_int, c_float, c_float, _P]),
-    "mojo_hip_moe_gating": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, c_int, _P]),
+    "mojo_hip_moe_gating_workspace_bytes": (c_int64, [_I, _I, _I, c_int]),
+    "mojo_hip_moe_gating": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_moe_dispatch_workspace_bytes": (c_int64, [_I, _I]),
     "mojo_hip_moe_dispatch": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_moe_combine_workspace_bytes": (c_int64, [_I, _I]),

@@ -24,8 +24,11 @@ class HIPMoEGating(MojoMoEGating):
         experts = w.shape[1]
         idx = torch.empty(tokens, self.top_k, dtype=torch.int32, device=x.device)
         gates = torch.empty(tokens, self.top_k, dtype=torch.float32, device=x.device)
-        L.check(L.load().mojo_hip_moe_gating(L.ptr(x), L.ptr(w), L.ptr(idx), L.ptr(gates), tokens, hidden, experts,
-                                             self.top_k, L.dtype_code(x.dtype), L.stream_of(x)), "HIPMoEGating")
+        lib = L.load()
+        code = L.dtype_code(x.dtype)
+        ws = torch.empty(lib.mojo_hip_moe_gating_workspace_bytes(tokens, hidden, experts, code), dtype=torch.uint8, device=x.device)
+        L.check(lib.mojo_hip_moe_gating(L.ptr(x), L.ptr(w), L.ptr(idx), L.ptr(gates), tokens, hidden, experts, self.top_k, code,
+                                        L.ptr(ws), ws.numel(), L.stream_of(x)), "HIPMoEGating")
         return idx, gates
 
 

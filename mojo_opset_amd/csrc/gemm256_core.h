@@ -89,6 +89,21 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias, added after the roundi
   }
 };
 
+struct EpilogueF32 {         // C (fp32) = acc, or C += acc: two-pass products (x @ w_hi, then + x @ w_lo) of the MoE router
+  float* C; int64_t ldc; int accumulate;
+  __device__ __forceinline__ void row_begin(int) {}
+  __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
+    float* dst = C + static_cast<int64_t>(m) * ldc + n;
+    if (n + 4 <= n_limit) {
+      f32x4 o = acc;
+      if (accumulate) o += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = o;
+    } else {
+      for (int e = 0; e < 4 && n + e < n_limit; ++e) dst[e] = accumulate ? dst[e] + acc[e] : acc[e];
+    }
+  }
+};
+
 template <typename TO, typename ACC>
 struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_scale[n] )   (golden: gemm.py:213-223)
   TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;

@@ -40,4 +40,13 @@ int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream
   return g256::gemm256_launch<g256::PolF16>(a, epi, m_total, s);
 }
 
+// 16-bit operands, fp32 output (optionally accumulated onto C): used by the MoE router for its hi/lo split product
+int launch_gemm_mfma256_f32out(const GemmArgs& a, int dtype, int accumulate, int64_t m_total, hipStream_t s) {
+  MOJO_REQUIRE((dtype == MOJO_BF16 || dtype == MOJO_F16) && a.ldc % 4 == 0 && aligned_to(a.C, 16) && g256::gemm256_layout_ok(a, 2),
+               MOJO_EUNSUPPORTED, "gemm_mfma256_f32out: preconditions not met");
+  g256::EpilogueF32 epi{static_cast<float*>(a.C), a.ldc, accumulate};
+  if (dtype == MOJO_BF16) return g256::gemm256_launch<g256::PolBF16>(a, epi, m_total, s);
+  return g256::gemm256_launch<g256::PolF16>(a, epi, m_total, s);
+}
+
 }  // namespace mojo

@@ -7,8 +7,10 @@
 //   combine  reads N x H x elt and writes T x H x elt.
 // Nothing here syncs with the host; dispatch and combine are deterministic (no atomics decide an order).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
+#include "gemm.h"
 
 namespace mojo {
 
@@ -20,6 +22,64 @@ namespace mojo {
 // broadcast load.  The four waves of the block split the hidden dimension; their partial logits meet in LDS, where one
 // token's E values then sit on consecutive lanes for the softmax and the k rounds of wave-wide arg-max.
 constexpr int GATE_MAX_E = 1024;
+
+// One token: logits = sum of `parts` fp32 partials (stride `part_stride` floats), softmax over E, k rounds of wave-wide
+// arg-max (descending value, ties -> lowest expert id), gates renormalised over the selected.  Lane l holds experts
+// l, l+64, ...; all 64 lanes of the wave call this together.
+__device__ __forceinline__ void gate_softmax_topk(const float* logits, int64_t part_stride, int parts, int experts, int top_k,
+                                                  int lane, int32_t* out_idx, float* out_gate) {
+  constexpr int PER = GATE_MAX_E / 64;
+  float v[PER];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = lane + 64 * i;
+    if (e < experts) {
+      float acc = 0.f;
+      for (int p = 0; p + 1 < parts; p += 2) acc += logits[e + p * part_stride] + logits[e + (p + 1) * part_stride];
+      if (parts & 1) acc += logits[e + (parts - 1) * part_stride];
+      v[i] = acc;
+    } else {
+      v[i] = -INFINITY;
+    }
+    mx = fmaxf(mx, v[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = v[i] == -INFINITY ? 0.f : __expf(v[i] - mx);
+    sum += v[i];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) v[i] = (lane + 64 * i < experts) ? v[i] / sum : -1.f;      // -1: not a candidate
+  float sel_sum = 0.f, my_val = 0.f;
+  int my_idx = 0;
+  for (int r = 0; r < top_k; ++r) {
+    float best = -1.f;
+    int best_e = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (v[i] > best) { best = v[i]; best_e = lane + 64 * i; }     // ascending e inside a lane: first maximum wins
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int oe = __shfl_xor(best_e, o);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (lane + 64 * i == best_e) v[i] = -1.f;
+    sel_sum += best;
+    if (lane == r) { my_val = best; my_idx = best_e; }           // top_k <= 64 results, one per lane
+  }
+  if (lane < top_k) {
+    out_idx[lane] = my_idx;
+    out_gate[lane] = my_val / sel_sum;
+  }
+}
 
 template <typename T, int TT, int EI>
 __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x, const float* __restrict__ w,
@@ -83,60 +143,40 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
   }
   __syncthreads();
   // softmax + top-k: wave w takes tokens w, w+4, ... of the block; lane l holds experts l, l+64, ...
-  constexpr int PER = GATE_MAX_E / 64;
-  const int per = (experts + 63) >> 6;
   const int part = tpw * experts;                                       // stride between the waves' partial logits
   for (int t = wave; t < tpw; t += 4) {
     const int64_t token = tok0 + t;
     if (token >= tokens) break;
-    float v[PER];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = lane + 64 * i;
-      if (i < per && e < experts) {
-        const float* l = s_logits + t * experts + e;
-        v[i] = (l[0] + l[part]) + (l[2 * part] + l[3 * part]);
-      } else {
-        v[i] = -INFINITY;
-      }
-      mx = fmaxf(mx, v[i]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      v[i] = v[i] == -INFINITY ? 0.f : __expf(v[i] - mx);
-      sum += v[i];
-    }
-    sum = wave_sum(sum);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) v[i] = (lane + 64 * i < experts) ? v[i] / sum : -1.f;      // -1: not a candidate
-    float sel_sum = 0.f, my_val = 0.f;
-    int my_idx = 0;
-    for (int r = 0; r < top_k; ++r) {
-      float best = -1.f;
-      int best_e = 0x7fffffff;
-#pragma unroll
-      for (int i = 0; i < PER; ++i)
-        if (v[i] > best) { best = v[i]; best_e = lane + 64 * i; }     // ascending e inside a lane: first maximum wins
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ob = __shfl_xor(best, o);
-        const int oe = __shfl_xor(best_e, o);
-        if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
-      }
-#pragma unroll
-      for (int i = 0; i < PER; ++i)
-        if (lane + 64 * i == best_e) v[i] = -1.f;
-      sel_sum += best;
-      if (lane == r) { my_val = best; my_idx = best_e; }           // top_k <= 64 results, one per lane
-    }
-    if (lane < top_k) {
-      out_idx[token * top_k + lane] = my_idx;
-      out_gate[token * top_k + lane] = my_val / sel_sum;
-    }
+    gate_softmax_topk(s_logits + t * experts, part, 4, experts, top_k, lane, out_idx + token * top_k, out_gate + token * top_k);
+  }
+}
+
+// large expert counts: logits come from the MFMA GEMM (x @ w_hi + x @ w_lo, `parts` fp32 slabs of [tokens, e_pad]);
+// one wave per token
+__global__ __launch_bounds__(256) void moe_gate_select_kernel(const float* __restrict__ logits, int64_t part_stride, int parts,
+                                                              int e_pad, int32_t* __restrict__ out_idx,
+                                                              float* __restrict__ out_gate, int64_t tokens, int experts,
+                                                              int top_k) {
+  const int lane = threadIdx.x & 63;
+  const int64_t token = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  if (token >= tokens) return;
+  gate_softmax_topk(logits + token * e_pad, part_stride, parts, experts, top_k, lane, out_idx + token * top_k,
+                    out_gate + token * top_k);
+}
+
+// fp32 gate weight [hidden, E] -> hi + lo in the activation dtype, [hidden, e_pad] each (zero padded columns):
+// x @ w = x @ hi + x @ lo to ~2^-16 relative, which keeps the expert ranking of the fp32 product
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gate_split_kernel(const float* __restrict__ w, T* __restrict__ hi, T* __restrict__ lo,
+                                                             int hidden, int experts, int e_pad) {
+  const int64_t total = static_cast<int64_t>(hidden) * e_pad;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const int e = static_cast<int>(i % e_pad);
+    const int64_t h = i / e_pad;
+    const float v = e < experts ? w[h * experts + e] : 0.f;
+    const T a = elt<T>::from_f(v);
+    hi[i] = a;
+    lo[i] = elt<T>::from_f(v - elt<T>::to_f(a));
   }
 }
 
@@ -396,9 +436,64 @@ static int launch_gating(const void* x, const float* w, int32_t* idx, float* gat
 
 using namespace mojo;
 
+// The MFMA route pays when the logits are real GEMM work: many experts, many tokens, 16-bit activations.
+static bool gate_use_mfma(int64_t tokens, int64_t hidden, int64_t experts, int dtype) {
+  if (const char* e = getenv("MOJO_HIP_GATING_MFMA")) return atoi(e) != 0 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && hidden % 64 == 0 && hidden >= 64;
+  return (dtype == MOJO_BF16 || dtype == MOJO_F16) && experts >= 32 && tokens >= 512 && hidden % 64 == 0 && hidden >= 64;
+}
+static int64_t gate_e_pad(int64_t experts) { return (experts + 15) / 16 * 16; }
+static int gate_splitk(int64_t tokens, int64_t hidden, int64_t e_pad) {
+  const int64_t tiles = ceil_div(tokens, 256) * ceil_div(e_pad, 256);
+  int64_t sk = ceil_div(256, tiles);
+  const int64_t nkt = hidden / 64;
+  if (sk > nkt / 4) sk = nkt / 4;
+  if (sk > 8) sk = 8;
+  return sk < 1 ? 1 : static_cast<int>(sk);
+}
+
+extern "C" int64_t mojo_hip_moe_gating_workspace_bytes(int64_t tokens, int64_t hidden_size, int64_t num_experts, int dtype) {
+  if (!gate_use_mfma(tokens, hidden_size, num_experts, dtype)) return 64;
+  const int64_t e_pad = gate_e_pad(num_experts);
+  const int sk = gate_splitk(tokens, hidden_size, e_pad);
+  return 2 * hidden_size * e_pad * 2 + 2 * sk * tokens * e_pad * 4 + 256;
+}
+
+template <typename T>
+static int gating_mfma(const void* x, const float* w, int32_t* idx, float* gate, int64_t tokens, int hidden, int experts,
+                       int top_k, int dtype, void* workspace, hipStream_t s) {
+  const int e_pad = static_cast<int>(gate_e_pad(experts));
+  const int sk = gate_splitk(tokens, hidden, e_pad);
+  char* ws = static_cast<char*>(workspace);
+  T* hi = reinterpret_cast<T*>(ws);
+  T* lo = hi + static_cast<int64_t>(hidden) * e_pad;
+  const int64_t w_bytes = (2 * static_cast<int64_t>(hidden) * e_pad * 2 + 255) / 256 * 256;
+  float* logits = reinterpret_cast<float*>(ws + w_bytes);                   // [2 * sk][tokens][e_pad]
+  const int64_t slab = tokens * e_pad;
+  int64_t blocks = ceil_div(static_cast<int64_t>(hidden) * e_pad, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(moe_gate_split_kernel<T>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, w, hi, lo, hidden, experts, e_pad);
+  MOJO_CHECK_LAUNCH("moe_gating(split)");
+  for (int pass = 0; pass < 2; ++pass) {
+    GemmArgs a;
+    a.A = x; a.W = pass ? lo : hi; a.bias = nullptr;
+    a.C = logits + static_cast<int64_t>(pass) * sk * slab;
+    a.lda = hidden; a.ldc = e_pad; a.w_group = 0; a.w_k = e_pad; a.w_n = 1;          // [K, N] weights
+    a.K = hidden; a.N = e_pad; a.G = 1;
+    a.uniform_rows = static_cast<int>(tokens);
+    if (sk > 1) { a.splitk = sk; a.slab = a.C; a.slab_rows = static_cast<int>(tokens); }
+    const int rc = launch_gemm_mfma256_f32out(a, dtype, 0, tokens, s);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(moe_gate_select_kernel, dim3(static_cast<unsigned>(ceil_div(tokens, 4))), dim3(256), 0, s, logits, slab,
+                     2 * sk, e_pad, idx, gate, tokens, experts, top_k);
+  MOJO_CHECK_LAUNCH("moe_gating(select)");
+  return MOJO_OK;
+}
+
 extern "C" int mojo_hip_moe_gating(const void* hidden, const float* gate_weight, int32_t* top_k_indices,
                                    float* top_k_gates, int64_t tokens, int64_t hidden_size, int64_t num_experts,
-                                   int64_t top_k, int dtype, mojo_stream_t stream) {
+                                   int64_t top_k, int dtype, void* workspace, int64_t workspace_bytes,
+                                   mojo_stream_t stream) {
   if (tokens == 0) return MOJO_OK;
   MOJO_REQUIRE(hidden && gate_weight && top_k_indices && top_k_gates, MOJO_EINVAL, "moe_gating: null pointer");
   MOJO_REQUIRE(tokens > 0 && hidden_size > 0 && hidden_size < (1LL << 30), MOJO_EINVAL, "moe_gating: bad shape");
@@ -409,6 +504,14 @@ extern "C" int mojo_hip_moe_gating(const void* hidden, const float* gate_weight,
   MOJO_REQUIRE(aligned_to(hidden, 16), MOJO_EUNSUPPORTED, "moe_gating: hidden_states must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int h = static_cast<int>(hidden_size), e = static_cast<int>(num_experts), k = static_cast<int>(top_k);
+  if (gate_use_mfma(tokens, hidden_size, num_experts, dtype)) {
+    MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_moe_gating_workspace_bytes(tokens, hidden_size, num_experts, dtype) &&
+                     aligned_to(workspace, 256),
+                 MOJO_EWORKSPACE, "moe_gating: workspace too small");
+    MOJO_REQUIRE(tokens < (1LL << 31), MOJO_EUNSUPPORTED, "moe_gating: too many tokens");
+    return dtype == MOJO_BF16 ? gating_mfma<bf16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, dtype, workspace, s)
+                              : gating_mfma<f16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, dtype, workspace, s);
+  }
   switch (dtype) {
     case MOJO_F32: return launch_gating<float>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, s);
     case MOJO_F16: return launch_gating<f16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, s);

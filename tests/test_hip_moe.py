@@ -54,7 +54,9 @@ def test_gating_vectors(case):
 
 @pytest.mark.parametrize("experts,k,hidden,tokens", [(16, 4, 1024, 64), (32, 8, 1024, 128), (64, 8, 1024, 256),
                                                      (64, 8, 1024, 1024), (8, 2, 4096, 8192), (384, 8, 3584, 128),
-                                                     (256, 8, 7168, 77), (5, 5, 200, 33)])
+                                                     (256, 8, 7168, 77), (5, 5, 200, 33),
+                                                     # many experts x many tokens: the MFMA route (x @ w_hi + x @ w_lo)
+                                                     (384, 8, 3584, 2048), (256, 8, 7168, 600), (33, 3, 128, 515)])
 def test_gating_reference_space(experts, k, hidden, tokens):
     torch.manual_seed(0)
     ref = torch_cls("MojoMoEGating")(hidden_size=hidden, num_experts=experts, top_k=k)
@@ -188,3 +190,21 @@ def test_moe_layer_end_to_end_matches_the_oracle_chain():
     want = chain(g_ref, refs["MojoMoEDispatch"](num_experts=experts), e_ref, refs["MojoMoECombine"](), x)
     got = chain(g_hip, hip_cls("MojoMoEDispatch")(num_experts=experts), e_hip, hip_cls("MojoMoECombine")(), x.to(DEV))
     check_tol_diff(to_cpu(got), want, mixed_tol=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gating_mfma_route_agrees_with_vector_route(dtype, monkeypatch):
+    """Same inputs through both routes of `mojo_hip_moe_gating`: identical expert choice (up to near-ties), gates to 1e-4."""
+    torch.manual_seed(3)
+    experts, k, hidden, tokens = 128, 6, 1024, 768
+    op = hip_cls("MojoMoEGating")(hidden_size=hidden, num_experts=experts, top_k=k).to(DEV)
+    with torch.no_grad():
+        op.gate_weight.normal_(std=0.05)
+    x = torch.rand(tokens, hidden, dtype=dtype, device=DEV)
+    monkeypatch.setenv("MOJO_HIP_GATING_MFMA", "1")
+    idx_m, g_m = op(x)
+    monkeypatch.setenv("MOJO_HIP_GATING_MFMA", "0")
+    idx_v, g_v = op(x)
+    same = idx_m == idx_v
+    assert float(same.float().mean()) >= 0.999
+    torch.testing.assert_close(g_m[same], g_v[same], atol=1e-4, rtol=1e-3)
