@@ -51,6 +51,16 @@ __device__ __forceinline__ unsigned char to_fp8_e4m3(float v) {
   return static_cast<unsigned char>(packed & 0xff);
 }
 
+// round_half_even(y / scale), bit-identical to the IEEE division, at the price of one multiply for almost every element:
+// t = y * (1/scale) is within a few ulp of the true quotient, so rint(t) can only differ from rint(y / scale) when t sits
+// within that distance of a rounding boundary (k + 0.5); only those elements take the real division.  |t| <= ~448.
+__device__ __forceinline__ float round_quotient(float y, float scale, float inv_scale) {
+  const float t = y * inv_scale;
+  const float r = rintf(t);
+  if (fabsf(fabsf(t - r) - 0.5f) < 1e-3f) return rintf(__fdiv_rn(y, scale));
+  return r;
+}
+
 template <typename T, int VEC, int CACHE>
 __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
   typedef typename vec_of<T, VEC>::type V;
@@ -103,16 +113,35 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
       rstd = rsqrtf(ss / static_cast<float>(a.dim) + a.eps);
     }
     // y = ((f * rstd) * w) [* smooth]: single IEEE multiplies, the golden's order
-    auto finish = [&](int v, float (&f)[VEC]) {
+    auto load_f32 = [&](const float* p, int v, float (&dst)[VEC]) {        // VEC floats of a per-column vector
+      if constexpr (VEC % 4 == 0) {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float t = f[j];
-        if (a.weight) {
-          t = __fmul_rn(__fmul_rn(t, rstd), a.weight[v * VEC + j]);
-          if (a.out_normed) a.out_normed[base + v * VEC + j] = t;
+        for (int q = 0; q < VEC / 4; ++q) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(p + v * VEC + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * q + e] = t[e];
         }
-        if (a.smooth) t = __fmul_rn(t, a.smooth[v * VEC + j]);
-        f[j] = t;
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = p[v * VEC + j];
+      }
+    };
+    auto finish = [&](int v, float (&f)[VEC]) {
+      if (a.weight) {
+        float w[VEC];
+        load_f32(a.weight, v, w);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = __fmul_rn(__fmul_rn(f[j], rstd), w[j]);
+        if (a.out_normed) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) a.out_normed[base + v * VEC + j] = f[j];
+        }
+      }
+      if (a.smooth) {
+        float sm[VEC];
+        load_f32(a.smooth, v, sm);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] = __fmul_rn(f[j], sm[j]);
       }
     };
     // ---- pass 2: y, row maximum ----------------------------------------------------------------------------------
@@ -137,12 +166,13 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     float scale = __fdiv_rn(fmaxf(amax, 1e-12f), a.q_max);
     if (a.tiny_scale_is_one && scale < 1e-6f) scale = 1.0f;
     if (threadIdx.x == 0) a.out_scale[row] = scale;
+    const float inv_scale = __fdiv_rn(1.0f, scale);
     // ---- pass 3: quantise ------------------------------------------------------------------------------------------
     auto emit = [&](int v, const float (&f)[VEC]) {
       unsigned char q[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const float r = fminf(fmaxf(rintf(__fdiv_rn(f[j], scale)), a.q_min), a.q_max);
+        const float r = fminf(fmaxf(round_quotient(f[j], scale, inv_scale), a.q_min), a.q_max);
         q[j] = a.fp8 ? to_fp8_e4m3(r) : static_cast<unsigned char>(static_cast<signed char>(static_cast<int>(r)));
       }
       unsigned char* dst = out_q + base + v * VEC;
@@ -184,7 +214,8 @@ static int launch_norm_quant(const NormQuantArgs& a, hipStream_t s) {
   constexpr int WIDE = 16 / sizeof(T);
   const size_t al = WIDE * sizeof(T);
   const bool wide = a.dim % WIDE == 0 && aligned_to(a.hidden, al) && (!a.residual || aligned_to(a.residual, al)) &&
-                    (!a.out_sum || aligned_to(a.out_sum, al)) && aligned_to(a.out_q, WIDE);
+                    (!a.out_sum || aligned_to(a.out_sum, al)) && aligned_to(a.out_q, WIDE) &&
+                    (!a.weight || aligned_to(a.weight, 16)) && (!a.smooth || aligned_to(a.smooth, 16));
   int64_t blocks = a.rows > 256 * 32 ? 256 * 32 : a.rows;
   if (wide) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((norm_quant_kernel<T, 1, 8>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);

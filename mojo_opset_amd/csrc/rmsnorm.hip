@@ -25,8 +25,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
   const int n_vec = dim / VEC;
   const float inv_dim = 1.0f / static_cast<float>(dim);
 
-  for (int64_t row = static_cast<int64_t>(blockIdx.x) * ROWS_PER_BLOCK + sub; row < rows;
-       row += static_cast<int64_t>(gridDim.x) * ROWS_PER_BLOCK) {
+  // (the trip count is the same for every thread of the block — the NW > 1 forms synchronise inside the loop; a row
+  // group past the end recomputes the last row and stores nothing)
+  for (int64_t row0 = static_cast<int64_t>(blockIdx.x) * ROWS_PER_BLOCK; row0 < rows;
+       row0 += static_cast<int64_t>(gridDim.x) * ROWS_PER_BLOCK) {
+    const bool live = row0 + sub < rows;
+    const int64_t row = live ? row0 + sub : rows - 1;
     const T* h = hidden + row * dim;
     const T* r = residual ? residual + row * dim : nullptr;
     V cache[CACHE];
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
           vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(y, j))));
-        if (summed) store_vec<T, VEC>(summed + row * dim + v * VEC, x);
+        if (summed && live) store_vec<T, VEC>(summed + row * dim + v * VEC, x);
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -49,11 +53,18 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
       }
       if (c < CACHE) cache[c] = x;   // c is uniform across the unrolled prefix; see below
     }
-    if constexpr (ROWS_PER_BLOCK == 1) {
-      ss = block_sum<NW>(ss, red);
-      __syncthreads();                // `red` is reused by the next row
-    } else {
+    if constexpr (NW == 1) {
       ss = wave_sum(ss);
+    } else {                          // NW waves per row, 4 / NW rows per block: sum the row's own waves
+      ss = wave_sum(ss);
+      const int wave = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) red[wave] = ss;
+      __syncthreads();
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) t += red[sub * NW + i];
+      ss = t;
+      __syncthreads();                // `red` is reused by the next row
     }
     const float rstd = rsqrtf(ss * inv_dim + eps);
     // pass 2
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidd
 #pragma unroll
       for (int j = 0; j < VEC; ++j)
         vset<T, VEC>(o, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) * rstd * elt<T>::to_f(vget<T, VEC>(w, j))));
-      store_vec<T, VEC>(normed + row * dim + v * VEC, o);
+      if (live) store_vec<T, VEC>(normed + row * dim + v * VEC, o);
     }
   }
 }
@@ -94,6 +105,11 @@ static void launch_rms(const void* hidden, const void* residual, const void* wei
     int64_t blocks = ceil_div(rows, 4);
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 64, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
+                       static_cast<int>(dim), eps);
+  } else if (n_vec <= 128 * 4) {   // two waves per row, two rows per block: half the barriers per byte of the 256-thread form
+    int64_t blocks = ceil_div(rows, 2);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 128, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
                        static_cast<int>(dim), eps);
   } else {
     int64_t blocks = rows > 256 * 32 ? 256 * 32 : rows;

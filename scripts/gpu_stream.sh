@@ -4,5 +4,5 @@ python - <<'PY'
 import json, torch, sys
 sys.path.insert(0, '.')
 from benchmarks.extras import bench_streaming
-print(json.dumps(bench_streaming(torch.device('cuda', 0)), indent=1))
+for k, v in bench_streaming(torch.device('cuda', 0)).items(): print(k, round(v["us"], 1), "us", round(v["frac_of_hbm_peak"], 3))
 PY
