@@ -346,6 +346,7 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
 
 }  // namespace mojo
 #include "mla512_pair.h"
+#include "mla512_oct.h"
 namespace mojo {
 
 // merge the splits of one (token, head): grid = (Tq, H), R/4 threads
@@ -399,9 +400,17 @@ template <typename T>
 static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
   if (r == 512 && rope == 64 && a.page_shift >= 0) {
     const int head_blocks = (a.heads + 63) / 64;
-    void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
-    hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
+    // MOJO_HIP_MLA_KERNEL=pair selects the one-wave-per-SIMD layout (32 heads per wave); default: two waves per SIMD
+    static const bool use_pair = [] { const char* e = getenv("MOJO_HIP_MLA_KERNEL"); return e && e[0] == 'p'; }();
+    if (use_pair) {
+      void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
+      hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
+    } else {
+      void (*fn)(MlaArgs) = mla512_oct_kernel<T>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_OCT_LDS);
+      hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(512), MLA512_OCT_LDS, s, a);
+    }
     MOJO_CHECK_LAUNCH("mla512");
     if (a.n_splits > 1) {
       hipLaunchKernelGGL(mla_merge_kernel<T>, dim3(a.n_tiles, a.heads), dim3(128), 0, s, a, 512);

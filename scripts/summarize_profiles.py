@@ -23,8 +23,15 @@ def counter_mean(path, kernel_substr, counter):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def kernel_avg_ns(path, kernel_substr):
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(path)) if kernel_substr in r["Kernel_Name"]]
+def kernel_avg_ns(path, kernel_substr, last=None):
+    """Mean duration of the launches of one kernel; ``last`` keeps only the final N launches in start order (the timed
+    steps of bench.py: the settle and warmup launches in front of them run through the clock transient)."""
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for r in csv.DictReader(open(path)) if kernel_substr in r["Kernel_Name"]]
+    rows.sort()
+    d = [x[1] for x in rows]
+    if last is not None:
+        d = d[-last:]
     return (sum(d) / len(d), len(d)) if d else (None, 0)
 
 
@@ -37,13 +44,19 @@ for tag in ("decode", "gg", "mla", "prefill"):
 # their size (MI355X_MICROARCH.md §HBM) -> doubled.
 fetch, nf = counter_mean(one("decode_fetch/**/*counter_collection.csv"), "decode_split_kernel", "FETCH_SIZE")
 write, nw = counter_mean(one("decode_write/**/*counter_collection.csv"), "decode_split_kernel", "WRITE_SIZE")
-avg_ns, n = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_split_kernel")
-merge_ns, _ = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_merge_kernel")
+TIMED_STEPS = 200                     # scripts/profile_r1.sh runs bench.py --steps 200
+avg_ns, n = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_split_kernel", last=TIMED_STEPS)
+all_ns, n_all = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_split_kernel")
+merge_ns, _ = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_merge_kernel", last=TIMED_STEPS)
 if fetch is not None and write is not None:
     out = {
         "kernel": "mojo::decode_split_kernel<bf16,4,nt>",
         "launches": n,
         "avg_duration_us": avg_ns / 1e3,
+        "note": "mean over the timed steps (the last 200 launches); the kernel_stats CSV also averages the settle and "
+                "warmup launches, which run through the clock transient",
+        "all_launches": n_all,
+        "avg_duration_us_all_launches": all_ns / 1e3,
         "merge_kernel_avg_us": merge_ns / 1e3 if merge_ns else None,
         "FETCH_SIZE_KiB_raw": fetch,
         "WRITE_SIZE_KiB_raw": write,
