@@ -63,21 +63,24 @@ struct DecodeArgs {
   int abab;
 };
 
-template <typename T, int G, bool NT>
-__global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
+// FUSED: one workgroup = all chunks of one (sequence, kv-head), one wave per chunk (n_chunks <= 8); the partial states
+// meet in LDS and the workgroup writes the final output itself — no partials in HBM, no merge launch.
+template <typename T, int G, bool NT, bool FUSED>
+__global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeArgs a) {
   typedef typename pack8<T>::vec V8;
   typedef typename pack8<T>::pair V2;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const int r = lane / DEC_LPT;
   const int j = lane % DEC_LPT;
-  const int chunk = blockIdx.x;
+  const int chunk = FUSED ? static_cast<int>(threadIdx.x >> 6) : static_cast<int>(blockIdx.x);
   const int b = blockIdx.y / a.hkv;
   const int kvh = blockIdx.y % a.hkv;
 
   const int seq_len = a.seq_lens[b];
   const int tok_begin = chunk * a.chunk_tokens;
-  if (seq_len <= 0 || tok_begin >= seq_len) return;
-  const int tok_end = min(seq_len, tok_begin + a.chunk_tokens);
+  const bool has_work = seq_len > 0 && tok_begin < seq_len;
+  if (!FUSED && !has_work) return;
+  const int tok_end = has_work ? min(seq_len, tok_begin + a.chunk_tokens) : tok_begin + 1;
   const bool dim_ok = j * 8 < a.dim;
   const int jd = dim_ok ? j * 8 : a.dim - 8;          // lanes past a short head re-read its last slice
 
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
 
   // three-tile register ring, prefetch distance two tiles (16 KiB in flight per wave)
   Tile ta, tb, tc;
+  if (has_work) {
   load_tile(ta, tok_begin);
   if (tok_begin + DEC_TILE < tok_end) load_tile(tb, tok_begin + DEC_TILE);
   for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DEC_TILE) {
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
     if (t0 + 2 * DEC_TILE >= tok_end) break;
     if (t0 + 4 * DEC_TILE < tok_end) load_tile(tb, t0 + 4 * DEC_TILE);
     process(tc, t0 + 2 * DEC_TILE);
+  }
   }
 
   // merge the DEC_TPL lane rows (lanes j, j+16, j+32, j+48 hold the same head-dim slice)
@@ -240,6 +245,44 @@ __global__ __launch_bounds__(64) void decode_split_kernel(DecodeArgs a) {
     }
   }
 
+  if constexpr (FUSED) {
+    extern __shared__ float s_part[];                    // [n_chunks][G][dim + 2]
+    const int stride = a.dim + 2;
+    if (r == 0 && dim_ok) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        float* dst = s_part + (chunk * G + g) * stride;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[j * 8 + e] = acc[g][e];
+        if (j == 0) { dst[a.dim] = m[g]; dst[a.dim + 1] = l[g]; }
+      }
+    }
+    __syncthreads();
+    // every thread of the workgroup takes (head g, 4 output elements) items
+    const int n_chunks_seq = seq_len <= 0 ? 0 : min((seq_len + a.chunk_tokens - 1) / a.chunk_tokens, static_cast<int>(blockDim.x >> 6));
+    const int per_head = a.dim / 4;
+    typedef typename vec_of<T, 4>::type V4;
+    for (int item = threadIdx.x; item < G * per_head; item += blockDim.x) {
+      const int g = item / per_head, d0 = (item - g * per_head) * 4;
+      const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+      float mx = -INFINITY;
+      for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, s_part[(c * G + g) * stride + a.dim]);
+      f32x4 num = {0.f, 0.f, 0.f, 0.f};
+      float den = 0.f;
+      for (int c = 0; c < n_chunks_seq; ++c) {
+        const float* src = s_part + (c * G + g) * stride;
+        const float w = exp2f(src[a.dim] - mx);
+        den = fmaf(w, src[a.dim + 1], den);
+        num += f32x4{src[d0], src[d0 + 1], src[d0 + 2], src[d0 + 3]} * w;
+      }
+      const float inv = n_chunks_seq > 0 ? 1.0f / den : 0.f;      // empty sequence: zeros (golden semantics)
+      V4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(num[e] * inv);
+      *reinterpret_cast<V4*>(static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + d0) = o;
+    }
+    return;
+  }
   if (r != 0 || !dim_ok) return;
   const int n_chunks_seq = (seq_len + a.chunk_tokens - 1) / a.chunk_tokens;
   if (n_chunks_seq == 1) {
@@ -332,12 +375,27 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
 
 template <typename T, bool NT>
 static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
+  static const bool no_fuse = [] { const char* e = getenv("MOJO_HIP_DECODE_FUSE"); return e && e[0] == '0'; }();
+  if (a.n_chunks <= 8 && a.dim % 4 == 0 && !no_fuse) {   // all chunks of a (sequence, kv-head) in one workgroup: merged in LDS
+    dim3 grid(1, static_cast<unsigned>(batch * a.hkv));
+    const dim3 block(static_cast<unsigned>(64 * a.n_chunks));
+    const size_t lds = static_cast<size_t>(a.n_chunks) * G * (a.dim + 2) * sizeof(float);
+    switch (G) {
+      case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, true>), grid, block, lds, s, a); break;
+      case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, true>), grid, block, lds, s, a); break;
+      case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, true>), grid, block, lds, s, a); break;
+      case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, true>), grid, block, lds, s, a); break;
+      default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
+    }
+    MOJO_CHECK_LAUNCH("paged_decode_gqa(fused)");
+    return MOJO_OK;
+  }
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv));
   switch (G) {
-    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT>), grid, dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT>), grid, dim3(64), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT>), grid, dim3(64), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT>), grid, dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, false>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, false>), grid, dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, false>), grid, dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, false>), grid, dim3(64), 0, s, a); break;
     default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
   }
   MOJO_CHECK_LAUNCH("paged_decode_gqa(split)");

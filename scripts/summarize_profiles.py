@@ -14,7 +14,7 @@ os.makedirs(DST, exist_ok=True)
 
 def one(pattern):
     hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None     # gpurun merges new runs next to old ones
 
 
 def counter_mean(path, kernel_substr, counter):
