@@ -178,7 +178,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
-                     "kernel": "mojo::decode_split_kernel<bf16,4> + decode_merge_kernel (one op call)"},
+                     "kernel": "mojo::decode_split_kernel<bf16,4,nt,fused> (one launch per op call: the chunk partials are merged in LDS)"},
     }
     hung = False
     if not ns.no_extras:            # every rank takes part: the GEMM + collective cases contain collectives

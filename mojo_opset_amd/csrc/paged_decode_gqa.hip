@@ -72,7 +72,8 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
   const int lane = threadIdx.x & 63;
   const int r = lane / DEC_LPT;
   const int j = lane % DEC_LPT;
-  const int chunk = FUSED ? static_cast<int>(threadIdx.x >> 6) : static_cast<int>(blockIdx.x);
+  // (readfirstlane: the wave index must be a scalar, or every page-table lookup below turns into a vector load)
+  const int chunk = FUSED ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) : static_cast<int>(blockIdx.x);
   const int b = blockIdx.y / a.hkv;
   const int kvh = blockIdx.y % a.hkv;
 

@@ -50,7 +50,7 @@ all_ns, n_all = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_
 merge_ns, _ = kernel_avg_ns(one("decode_stats/**/*kernel_trace.csv"), "decode_merge_kernel", last=TIMED_STEPS)
 if fetch is not None and write is not None:
     out = {
-        "kernel": "mojo::decode_split_kernel<bf16,4,nt>",
+        "kernel": "mojo::decode_split_kernel<bf16,4,nt,fused>",
         "launches": n,
         "avg_duration_us": avg_ns / 1e3,
         "note": "mean over the timed steps (the last 200 launches); the kernel_stats CSV also averages the settle and "
