@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   typedef typename std::conditional<FP8, f32x4, i32x4>::type acc_t;
   constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
   __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];        // per wave: its 16 weight rows of a K block
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64 + wave * 16;
@@ -93,7 +94,10 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   const int nkb = K / 256;
   const int kb0 = static_cast<int>(static_cast<int64_t>(nkb) * slice / splitk);
   const int kb1 = static_cast<int>(static_cast<int64_t>(nkb) * (slice + 1) / splitk);
-  const uint8_t* wrow = W + static_cast<int64_t>(n0 + l15) * K + g * 16;
+  // weight loads are row-contiguous: instruction j covers rows 4j .. 4j+3 of the wave's 16, 16 lanes x 16 B = one row's
+  // 256-byte K block (measured: the M <= 4 GEMV, which reads whole rows, streams at twice the rate of 64-byte runs);
+  // the MFMA fragment shape (lane = column) is restored by a pass through a wave-private LDS image.
+  const uint8_t* wrow = W + static_cast<int64_t>(n0 + (lane >> 4)) * K + (lane & 15) * 16;
 
   acc_t acc[MT];
 #pragma unroll
@@ -109,7 +113,12 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   auto load_w = [&](int i, u32x4 (&wr)[4]) {
     const uint8_t* wp = wrow + static_cast<int64_t>(block_at(i)) * 256;
 #pragma unroll
-    for (int sx = 0; sx < 4; ++sx) wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + sx * 64));
+    for (int sx = 0; sx < 4; ++sx) wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + static_cast<int64_t>(sx) * 4 * K));
+  };
+  auto store_w = [&](int buf, const u32x4 (&wr)[4]) {
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx)
+      *reinterpret_cast<u32x4*>(&s_w[wave][buf][(4 * sx + (lane >> 4)) * ROW + (lane & 15) * 16]) = wr[sx];
   };
   auto load_a = [&](int i, u32x4 (&ar)[MT]) {
     const int64_t k0 = static_cast<int64_t>(block_at(i)) * 256;
@@ -134,6 +143,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
     for (int d = 0; d < DEPTH; ++d)
       if (d < nb) load_w(d, wreg[d]);
     store_a(0, areg[0]);
+    store_w(0, wreg[0]);
   }
   __syncthreads();
   // The ring index is kept compile-time by unrolling the body DEPTH + 1 times.  The steady-state rounds contain NO
@@ -154,18 +164,22 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const u32x4 af = *reinterpret_cast<const u32x4*>(&s_a[r & 1][(mt * 16 + l15) * ROW + sx * 64 + g * 16]);
+        const u32x4 wf = *reinterpret_cast<const u32x4*>(&s_w[wave][r & 1][l15 * ROW + sx * 64 + g * 16]);
         if constexpr (FP8) {
           typedef long i64x2 __attribute__((ext_vector_type(2)));
-          const i64x2 wl = __builtin_bit_cast(i64x2, wreg[r][sx]), al = __builtin_bit_cast(i64x2, af);
+          const i64x2 wl = __builtin_bit_cast(i64x2, wf), al = __builtin_bit_cast(i64x2, af);
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], al[0], acc[mt], 0, 0, 0);
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], al[1], acc[mt], 0, 0, 0);
         } else {
-          acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wreg[r][sx]), __builtin_bit_cast(i32x4, af),
+          acc[mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wf), __builtin_bit_cast(i32x4, af),
                                                           acc[mt], 0, 0, 0);
         }
       }
     }
-    if (!guarded || i + 1 < nb) { if (r & 1) store_a(0, areg[0]); else store_a(1, areg[1]); }
+    if (!guarded || i + 1 < nb) {
+      if (r & 1) store_a(0, areg[0]); else store_a(1, areg[1]);
+      store_w((r & 1) ^ 1, wreg[(r + 1) % (DEPTH + 1)]);
+    }
     __syncthreads();
     (void)cur;
   };
@@ -199,6 +213,134 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
       *reinterpret_cast<V4*>(C + static_cast<int64_t>(m) * N + n) = o;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// M <= 4 with [N,K] weights: a GEMV.  One wave per pair of weight rows, all 64 lanes along K (1 KiB contiguous per load
+// instruction, the whole row read front to back), v_dot4_i32_i8 (or fp8 -> fp32 FMAs) against the activations held in
+// LDS, one cross-lane reduction per output at the end.  No split-K, no finalize: one launch.
+// Algorithmic bytes: K*N (the weight stream; the M*K activations are read once per workgroup from L2).
+template <typename TO, bool FP8, int MV>
+__global__ __launch_bounds__(256) void quant_gemv_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
+                                                         const float* __restrict__ rs, const bf16_t* __restrict__ cs,
+                                                         TO* __restrict__ C, int M, int K, int N) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_act[];        // [MV][K], rows >= M are zero
+  constexpr int RPW = 2;                                                 // weight rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int idx = threadIdx.x * 16; idx < MV * K; idx += 256 * 16) {
+    const int m = idx / K;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (m < M) v = *reinterpret_cast<const u32x4*>(A + idx);
+    *reinterpret_cast<u32x4*>(s_act + idx) = v;
+  }
+  __syncthreads();
+  const int n0 = (blockIdx.x * 4 + wave) * RPW;
+  if (n0 >= N) return;
+  typedef typename std::conditional<FP8, float, int>::type acc_t;
+  acc_t acc[RPW][MV];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+    for (int m = 0; m < MV; ++m) acc[rr][m] = 0;
+  const uint8_t* wp[RPW];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) wp[rr] = W + static_cast<int64_t>(min(n0 + rr, N - 1)) * K + lane * 16;
+  const int chunks = (K + 1023) / 1024;
+  constexpr int AHEAD = 4;                                                // 1 KiB loads in flight per row
+  u32x4 ring[AHEAD][RPW];
+  auto fetch = [&](int c, u32x4 (&dst)[RPW]) {
+    const bool ok = c * 1024 + lane * 16 < K;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[rr] + c * 1024));
+      dst[rr] = v;
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < AHEAD; ++c)
+    if (c < chunks) fetch(c, ring[c]);
+  for (int c0 = 0; c0 < chunks; c0 += AHEAD) {
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) {
+      const int c = c0 + q;
+      if (c < chunks) {
+        u32x4 w[RPW];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) w[rr] = ring[q][rr];
+        if (c + AHEAD < chunks) fetch(c + AHEAD, ring[q]);
+        const int k0 = min(c * 1024 + lane * 16, K - 16);                 // lanes past the row read zero weights anyway
+#pragma unroll
+        for (int m = 0; m < MV; ++m) {
+          const u32x4 av = *reinterpret_cast<const u32x4*>(s_act + m * K + k0);
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (FP8) {
+                const int wi = static_cast<int>(w[rr][e]), ai = static_cast<int>(av[e]);
+                acc[rr][m] = fmaf(__builtin_amdgcn_cvt_f32_fp8(wi, 0), __builtin_amdgcn_cvt_f32_fp8(ai, 0), acc[rr][m]);
+                acc[rr][m] = fmaf(__builtin_amdgcn_cvt_f32_fp8(wi, 1), __builtin_amdgcn_cvt_f32_fp8(ai, 1), acc[rr][m]);
+                acc[rr][m] = fmaf(__builtin_amdgcn_cvt_f32_fp8(wi, 2), __builtin_amdgcn_cvt_f32_fp8(ai, 2), acc[rr][m]);
+                acc[rr][m] = fmaf(__builtin_amdgcn_cvt_f32_fp8(wi, 3), __builtin_amdgcn_cvt_f32_fp8(ai, 3), acc[rr][m]);
+              } else {
+                acc[rr][m] = __builtin_amdgcn_sdot4(static_cast<int>(w[rr][e]), static_cast<int>(av[e]), acc[rr][m], false);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+    for (int m = 0; m < MV; ++m) {
+      acc_t v = acc[rr][m];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      acc[rr][m] = v;
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int n = n0 + rr;
+      if (n >= N) continue;
+      const float c = static_cast<float>(cs[n]);
+#pragma unroll
+      for (int m = 0; m < MV; ++m) {
+        if (m >= M) continue;
+        float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[rr][m]), rs[m]), c);
+        asm volatile("" : "+v"(v));
+        C[static_cast<int64_t>(m) * N + n] = elt<TO>::from_f(v);
+      }
+    }
+  }
+}
+
+static bool quant_gemv_ok(int64_t m, const GemmArgs& a) {
+  return m <= 4 && a.w_k == 1 && a.w_n == a.K && a.K % 16 == 0 && a.lda == a.K && a.ldc == a.N && m * a.K <= 96 * 1024 &&
+         aligned_to(a.A, 16) && aligned_to(a.W, 16);
+}
+
+template <typename TO, bool FP8>
+static int launch_quant_gemv(const GemmArgs& a, const float* rs, const bf16_t* cs, int64_t m, hipStream_t s) {
+  const int mv = m <= 1 ? 1 : (m <= 2 ? 2 : 4);
+  const unsigned blocks = static_cast<unsigned>(ceil_div(a.N, 8));
+  const size_t lds = static_cast<size_t>(mv) * a.K;
+  const uint8_t* A = static_cast<const uint8_t*>(a.A);
+  const uint8_t* W = static_cast<const uint8_t*>(a.W);
+  TO* C = static_cast<TO*>(a.C);
+#define GEMV(MV_)                                                                                                       \
+  do {                                                                                                                  \
+    auto* fn = quant_gemv_kernel<TO, FP8, MV_>;                                                                          \
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), lds, s, A, W, rs, cs, C, static_cast<int>(m), a.K, a.N);             \
+  } while (0)
+  if (mv == 1) GEMV(1); else if (mv == 2) GEMV(2); else GEMV(4);
+#undef GEMV
+  MOJO_CHECK_LAUNCH("quant_gemm(gemv)");
+  return MOJO_OK;
 }
 
 static bool quant_skinny_ok(int64_t m, const GemmArgs& a) {
@@ -255,6 +397,9 @@ template <typename TO>
 static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, int quant_dtype, void* slab_ws,
                      hipStream_t s) {
   const bool fp8 = quant_dtype == MOJO_F8E4M3;
+  static const bool no_gemv = [] { const char* e = getenv("MOJO_HIP_QGEMM_GEMV"); return e && e[0] == '0'; }();
+  if (quant_gemv_ok(m, a) && !no_gemv)
+    return fp8 ? launch_quant_gemv<TO, true>(a, rs, cs, m, s) : launch_quant_gemv<TO, false>(a, rs, cs, m, s);
   if (quant_skinny_ok(m, a))
     return fp8 ? launch_quant_skinny<TO, true>(a, rs, cs, m, slab_ws, s) : launch_quant_skinny<TO, false>(a, rs, cs, m, slab_ws, s);
   if (g256::gemm256_layout_ok(a, 1)) {

@@ -28,7 +28,9 @@ def test_quant_gemm_vectors_bit_exact(case):
                                    # decode-sized M on the weight-streaming kernel ([N,K] weights): every row-tile count,
                                    # ragged M, one K block per slice, no split, DeepSeek-V3 shapes
                                    (16, 512, 64), (17, 7168, 4096), (33, 1536, 7168), (48, 256, 128), (64, 18432, 7168),
-                                   (3, 2048, 64), (65, 1024, 128), (128, 7168, 4096), (100, 512, 64)])
+                                   (3, 2048, 64), (65, 1024, 128), (128, 7168, 4096), (100, 512, 64),
+                                   # M <= 4: the GEMV kernel (one wave per two weight rows), ragged K and N
+                                   (1, 7168, 4096), (2, 1536, 7168), (4, 18432, 64), (3, 272, 10), (1, 48, 3)])
 @pytest.mark.parametrize("trans_weight", [False, True])
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16, torch.float32])
 def test_quant_gemm_int8_equals_integer_formula(m, k, n, trans_weight, odt):
@@ -69,7 +71,7 @@ def test_quant_gemm_error_conventions():
 
 
 @pytest.mark.parametrize("m,k,n", [(128, 7168, 1536), (32, 2048, 7168), (1, 512, 256), (300, 1024, 1000), (7, 96, 40),
-                                   (17, 7168, 4096), (64, 1536, 7168)])
+                                   (17, 7168, 4096), (64, 1536, 7168), (1, 7168, 4096), (4, 2048, 130)])
 @pytest.mark.parametrize("trans_weight", [False, True])
 def test_quant_gemm_fp8_matches_oracle(m, k, n, trans_weight):
     """Extension dtype — parity unpinned: there is no reference implementation (gemm.py:171-173 asserts int8)."""
