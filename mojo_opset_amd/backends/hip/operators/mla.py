@@ -25,6 +25,17 @@ def _per_head_gemm(x: torch.Tensor, lda: int, out: torch.Tensor, proj: torch.Ten
                                             L.ptr(ws), ws.numel(), L.stream_of(x)), "hip mla projection")
 
 
+def _absorbed_k_major(op, proj: torch.Tensor, heads: int, nope: int, vdim: int, r: int) -> torch.Tensor:
+    """``W_kn[h]^T`` for every head, contiguous ``[H, r, nope]`` (weight repacking, not per-call compute)."""
+    key = (proj.data_ptr(), proj._version, proj.dtype, str(proj.device))
+    cached = getattr(op, "_hip_w_kn_t", None)
+    if cached is None or cached[0] != key:
+        w = proj.view(heads, nope + vdim, r)[:, :nope, :].transpose(1, 2).contiguous()
+        cached = (key, w)
+        object.__setattr__(op, "_hip_w_kn_t", cached)
+    return cached[1]
+
+
 def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *, total_seq_lens=None, cu_q_lens=None,
                  cu_total_seq_lens=None):
     L.require_cuda(query, ckv_cache, kpe_cache, block_tables, total_seq_lens, cu_q_lens, cu_total_seq_lens, op.kv_b_proj)
@@ -51,7 +62,13 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     if query.stride(2) != 1 or query.stride(1) != qk or query.stride(0) != heads * qk:
         query = query.contiguous()
     q_abs = torch.empty(tq, heads, r, dtype=query.dtype, device=dev)
-    _per_head_gemm(query, qk, q_abs, proj, heads, tq, nope, r, 0, (nope + vdim) * r, r, 1)
+    if tq <= 128 and nope % 128 == 0 and r % 64 == 0:
+        # decode-sized: the weight-streaming grouped GEMM wants K-major weights; W_kn is stored [nope, r] per head, so a
+        # K-major copy [H, r, nope] is kept next to the parameter (a one-time repack, redone when the parameter changes)
+        w_t = _absorbed_k_major(op, proj, heads, nope, vdim, r)
+        _per_head_gemm(query, qk, q_abs, w_t, heads, tq, nope, r, 0, r * nope, 1, nope)
+    else:
+        _per_head_gemm(query, qk, q_abs, proj, heads, tq, nope, r, 0, (nope + vdim) * r, r, 1)
     q_rope, q_rope_ld = query[..., nope:], qk                                      # read in place by the kernel
     if nope % 8 or qk % 8:
         q_rope, q_rope_ld = q_rope.contiguous(), rope

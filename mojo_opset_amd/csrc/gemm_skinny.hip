@@ -1,0 +1,163 @@
+// Grouped GEMM for decode-sized groups (<= 128 rows per group, equal-sized groups, K-major "[N,K]" weights, 16-bit types).
+//
+// With few rows per group the product is a weight STREAM: the 256x256 tile kernel pads every group to 256 rows and spends
+// its time in prologue and epilogue (MLA's per-head projections: 64 rows per head, K = 128 or 512).  Here one workgroup =
+// 64 output columns x all rows of one group; structure as quant_skinny_kernel (quant_gemm.hip): each wave owns 16 columns,
+// loads their weight rows row-contiguously (4 rows x 256 B per instruction) and restores the MFMA fragment shape through a
+// wave-private LDS image; the group's activation block [16*MT rows][256 B of K] is shared through a padded LDS image;
+// weights of the next three K blocks and activations of the next two are in flight while a block is multiplied.
+// Row maps (gemm.h) are honoured, so the MLA shim's token-major tensors are read and written in place.
+//
+// Algorithmic bytes: G*K*N*elt (weights) + M*K*elt * (N/64) (activations, from L2) + M*N*elt.
+#include "gemm.h"
+
+namespace mojo {
+
+template <typename T> struct skinny_mfma;
+template <> struct skinny_mfma<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(u32x4 w, u32x4 a, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+  }
+};
+template <> struct skinny_mfma<f16_t> {
+  static __device__ __forceinline__ f32x4 run(u32x4 w, u32x4 a, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int MT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
+  constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
+  constexpr int KB = 128;                                    // elements of K per block
+  __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int grp = blockIdx.y;
+  const int R = a.uniform_rows;
+  const int n0 = blockIdx.x * 64 + wave * 16;
+  const int nb = a.K / KB;
+  const T* A = static_cast<const T*>(a.A);
+  const T* W = static_cast<const T*>(a.W) + static_cast<int64_t>(grp) * a.w_group;
+  // weight rows: instruction sx covers rows 4 sx .. 4 sx + 3 of the wave's 16; lane (row l / 16, 16-byte chunk l % 16)
+  const T* wrow = W + static_cast<int64_t>(n0 + (lane >> 4)) * a.w_n + (lane & 15) * 8;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // activation chunk p of this thread: row idx / 16 of the group, 16-byte chunk idx % 16 of the K block
+  const T* arow[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) {
+    const int idx = threadIdx.x + 256 * p;
+    const int t = min(idx >> 4, R - 1);
+    arow[p] = A + static_cast<int64_t>(map_row(grp * R + t, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda + (idx & 15) * 8;
+  }
+  constexpr int DEPTH = 3;
+  u32x4 wreg[DEPTH + 1][4], areg[2][MT];
+  auto load_w = [&](int i, u32x4 (&wr)[4]) {
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx)
+      wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(sx) * 4 * a.w_n + i * KB));
+  };
+  auto store_w = [&](int buf, const u32x4 (&wr)[4]) {
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx)
+      *reinterpret_cast<u32x4*>(&s_w[wave][buf][(4 * sx + (lane >> 4)) * ROW + (lane & 15) * 16]) = wr[sx];
+  };
+  auto load_a = [&](int i, u32x4 (&ar)[MT]) {
+#pragma unroll
+    for (int p = 0; p < MT; ++p) ar[p] = *reinterpret_cast<const u32x4*>(arow[p] + i * KB);
+  };
+  auto store_a = [&](int buf, const u32x4 (&ar)[MT]) {
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      const int idx = threadIdx.x + 256 * p;
+      *reinterpret_cast<u32x4*>(&s_a[buf][(idx >> 4) * ROW + (idx & 15) * 16]) = ar[p];
+    }
+  };
+  if (nb > 0) {
+    load_a(0, areg[0]);
+    if (nb > 1) load_a(1, areg[1]);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+      if (d < nb) load_w(d, wreg[d]);
+    store_a(0, areg[0]);
+    store_w(0, wreg[0]);
+  }
+  __syncthreads();
+  auto body = [&](int i, auto RC, auto GUARD) {
+    constexpr int r = decltype(RC)::value;
+    constexpr bool guarded = decltype(GUARD)::value;
+    if (!guarded || i + 2 < nb) { if (r & 1) load_a(i + 2, areg[1]); else load_a(i + 2, areg[0]); }
+    if (!guarded || i + DEPTH < nb) load_w(i + DEPTH, wreg[(r + DEPTH) % (DEPTH + 1)]);
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+      const u32x4 wf = *reinterpret_cast<const u32x4*>(&s_w[wave][r & 1][l15 * ROW + sx * 64 + g4 * 16]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(&s_a[r & 1][(mt * 16 + l15) * ROW + sx * 64 + g4 * 16]);
+        acc[mt] = skinny_mfma<T>::run(wf, af, acc[mt]);
+      }
+    }
+    if (!guarded || i + 1 < nb) {
+      if (r & 1) store_a(0, areg[0]); else store_a(1, areg[1]);
+      store_w((r & 1) ^ 1, wreg[(r + 1) % (DEPTH + 1)]);
+    }
+    __syncthreads();
+  };
+  int i0 = 0;
+  for (; i0 + 2 * DEPTH + 1 <= nb; i0 += DEPTH + 1)
+    static_for<DEPTH + 1>([&](auto RC) { body(i0 + decltype(RC)::value, RC, std::false_type{}); });
+  for (; i0 < nb; i0 += DEPTH + 1)
+    static_for<DEPTH + 1>([&](auto RC) {
+      constexpr int r = decltype(RC)::value;
+      if (i0 + r < nb) body(i0 + r, RC, std::true_type{});
+    });
+  // lane holds rows t = mt*16 + l15 of the group, columns n0 + 4 g4 .. +3
+  const int n = n0 + 4 * g4;
+  T* C = static_cast<T*>(a.C);
+  const T* bias = static_cast<const T*>(a.bias);
+  typedef typename vec_of<T, 4>::type V4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = mt * 16 + l15;
+    if (t >= R) continue;
+    V4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[mt][e]);
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
+    }
+    *reinterpret_cast<V4*>(C + static_cast<int64_t>(map_row(grp * R + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
+  }
+}
+
+bool gemm_skinny_ok(const GemmArgs& a, int dtype) {
+  if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
+  static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_SKINNY"); return e && e[0] == '0'; }();
+  if (off) return false;
+  return a.uniform_rows > 0 && a.uniform_rows <= 128 && a.w_k == 1 && a.K % 128 == 0 && a.N % 64 == 0 && a.lda % 8 == 0 &&
+         a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && a.splitk == 1 && aligned_to(a.A, 16) && aligned_to(a.W, 16) &&
+         aligned_to(a.C, 8);
+}
+
+int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
+  MOJO_REQUIRE(gemm_skinny_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_skinny: preconditions not met");
+  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G));
+  const int mt = (a.uniform_rows + 15) / 16;
+#define SKINNY(TY, MT_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_>), grid, dim3(256), 0, s, a)
+#define SKINNY_MT(TY)                                                                          \
+  do {                                                                                         \
+    if (mt <= 1) SKINNY(TY, 1); else if (mt <= 2) SKINNY(TY, 2); else if (mt <= 4) SKINNY(TY, 4); else SKINNY(TY, 8); \
+  } while (0)
+  if (dtype == MOJO_BF16) SKINNY_MT(bf16_t); else SKINNY_MT(f16_t);
+#undef SKINNY_MT
+#undef SKINNY
+  MOJO_CHECK_LAUNCH("gemm_skinny");
+  return MOJO_OK;
+}
+
+}  // namespace mojo

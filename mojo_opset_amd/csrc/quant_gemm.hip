@@ -66,14 +66,13 @@ __global__ __launch_bounds__(256) void quant_finalize_kernel(const ACC* __restri
 // Decode-sized M (<= 128) with [N,K] weights: the op is a weight STREAM (K*N bytes from HBM against 2*M*K*N cheap
 // integer ops), so the 256x256 tile shape is the wrong tool — it pads M to 256 and needs 16-way split-K with fp32 slabs
 // larger than the weight itself.  Skinny kernel: one workgroup = 64 output columns x all M rows x one K slice.
-//   * each wave owns 16 columns; its weight fragments go global -> registers (never through LDS).  MFMA does not care
-//     which k a lane supplies as long as both operands agree, so k-step s of a 256-byte K block is "bytes 64s + 16g ..
-//     +15 for lane group g": the four lanes of a column read one contiguous 64-byte segment per instruction (a lane
-//     can only feed its own column, so 64 B is the longest run an instruction can get), and the activation fragments
-//     are read from LDS with the same permutation;
+//   * each wave owns 16 columns and loads their weight rows row-contiguously (4 rows x 256 B per instruction), then
+//     restores the MFMA fragment shape (lane = column) through a wave-private LDS image.  MFMA does not care which k a
+//     lane supplies as long as both operands agree, so k-step s of a 256-byte K block is "bytes 64s + 16g .. +15 for
+//     lane group g" and the activation fragments are read from LDS with the same permutation;
 //   * the activation block [16*MT rows][256 B] is staged through registers into a double-buffered, padded LDS image
 //     shared by the four waves (stride 272 B: conflict-free ds_read_b128);
-//   * the weights of the next three K blocks and the activation block of the next one are in flight while a block is
+//   * the weights of the next three K blocks and the activation blocks of the next two are in flight while a block is
 //     multiplied;
 //   * grid = (N/64) x splitk with ~256 workgroups (each keeps 48 KiB of weights in flight); split-K slices write raw
 //     accumulators to their own slab, summed in slice order by quant_finalize_kernel (deterministic).

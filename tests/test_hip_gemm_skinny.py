@@ -1,0 +1,59 @@
+"""GPU parity of the decode-sized grouped / dense GEMM path (`csrc/gemm_skinny.hip`): equal-sized groups of <= 128 rows,
+K-major weights, optional row maps — reached through `mojo_hip_group_gemm_strided` / `mojo_hip_gemm`."""
+import pytest
+import torch
+
+from hip_utils import DEV, max_ulp_bf16ish, to_cpu
+from mojo_opset_amd.backends.hip import lib as L
+from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+
+pytestmark = pytest.mark.gpu
+
+
+def _grouped(x, w, groups, rows, k, n, lda, a_map=None, c_map=None, out=None, ldc=None):
+    lib = L.load()
+    out = torch.empty(groups * rows, n, dtype=x.dtype, device=x.device) if out is None else out
+    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(groups), dtype=torch.uint8, device=x.device)
+    L.check(lib.mojo_hip_group_gemm_strided(L.ptr(x), L.ptr(w), L.ptr(out), None, 0, groups * rows, k, n, groups, lda,
+                                            n if ldc is None else ldc, n * k, 1, k,
+                                            None if a_map is None else L.ints4(*a_map), None if c_map is None else L.ints4(*c_map),
+                                            L.dtype_code(x.dtype), L.ptr(ws), ws.numel(), L.stream_of(x)), "test gemm")
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("groups,rows,k,n", [(1, 1, 128, 64), (3, 16, 256, 128), (128, 64, 512, 128), (128, 64, 128, 512),
+                                             (2, 17, 1024, 192), (5, 128, 2048, 64), (1, 100, 4096, 256), (4, 33, 896, 320)])
+def test_skinny_grouped_gemm_integer_data_is_exact(dtype, groups, rows, k, n):
+    g = torch.Generator().manual_seed(groups * 1000 + rows)
+    x = torch.randint(-3, 4, (groups * rows, k), generator=g).to(dtype)
+    w = torch.randint(-3, 4, (groups, n, k), generator=g).to(dtype)                     # [G, N, K]
+    got = to_cpu(_grouped(x.to(DEV), w.to(DEV), groups, rows, k, n, k))
+    want = torch.einsum("grk,gnk->grn", x.view(groups, rows, k).float(), w.float()).reshape(groups * rows, n).to(dtype)
+    assert torch.equal(got.float(), want.float())
+
+
+def test_skinny_grouped_gemm_row_maps_token_major():
+    """The MLA projections' view: logical row h*T + t lives at storage row t*H + h on both sides."""
+    torch.manual_seed(0)
+    heads, tokens, k, n = 16, 24, 256, 128
+    x = torch.randn(tokens, heads, k, dtype=torch.bfloat16)
+    w = torch.randn(heads, n, k, dtype=torch.bfloat16) * 0.1
+    out = torch.zeros(tokens, heads, n, dtype=torch.bfloat16, device=DEV)
+    m = (tokens, 1, 0, heads)
+    _grouped(x.to(DEV), w.to(DEV), heads, tokens, k, n, k, a_map=m, c_map=m, out=out)
+    want = torch.einsum("thk,hnk->thn", x.float(), w.float())
+    assert max_ulp_bf16ish(to_cpu(out), want.to(torch.bfloat16), atol=1e-2) <= 1
+
+
+@pytest.mark.parametrize("m,k,n,bias", [(1, 4096, 4096, False), (64, 8192, 1024, True), (128, 1024, 28672, False), (37, 384, 64, True)])
+def test_skinny_dense_gemm_matches_fp32_reference(m, k, n, bias):
+    torch.manual_seed(1)
+    x = torch.randn(m, k, dtype=torch.bfloat16)
+    w = torch.randn(n, k, dtype=torch.bfloat16) * 0.05                                   # F.linear layout = [N, K]
+    b = torch.randn(n, dtype=torch.bfloat16) if bias else None
+    got = to_cpu(dense_gemm(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), False))
+    want = (x.float() @ w.float().t()).to(torch.bfloat16)
+    if bias:
+        want = (want.float() + b.float()).to(torch.bfloat16)
+    assert max_ulp_bf16ish(got, want, atol=2e-2) <= (2 if bias else 1)      # bias: two roundings, each may differ by one step
