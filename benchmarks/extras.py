@@ -314,11 +314,27 @@ def bench_moe(device):
     return out
 
 
+def bench_dense_decode(device):
+    """Decode-sized dense bf16 GEMMs with K-major ([N,K], `F.linear`) weights — the GEMM half of the GEMM+collective ops at
+    decode batch sizes; timed under HIP-graph replay (the Python shim's launch overhead would hide the kernel)."""
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+
+    out = {}
+    for m, k, n in ((1, 8192, 8192), (64, 8192, 8192), (64, 14336, 4096), (128, 8192, 8192)):
+        x = torch.randn(m, k, device=device, dtype=torch.bfloat16)
+        w = torch.randn(n, k, device=device, dtype=torch.bfloat16)
+        t = _time_graph(lambda: dense_gemm(x, w, None, False))
+        out[f"bf16_{m}x{k}x{n}_NK"] = {**_hbm(t, n * k * 2 + m * k * 2 + m * n * 2), "tflops": 2.0 * m * k * n / t / 1e12}
+        del x, w
+    return out
+
+
 def run_extras(device, world, rank=0):
     out = {}
     for name, fn in (("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
-                     ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe)):
+                     ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),
+                     ("dense_gemm_decode_bf16", bench_dense_decode)):
         try:
             out[name] = fn(device)
         except Exception as e:  # one failing extra must not hide the others

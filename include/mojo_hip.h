@@ -178,8 +178,10 @@ int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride, const void
 /* ---- dense GEMM used by the GEMM+collective operators (core/operators/compute_with_comm.py:12-24,
  *      `_gemm`): out[M,N] = input[M,K] @ W (+ bias).  W element (k,n) at weight + k*w_k_stride +
  *      n*w_n_stride (one of the two strides is 1).  bias (optional, [N]) is added after the product
- *      has been rounded to the storage type, as the golden's two separate ops do.                   */
-int64_t mojo_hip_gemm_workspace_bytes(void);
+ *      has been rounded to the storage type, as the golden's two separate ops do.  Decode-sized M with
+ *      K-major weights streams the weight (gemm_skinny.hip), cut along K into fp32 slabs in the workspace
+ *      when there are few column tiles (slabs summed in fixed order).                                    */
+int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n);
 int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void* out, int64_t m,
                   int64_t k, int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride,
                   int64_t w_n_stride, int dtype, void* workspace, int64_t workspace_bytes,

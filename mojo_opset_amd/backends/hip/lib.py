@@ -60,7 +60,7 @@ SIGNATURES = {
     "mojo_hip_mla_latent_attn_workspace_bytes": (c_int64, [_I, _I, _I, _I]),
     "mojo_hip_mla_latent_attn": (c_int, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I,
                                          _I, _I, _I, _I, _I, _I, c_float, c_int, _P]),
-    "mojo_hip_gemm_workspace_bytes": (c_int64, []),
+    "mojo_hip_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "mojo_hip_gemm": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_gemm_rowmap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_int, _P, _I, _P]),
     "mojo_hip_quant_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),

@@ -34,7 +34,7 @@ class HipGemmEngine(GemmEngine):
         if out is None:
             out = torch.empty(rows, n, dtype=x.dtype, device=x.device)
         assert out.dim() == 2 and out.shape[1] == n and out.stride(1) == 1 and out.dtype == x.dtype
-        ws = torch.empty(64, dtype=torch.uint8, device=x.device)
+        ws = torch.empty(L.load().mojo_hip_gemm_workspace_bytes(rows, k, n), dtype=torch.uint8, device=x.device)
         amap = None if a_map is None else L.strides3(*a_map)
         cmap = None if c_map is None else L.strides3(*c_map)
         L.check(L.load().mojo_hip_gemm_rowmap(

@@ -28,7 +28,7 @@ def dense_gemm(x: torch.Tensor, weight: torch.Tensor, bias, trans_weight: bool) 
         x2 = x2.contiguous()
     m = x2.shape[0]
     out = torch.empty(m, n, dtype=x.dtype, device=x.device)
-    ws = torch.empty(64, dtype=torch.uint8, device=x.device)
+    ws = torch.empty(L.load().mojo_hip_gemm_workspace_bytes(m, k, n), dtype=torch.uint8, device=x.device)
     L.check(L.load().mojo_hip_gemm(L.ptr(x2), L.ptr(weight), L.ptr(None if bias is None else bias.contiguous()),
                                    L.ptr(out), m, k, n, x2.stride(0), n, w_k, w_n, L.dtype_code(x.dtype), L.ptr(ws),
                                    ws.numel(), L.stream_of(x2)), "hip gemm")

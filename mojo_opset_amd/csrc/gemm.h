@@ -70,6 +70,7 @@ int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, i
 // fast MFMA path (256x256x64 tiles); returns MOJO_EUNSUPPORTED when its preconditions do not hold
 int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
 bool gemm_skinny_ok(const GemmArgs& a, int dtype);
+int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups);
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s);
 int launch_gemm_mfma256_f32out(const GemmArgs& a, int dtype, int accumulate, int64_t m_total, hipStream_t s);
 bool gemm_mfma256_ok(const GemmArgs& a, int dtype);

@@ -68,7 +68,10 @@ extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* 
                                      workspace, workspace_bytes, stream);
 }
 
-extern "C" int64_t mojo_hip_gemm_workspace_bytes(void) { return 64; }
+extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
+  const int sk = gemm_skinny_splitk(m, k, n, 1);
+  return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
+}
 
 extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const void* bias, void* out, int64_t m,
                                     int64_t k, int64_t n, int64_t lda, int64_t ldc, int64_t w_k_stride,
@@ -97,6 +100,13 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
   a.row_start = ws; a.tile_start = ws + 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   a.uniform_rows = static_cast<int>(m);
+  if (w_k_stride == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16)) {          // decode-sized, K-major weights: maybe split K
+    const int sk = gemm_skinny_splitk(m, k, n, 1);
+    if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {
+      a.splitk = sk; a.slab = static_cast<char*>(workspace) + 64; a.slab_rows = static_cast<int>(m);
+      if (!gemm_skinny_ok(a, dtype)) { a.splitk = 1; a.slab = nullptr; }
+    }
+  }
   return run_gemm(a, dtype, m, s);
 }
 

@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   const int grp = blockIdx.y;
   const int R = a.uniform_rows;
   const int n0 = blockIdx.x * 64 + wave * 16;
-  const int nb = a.K / KB;
+  const int nkb = a.K / KB;
+  const int slice = blockIdx.z;
+  const int kb0 = static_cast<int>(static_cast<int64_t>(nkb) * slice / a.splitk);
+  const int nb = static_cast<int>(static_cast<int64_t>(nkb) * (slice + 1) / a.splitk) - kb0;   // K blocks of this slice
   const T* A = static_cast<const T*>(a.A);
   const T* W = static_cast<const T*>(a.W) + static_cast<int64_t>(grp) * a.w_group;
   // weight rows: instruction sx covers rows 4 sx .. 4 sx + 3 of the wave's 16; lane (row l / 16, 16-byte chunk l % 16)
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   auto load_w = [&](int i, u32x4 (&wr)[4]) {
 #pragma unroll
     for (int sx = 0; sx < 4; ++sx)
-      wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(sx) * 4 * a.w_n + i * KB));
+      wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(sx) * 4 * a.w_n + (kb0 + i) * KB));
   };
   auto store_w = [&](int buf, const u32x4 (&wr)[4]) {
 #pragma unroll
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   };
   auto load_a = [&](int i, u32x4 (&ar)[MT]) {
 #pragma unroll
-    for (int p = 0; p < MT; ++p) ar[p] = *reinterpret_cast<const u32x4*>(arow[p] + i * KB);
+    for (int p = 0; p < MT; ++p) ar[p] = *reinterpret_cast<const u32x4*>(arow[p] + (kb0 + i) * KB);
   };
   auto store_a = [&](int buf, const u32x4 (&ar)[MT]) {
 #pragma unroll
@@ -124,6 +127,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   for (int mt = 0; mt < MT; ++mt) {
     const int t = mt * 16 + l15;
     if (t >= R) continue;
+    if (a.splitk > 1) {                                  // raw fp32 partials of this K slice (dense GEMMs only: G == 1)
+      *reinterpret_cast<f32x4*>(static_cast<float*>(a.slab) + (static_cast<int64_t>(slice) * a.slab_rows + t) * a.N + n) = acc[mt];
+      continue;
+    }
     V4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[mt][e]);
@@ -135,18 +142,52 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   }
 }
 
+// split-K finalize: C[row_map(m)][n] = round_T(sum_s slab[s][m][n]) (+ bias after the rounding), slices in index order
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_skinny_finalize_kernel(GemmArgs a, int64_t m_total) {
+  const float* slab = static_cast<const float*>(a.slab);
+  const T* bias = static_cast<const T*>(a.bias);
+  T* C = static_cast<T*>(a.C);
+  const int64_t total = m_total * a.N / 4;
+  typedef typename vec_of<T, 4>::type V4;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t m = (i * 4) / a.N;
+    const int n = static_cast<int>(i * 4 - m * a.N);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int sx = 0; sx < a.splitk; ++sx) acc += *reinterpret_cast<const f32x4*>(slab + (static_cast<int64_t>(sx) * m_total + m) * a.N + n);
+    V4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[e]);
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
+    }
+    *reinterpret_cast<V4*>(C + static_cast<int64_t>(map_row(static_cast<int>(m), a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
+  }
+}
+
+// few column tiles and a long K (down-projections at decode): cut K so that ~256 workgroups stream the weight
+int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups) {
+  if (groups != 1 || m > 128 || k % 128 != 0 || n % 64 != 0) return 1;
+  const int64_t tiles = n / 64, nkb = k / 128;
+  int64_t sk = (256 + tiles - 1) / tiles;
+  if (sk > nkb / 4) sk = nkb / 4;
+  if (sk > 16) sk = 16;
+  return sk < 1 ? 1 : static_cast<int>(sk);
+}
+
 bool gemm_skinny_ok(const GemmArgs& a, int dtype) {
   if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
   static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_SKINNY"); return e && e[0] == '0'; }();
   if (off) return false;
   return a.uniform_rows > 0 && a.uniform_rows <= 128 && a.w_k == 1 && a.K % 128 == 0 && a.N % 64 == 0 && a.lda % 8 == 0 &&
-         a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && a.splitk == 1 && aligned_to(a.A, 16) && aligned_to(a.W, 16) &&
+         a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && (a.splitk == 1 || (a.G == 1 && a.slab)) && aligned_to(a.A, 16) && aligned_to(a.W, 16) &&
          aligned_to(a.C, 8);
 }
 
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
   MOJO_REQUIRE(gemm_skinny_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_skinny: preconditions not met");
-  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G));
+  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G), static_cast<unsigned>(a.splitk));
   const int mt = (a.uniform_rows + 15) / 16;
 #define SKINNY(TY, MT_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_>), grid, dim3(256), 0, s, a)
 #define SKINNY_MT(TY)                                                                          \
@@ -157,6 +198,14 @@ int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
 #undef SKINNY_MT
 #undef SKINNY
   MOJO_CHECK_LAUNCH("gemm_skinny");
+  if (a.splitk > 1) {
+    const int64_t m_total = a.uniform_rows;
+    int64_t blocks = ceil_div(m_total * a.N / 4, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == MOJO_BF16) hipLaunchKernelGGL(gemm_skinny_finalize_kernel<bf16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, m_total);
+    else hipLaunchKernelGGL(gemm_skinny_finalize_kernel<f16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, m_total);
+    MOJO_CHECK_LAUNCH("gemm_skinny(finalize)");
+  }
   return MOJO_OK;
 }
 

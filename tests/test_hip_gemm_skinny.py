@@ -46,7 +46,9 @@ def test_skinny_grouped_gemm_row_maps_token_major():
     assert max_ulp_bf16ish(to_cpu(out), want.to(torch.bfloat16), atol=1e-2) <= 1
 
 
-@pytest.mark.parametrize("m,k,n,bias", [(1, 4096, 4096, False), (64, 8192, 1024, True), (128, 1024, 28672, False), (37, 384, 64, True)])
+@pytest.mark.parametrize("m,k,n,bias", [(1, 4096, 4096, False), (64, 8192, 1024, True), (128, 1024, 28672, False), (37, 384, 64, True),
+                                        # long K, few column tiles: split-K slabs + finalize
+                                        (64, 14336, 4096, False), (5, 28672, 64, True), (128, 8192, 512, True)])
 def test_skinny_dense_gemm_matches_fp32_reference(m, k, n, bias):
     torch.manual_seed(1)
     x = torch.randn(m, k, dtype=torch.bfloat16)
