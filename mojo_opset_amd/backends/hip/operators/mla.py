@@ -32,7 +32,7 @@ def _absorbed_k_major(op, proj: torch.Tensor, heads: int, nope: int, vdim: int, 
     if cached is None or cached[0] != key:
         w = proj.view(heads, nope + vdim, r)[:, :nope, :].transpose(1, 2).contiguous()
         cached = (key, w)
-        object.__setattr__(op, "_hip_w_kn_t", cached)
+        op._hip_w_kn_t = cached
     return cached[1]
 
 
