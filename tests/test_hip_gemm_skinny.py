@@ -59,3 +59,22 @@ def test_skinny_dense_gemm_matches_fp32_reference(m, k, n, bias):
     if bias:
         want = (want.float() + b.float()).to(torch.bfloat16)
     assert max_ulp_bf16ish(got, want, atol=2e-2) <= (2 if bias else 1)      # bias: two roundings, each may differ by one step
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("counts,k,n", [
+    ([2, 0, 5, 1, 0, 0, 3, 7], 256, 128),                       # MoE decode: a few rows per expert, empty experts
+    ([1] * 64, 1024, 192), ([0] * 31 + [9], 128, 64), ([40, 0, 33, 1], 512, 64),      # 40 and 33 rows: two 32-row chunks
+    ([3, 100, 0, 2, 1, 1, 0, 0], 384, 256),                     # one hot expert inside an otherwise sparse routing
+])
+def test_ragged_decode_groups_integer_data_is_exact(dtype, counts, k, n):
+    """MoE-decode-shaped `HIPGroupGemm` calls: a few rows per expert, empty experts, one hot expert."""
+    from hip_utils import hip_cls, torch_cls
+    g = torch.Generator().manual_seed(len(counts) * 7 + k)
+    groups = len(counts)
+    x = torch.randint(-3, 4, (sum(counts), k), generator=g).to(dtype)
+    w = torch.randint(-3, 4, (groups, n, k), generator=g).to(dtype)
+    gl = torch.tensor(counts, dtype=torch.int32)
+    want = torch_cls("MojoGroupGemm")(w.float(), True)(x.float(), gl).to(dtype)
+    got = hip_cls("MojoGroupGemm")(w.to(DEV), True)(x.to(DEV), gl.to(DEV))
+    assert torch.equal(to_cpu(got).float(), want.float())
