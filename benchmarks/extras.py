@@ -2,7 +2,6 @@
 at the BASELINE shapes, as absolute rate and fraction of the roofline that bounds them (HBM 8 TB/s, bf16
 MFMA 2.5 PFLOP/s dense, int8 5 POP/s).  Timing: HIP events on the launch stream, >= 10 launches after warm-up.
 With world > 1 every rank runs the GEMM + collective cases together (they contain collectives)."""
-import math
 
 import os
 

@@ -7,7 +7,7 @@ non-zero status, the caller gets an exception.
 import ctypes
 import os
 import threading
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 import torch
 

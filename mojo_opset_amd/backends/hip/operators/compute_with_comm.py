@@ -1,5 +1,4 @@
 """HIP<Op> classes of the GEMM + collective operators: the C-ABI GEMM plugged into `mojo_opset_amd.comm`."""
-from typing import Optional
 
 import torch
 

@@ -5,7 +5,6 @@ Constructor arguments, contracts and `forward` signatures follow
 `MojoPagedPrefillGQA` :315-451, contracts :12-37).  The classes are API-only; see
 `core/operator.py` for why the golden `forward` is not here.
 """
-from typing import Optional
 
 import torch
 

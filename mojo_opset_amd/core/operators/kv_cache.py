@@ -3,7 +3,6 @@
 Follows `mojo_opset/core/operators/kv_cache.py` (contracts :9-30, builder :33-101, op :104-171).
 A plan row is ``(src_token_start, dst_block_id, dst_block_offset, chunk_len)``.
 """
-from typing import Optional
 
 import torch
 

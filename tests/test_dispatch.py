@@ -1,7 +1,6 @@
 """Boundary behaviour pinned by the reference's `tests/base/test_backend_dispatch.py:16-74`
 (default instance type == first priority; `Torch*` prefix; strict-missing raises; name
 normalisation) plus the rules of `core/backend_registry.py:48-118`."""
-import os
 
 import pytest
 import torch

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+from hip_utils import DEV, hip_cls, run_hip_case, to_cpu, torch_cls
 
 pytestmark = pytest.mark.gpu
 # The reference's bound for these ops is atol = rtol = 1e-2, but it was never exercised against an accelerated

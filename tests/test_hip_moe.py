@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+from hip_utils import DEV, hip_cls, run_hip_case, to_cpu, torch_cls
 from mojo_opset_amd.core import check_tol_diff
 
 pytestmark = pytest.mark.gpu

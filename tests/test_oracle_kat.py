@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import mojo_opset_amd as mo
-import oracle
+import oracle  # noqa: F401  (registers the Torch* classes)
 from oracle import quant_gemm_formula
 
 

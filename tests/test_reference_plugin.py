@@ -2,7 +2,6 @@
 never on the GPU box): `mojo_opset_amd.plugin.rebase_hip_backend` must register a `HIP<Op>` subclass of every
 reference core op on the path, selectable with MOJO_BACKEND=hip, leaving the reference's torch backend intact.
 CPU only: registration, dispatch and signatures — no compute."""
-import inspect
 import os
 import subprocess
 import sys
