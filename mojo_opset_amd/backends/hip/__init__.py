@@ -9,5 +9,5 @@ from .operators.gemm import HIPGroupGemm, HIPQuantGemm  # noqa: F401
 from .operators.mla import HIPPagedDecodeMLA, HIPPagedPrefillMLA  # noqa: F401
 from .operators.compute_with_comm import (HIPAllGatherGemm, HIPGemmAll2All, HIPGemmAllReduce,  # noqa: F401
                                           HIPGemmReduceScatter)
-from .operators.moe import HIPExperts, HIPMoECombine, HIPMoEDispatch, HIPMoEGating  # noqa: F401
+from .operators.moe import HIPExperts, HIPMoE, HIPMoECombine, HIPMoEDispatch, HIPMoEGating  # noqa: F401
 from .operators.quantize import HIPDynamicQuant, HIPResidualAddRMSNormQuant  # noqa: F401

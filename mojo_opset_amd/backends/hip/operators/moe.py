@@ -2,7 +2,7 @@
 No host synchronisation anywhere: token counts stay on the device and feed the grouped GEMM as they are."""
 import torch
 
-from ....core.operators.moe import MojoExperts, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
+from ....core.operators.moe import MojoExperts, MojoMoE, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
 from .. import lib as L
 
 _ROCM = ["rocm"]
@@ -120,4 +120,15 @@ class HIPExperts(MojoExperts):
         return self._group_gemm(act, _dense(down_w), counts)
 
 
-__all__ = ["HIPMoEGating", "HIPMoEDispatch", "HIPMoECombine", "HIPExperts"]
+class HIPMoE(MojoMoE):
+    """The four HIP stages chained; with ``ep_size == 1`` nothing synchronises with the host."""
+
+    supported_platforms_list = _ROCM
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        # called through the class so the same body also binds to the reference's MojoMoE (plugin.rebase_hip_backend),
+        # which carries the same attributes but not this helper
+        return MojoMoE.compose_forward(self, hidden_states)
+
+
+__all__ = ["HIPMoEGating", "HIPMoEDispatch", "HIPMoECombine", "HIPExperts", "HIPMoE"]

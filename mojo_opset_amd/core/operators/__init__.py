@@ -4,7 +4,7 @@ from .compute_with_comm import MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllRe
 from .gemm import MojoGroupGemm, MojoQuantGemm
 from .kv_cache import MojoStorePagedKVCache, MojoStorePagedMLAKVCache, build_paged_kv_chunk_metadata
 from .mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
-from .moe import MojoExperts, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
+from .moe import MojoExperts, MojoMoE, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
 from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm
 from .position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
 from .quantize import MojoDynamicQuant, MojoResidualAddRMSNormQuant
@@ -14,5 +14,5 @@ __all__ = [
     "MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoGroupGemm", "MojoQuantGemm", "MojoStorePagedKVCache",
     "build_paged_kv_chunk_metadata", "MojoPagedDecodeMLA", "MojoPagedPrefillMLA", "MojoResidualAddRMSNorm",
     "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding", "MojoMoEGating", "MojoMoEDispatch", "MojoExperts",
-    "MojoMoECombine", "MojoDynamicQuant", "MojoResidualAddRMSNormQuant", "MojoStorePagedMLAKVCache",
+    "MojoMoECombine", "MojoMoE", "MojoDynamicQuant", "MojoResidualAddRMSNormQuant", "MojoStorePagedMLAKVCache",
 ]

@@ -89,4 +89,60 @@ def count_expert_tokens(top_k_indices: torch.Tensor, num_experts: int) -> torch.
     return torch.bincount(flat, minlength=num_experts).to(dtype=torch.int32, device=top_k_indices.device)
 
 
-__all__ = ["MojoMoEGating", "MojoMoEDispatch", "MojoExperts", "MojoMoECombine", "count_expert_tokens"]
+class MojoMoE(MojoOperator):
+    """forward(hidden_states [T, hidden]) -> [T, hidden]: ``gating -> dispatch -> experts -> combine`` built from the four
+    operators above on this instance's backend (reference `MojoMoE`, `core/operators/moe.py:12-130`), with the reference's
+    expert-parallel wiring: ``ep_size`` ranks each hold a contiguous slice of the experts, every rank routes all tokens,
+    keeps the rows of its own experts and the partial outputs are summed over ``ep_group`` (all-reduce, or reduce-scatter
+    when ``dp_input`` gathered the tokens first)."""
+
+    def __init__(self, num_experts, top_k, hidden_size, intermediate_size=None, activation: str = "swiglu", ep_size: int = 1,
+                 ep_rank: int = 0, ep_group=None, dp_input: bool = False, **kwargs):
+        super().__init__()
+        if activation != "swiglu":
+            raise NotImplementedError(f"MojoMoe: Activation {activation} is not supported.")
+        if intermediate_size is None:
+            raise ValueError("MojoMoE: intermediate_size must be provided.")
+        self.num_experts, self.top_k, self.hidden_size, self.intermediate_size = num_experts, top_k, hidden_size, intermediate_size
+        self.ep_size, self.ep_rank, self.ep_group, self.dp_input = ep_size, ep_rank, ep_group, dp_input
+        base, rem = divmod(num_experts, ep_size)
+        self.num_experts_local = base + 1 if ep_rank < rem else base
+        self.ep_start = base * ep_rank + min(ep_rank, rem)
+        self.ep_end = self.ep_start + self.num_experts_local
+        pick = lambda core: core.get_registry().get(self._backend)      # noqa: E731  sub-operators of the same backend
+        self.gating = pick(MojoMoEGating)(hidden_size=hidden_size, num_experts=num_experts, top_k=top_k, **kwargs)
+        self.dispatch = pick(MojoMoEDispatch)(num_experts=num_experts, **kwargs)
+        self.experts = pick(MojoExperts)(num_experts=self.num_experts_local, hidden_size=hidden_size,
+                                         intermediate_size=intermediate_size, activation=activation, **kwargs)
+        self.combine = pick(MojoMoECombine)(multiply_by_gates=True, **kwargs)
+
+    def compose_forward(self, hidden_states):
+        """The orchestration shared by every backend (no arithmetic of its own)."""
+        import torch.distributed as dist
+
+        if self.dp_input and self.ep_size > 1:
+            full = torch.empty(hidden_states.shape[0] * self.ep_size, *hidden_states.shape[1:], dtype=hidden_states.dtype,
+                               device=hidden_states.device)
+            dist.all_gather_into_tensor(full, hidden_states.contiguous(), group=self.ep_group)
+            hidden_states = full
+        top_k_indices, top_k_gates = self.gating(hidden_states)
+        rows, per_expert, gates, token_indices = self.dispatch(hidden_states, top_k_gates, top_k_indices)
+        if self.ep_size > 1:                      # keep the rows routed to this rank's experts (host sync, as the reference)
+            ends = per_expert.cumsum(0)
+            lo = 0 if self.ep_start == 0 else int(ends[self.ep_start - 1].item())
+            hi = int(ends[self.ep_end - 1].item())
+            rows, gates, token_indices = rows[lo:hi], gates[lo:hi], token_indices[lo:hi]
+            per_expert = per_expert[self.ep_start:self.ep_end]
+        expert_out = self.experts(rows, per_expert)
+        out = self.combine(torch.zeros_like(hidden_states, memory_format=torch.contiguous_format), expert_out, gates, token_indices)
+        if self.ep_size > 1:
+            if self.dp_input:
+                local = torch.empty(out.shape[0] // self.ep_size, *out.shape[1:], dtype=out.dtype, device=out.device)
+                dist.reduce_scatter_tensor(local, out.contiguous(), op=dist.ReduceOp.SUM, group=self.ep_group)
+                out = local
+            else:
+                dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.ep_group)
+        return out
+
+
+__all__ = ["MojoMoEGating", "MojoMoEDispatch", "MojoExperts", "MojoMoECombine", "MojoMoE", "count_expert_tokens"]

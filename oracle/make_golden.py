@@ -9,6 +9,7 @@ and stores ``{ctor, state, args, kwargs, out}`` per case.  It then runs this rep
 (`torch.equal`).  The fixtures are data only: tensors and scalars, no reference source.
 """
 import math
+import functools
 import os
 import sys
 
@@ -60,7 +61,7 @@ def same(a, b):
     return torch.equal(a, b)
 
 
-def run_case(op_name, ctor, state, args, kwargs, cast=None):
+def run_case(op_name, ctor, state, args, kwargs, cast=None, keep_dtype=()):
     """Run reference and restatement; return the fixture record."""
     outs = []
     for cls in (ref_cls(op_name), my_cls(op_name)):
@@ -69,12 +70,16 @@ def run_case(op_name, ctor, state, args, kwargs, cast=None):
             op = op.to(cast)
         with torch.no_grad():
             for k, v in state.items():
-                getattr(op, k).copy_(v)
+                slot = functools.reduce(getattr, k.split("."), op)
+                if k in keep_dtype:                  # e.g. the fp32 router weight inside a bf16 layer
+                    slot.data = v.clone()
+                else:
+                    slot.copy_(v)
             outs.append(op.forward(*clone(args), **clone(kwargs)))
     if not same(outs[0], outs[1]):
         raise SystemExit(f"restatement of {op_name} is NOT bit-identical to the reference for ctor={ctor}")
     return {"op": op_name, "ctor": ctor, "state": state, "args": args, "kwargs": kwargs, "cast": cast,
-            "out": outs[0]}
+            "keep_dtype": tuple(keep_dtype), "out": outs[0]}
 
 
 # --------------------------------------------------------------------------------------------
@@ -374,6 +379,27 @@ def gen_moe():
     return recs
 
 
+def gen_moe_layer():
+    """The composite MojoMoE (gating -> dispatch -> experts -> combine, `core/operators/moe.py:12-130`) set up the way the
+    reference's own test does (test_moe.py:73-103): bf16 layer, fp32 router weight, normal(0.02) parameters."""
+    recs = []
+    for experts, k, hidden, inter, tokens, std, seed in [(16, 4, 128, 64, 64, 0.2, 1380), (8, 2, 128, 64, 37, 0.2, 1381),
+                                                         (64, 8, 128, 32, 48, 0.5, 1452), (4, 1, 64, 32, 1, 0.2, 1383)]:
+        torch.manual_seed(seed)                   # seeds picked so that no routing decision sits on a near-tie
+        w = torch.randn(hidden, experts) * std
+        x = torch.rand(tokens, hidden, dtype=torch.bfloat16)
+        probs = torch.softmax(x.float() @ w, dim=-1).sort(dim=-1, descending=True).values
+        if k < experts:
+            assert float((probs[:, :k] - probs[:, 1: k + 1]).min()) > 1e-5, "near-tie in the gating vector: pick another seed"
+        state = {"gating.gate_weight": w,
+                 "experts.up_proj_weight": (torch.randn(experts, 2 * inter, hidden) * 0.02).to(torch.bfloat16),
+                 "experts.down_proj_weight": (torch.randn(experts, hidden, inter) * 0.02).to(torch.bfloat16)}
+        recs.append(run_case("MojoMoE", {"kwargs": {"num_experts": experts, "top_k": k, "hidden_size": hidden,
+                                                    "intermediate_size": inter}}, state, (x,), {}, cast=torch.bfloat16,
+                             keep_dtype=("gating.gate_weight",)))
+    return recs
+
+
 def gen_quantizers():
     """MojoDynamicQuant and MojoResidualAddRMSNormQuant on the reference's test shapes (test_quantize.py:41-50,
     test_normalization.py:442-446) plus zero rows, a non-multiple-of-8 width and the fp8 branch."""
@@ -531,23 +557,16 @@ def gen_comm():
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
-    groups = {
-        "paged_decode_gqa": gen_decode_gqa(),
-        "paged_prefill_gqa": gen_prefill_gqa(),
-        "paged_mla": gen_mla(),
-        "rmsnorm": gen_norm(),
-        "swiglu": gen_swiglu(),
-        "rope": gen_rope(),
-        "group_gemm": gen_group_gemm(),
-        "quant_gemm": gen_quant_gemm(),
-        "moe": gen_moe(),
-        "quantizers": gen_quantizers(),
-        "store_paged_mla": gen_store_mla(),
+    makers = {
+        "paged_decode_gqa": gen_decode_gqa, "paged_prefill_gqa": gen_prefill_gqa, "paged_mla": gen_mla, "rmsnorm": gen_norm,
+        "swiglu": gen_swiglu, "rope": gen_rope, "group_gemm": gen_group_gemm, "quant_gemm": gen_quant_gemm, "moe": gen_moe,
+        "moe_layer": gen_moe_layer, "quantizers": gen_quantizers, "store_paged_mla": gen_store_mla,
+        "compute_with_comm": gen_comm,
     }
-    store, plans = gen_store_kv()
-    groups["store_paged_kv"] = store
-    groups["kv_plan"] = plans
-    groups["compute_with_comm"] = gen_comm()
+    only = set(sys.argv[1:])                       # `python oracle/make_golden.py moe_layer` regenerates just that group
+    groups = {name: make() for name, make in makers.items() if not only or name in only}
+    if not only or only & {"store_paged_kv", "kv_plan"}:
+        groups["store_paged_kv"], groups["kv_plan"] = gen_store_kv()
     meta = {"torch": torch.__version__, "reference": "XPU-Forces/mojo_opset @ /root/reference (0.0.3.post27)"}
     for name, recs in groups.items():
         path = os.path.join(OUT, f"{name}.pt")

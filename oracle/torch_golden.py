@@ -29,7 +29,7 @@ __all__ = [
     "TorchRMSNorm", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
     "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
     "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
-    "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine", "TorchDynamicQuant",
+    "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine", "TorchMoE", "TorchDynamicQuant",
     "TorchResidualAddRMSNormQuant", "TorchStorePagedMLAKVCache",
     "gather_pages", "quant_gemm_formula",
 ]
@@ -554,6 +554,15 @@ class TorchMoECombine(_moe.MojoMoECombine):
         index = token_indices.to(torch.int64).unsqueeze(-1).expand(-1, output_buffer.size(1))
         acc = torch.zeros_like(output_buffer, dtype=torch.float32)
         return acc.scatter_reduce(0, index, rows, reduce="sum", include_self=True).to(expert_outputs.dtype)
+
+
+class TorchMoE(_moe.MojoMoE):
+    """`core/operators/moe.py:86-130`: the four golden stages chained (and the expert-parallel wiring)."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_states):
+        return self.compose_forward(hidden_states)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,3 +1,4 @@
+import functools
 import os
 import sys
 
@@ -59,7 +60,11 @@ def build_op(cls, case, device="cpu"):
     op = op.to(device)
     with torch.no_grad():
         for k, v in case["state"].items():
-            getattr(op, k).copy_(v.to(device))
+            slot = functools.reduce(getattr, k.split("."), op)
+            if k in case.get("keep_dtype", ()):      # e.g. the fp32 router weight inside a bf16 layer
+                slot.data = v.to(device)
+            else:
+                slot.copy_(v.to(device))
     return op
 
 

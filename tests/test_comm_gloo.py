@@ -181,3 +181,37 @@ def test_identity_without_process_group():
     for got in (comm.gemm_all_reduce(eng, x, w, None, True, None), comm.gemm_reduce_scatter(eng, x, w, None, True, None, 0),
                 comm.all_gather_gemm(eng, x, w, None, True, None, 0), comm.gemm_all2all(eng, x, w, None, True, None, 0, 1)):
         torch.testing.assert_close(got, x @ w)
+
+
+def _check_expert_parallel_moe(rank, ws, dp_input):
+    """`MojoMoE` with ep_size = world size (core/operators/moe.py:104-128): each rank holds a slice of the experts, the
+    summed partial outputs equal the single-process layer on all tokens."""
+    import mojo_opset_amd as mo
+    import oracle  # noqa: F401
+
+    cls = mo.MojoMoE.get_backend_impl("torch", strict=True)
+    experts, k, hidden, inter, tokens = 6, 2, 64, 48, 10 * ws
+    torch.manual_seed(7)
+    full = cls(num_experts=experts, top_k=k, hidden_size=hidden, intermediate_size=inter)
+    for p in full.parameters():
+        torch.nn.init.normal_(p, std=0.2)
+    x = torch.rand(tokens, hidden)
+    want = full(x)
+    part = cls(num_experts=experts, top_k=k, hidden_size=hidden, intermediate_size=inter, ep_size=ws, ep_rank=rank,
+               ep_group=dist.group.WORLD, dp_input=dp_input)
+    assert part.num_experts_local == experts // ws and part.experts.up_proj_weight.shape[0] == experts // ws
+    with torch.no_grad():
+        part.gating.gate_weight.copy_(full.gating.gate_weight)
+        part.experts.up_proj_weight.copy_(full.experts.up_proj_weight[part.ep_start:part.ep_end])
+        part.experts.down_proj_weight.copy_(full.experts.down_proj_weight[part.ep_start:part.ep_end])
+    if dp_input:
+        per = tokens // ws
+        got = part(x[rank * per:(rank + 1) * per].clone())
+        torch.testing.assert_close(got, want[rank * per:(rank + 1) * per], atol=1e-5, rtol=1e-5)
+    else:
+        torch.testing.assert_close(part(x.clone()), want, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dp_input", [False, True])
+def test_moe_expert_parallel_wiring(dp_input):
+    run_dist(_check_expert_parallel_moe, dp_input)

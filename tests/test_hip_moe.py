@@ -192,6 +192,33 @@ def test_moe_layer_end_to_end_matches_the_oracle_chain():
     check_tol_diff(to_cpu(got), want, mixed_tol=True)
 
 
+@pytest.mark.parametrize("case", [pytest.param(c, id=f"MojoMoE-{i}") for i, c in enumerate(load_golden("moe_layer"))])
+def test_moe_layer_vectors(case):
+    """The composite operator against the reference's recorded outputs (`mixed_tol`, test_moe.py:103)."""
+    out = to_cpu(run_hip_case(case))
+    assert out.dtype == case["out"].dtype and out.shape == case["out"].shape
+    check_tol_diff(out, case["out"], mixed_tol=True)
+
+
+@pytest.mark.parametrize("experts,k,hidden,inter,tokens", [(16, 4, 1024, 2048, 64), (32, 8, 1024, 4096, 128),
+                                                           (64, 8, 1024, 4096, 256), (64, 8, 1024, 4096, 1024),
+                                                           (8, 2, 4096, 1024, 1)])
+def test_moe_layer_reference_space(experts, k, hidden, inter, tokens):
+    """The reference's own `test_moe` (test_moe.py:57-103): bf16 layer, fp32 router, normal(0.02) parameters."""
+    torch.manual_seed(0)
+    kw = dict(num_experts=experts, top_k=k, hidden_size=hidden, intermediate_size=inter)
+    ref = torch_cls("MojoMoE")(**kw).to(torch.bfloat16)
+    op = hip_cls("MojoMoE")(**kw).to(torch.bfloat16).to(DEV)
+    assert type(op.gating).__name__ == "HIPMoEGating" and type(op.experts).__name__ == "HIPExperts"
+    ref.gating.gate_weight.data = ref.gating.gate_weight.data.float()
+    op.gating.gate_weight.data = op.gating.gate_weight.data.float()
+    for p in ref.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    op.load_state_dict(ref.state_dict())
+    x = torch.rand(tokens, hidden, dtype=torch.bfloat16)
+    op.forward_diff_with(ref, x.to(DEV), mixed_tol=True, ref_device="cpu")
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gating_mfma_route_agrees_with_vector_route(dtype, monkeypatch):
     """Same inputs through both routes of `mojo_hip_moe_gating`: identical expert choice (up to near-ties), gates to 1e-4."""
