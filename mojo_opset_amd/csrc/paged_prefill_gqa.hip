@@ -43,6 +43,7 @@ struct PrefillArgs {
   int hq, hkv, dim, page, page_shift, max_pages;
   float scale_log2;
   int abab;
+  int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
 };
 
 template <typename T> struct pf_mfma;
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem_generic[];
   lds_c* smem = (lds_c*)smem_generic;
 
-  const int b = blockIdx.z, kvh = blockIdx.y, qb = blockIdx.x;
+  // longest first: the last query block of a sequence sees the most keys, and workgroups are dispatched in blockIdx order
+  const int b = blockIdx.z, kvh = blockIdx.y, qb = gridDim.x - 1 - blockIdx.x;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
@@ -167,6 +169,45 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     }
   };
 
+  // Fast staging for tiles whose 64 keys all exist (every tile in front of the diagonal): with pages of >= 16 keys the 16
+  // keys a wave stages share one page, so the page id is a SCALAR load issued a whole tile ahead, the row base is scalar
+  // arithmetic and the per-lane byte offsets (key inside the 16, swizzled chunk) are loop invariants: no vector integer
+  // multiplies or LDS table reads per tile.
+  unsigned voff_k[4], voff_v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kl = wave * 16 + i * 4 + (lane >> 4);
+    const int cp = lane & 15;
+    int ck = cp ^ (kl & 15);
+    int cv = cp ^ ((kl & 7) << 1);
+    if (ck >= chunks) ck = chunks - 1;
+    if (cv >= chunks) cv = chunks - 1;
+    const unsigned rowb = static_cast<unsigned>((i * 4 + (lane >> 4)) * static_cast<int>(a.c_tok)) * sizeof(T);
+    voff_k[i] = rowb + ck * 16;
+    voff_v[i] = rowb + cv * 16;
+  }
+  auto page_of_tile = [&](int kb) -> int {               // scalar: page id of this wave's 16 keys of tile kb
+    int lp = (kb * PF_KEYS + wave * 16) >> a.page_shift;
+    lp = min(lp, a.max_pages - 1);
+    // constant address space: a plain global load next to LDS-DMA writes is never selected as s_load by hipcc
+    return ((const __attribute__((address_space(4))) int*)table)[lp];
+  };
+  auto stage_fast = [&](int kb, int buf, int phys) {
+    const int key_w = kb * PF_KEYS + wave * 16;
+    const int64_t sb = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key_w & (a.page - 1)) * a.c_tok;
+    const char* kp = reinterpret_cast<const char*>(kbase + sb);
+    const char* vp = reinterpret_cast<const char*>(vbase + sb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lds_c* dk = smem + buf * 2 * PF_TILE_BYTES + (wave * 16 + i * 4) * 256;
+      lds_c* dv = dk + PF_TILE_BYTES;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + voff_k[i]),
+                                       (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + voff_v[i]),
+                                       (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+    }
+  };
+
   // ---- state ----------------------------------------------------------------------------------------------
   f32x4 o[2][DT];
   float m[2], lsum[2];
@@ -182,14 +223,26 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   // V^T transposed-read lane offset: lane 4q+p of a 16-group -> key row (4*grp + q), 8 bytes at column 4p
   const int tq = l15 >> 2, tp = l15 & 3;
 
+  // leading key blocks that every row of this workgroup sees completely need no masking at all; the diagonal /
+  // tail / hole blocks run the masked variant.  Two loops, so neither carries the other's state.
+  const int n_full = min(min(kv_len, offset + qb * QPB + 1), first_neg_key) / PF_KEYS;
+  const int n_fast = a.fast_stage ? n_full : 0;          // tiles [0, n_fast) may be staged the fast way
+
   stage(0, 0);
+  int phys_next = a.fast_stage ? page_of_tile(1) : 0;    // page id for the NEXT stage, loaded a tile ahead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  auto key_block = [&](auto masked_tag, int kb) {
+  auto key_block = [&](auto masked_tag, auto fast_tag, int kb) {
     constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool FAST = decltype(fast_tag)::value;     // the NEXT tile is complete and staged the fast way
     const int buf = kb & 1;
-    if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
+    if constexpr (FAST) {
+      stage_fast(kb + 1, buf ^ 1, phys_next);
+      phys_next = page_of_tile(kb + 2);
+    } else {
+      if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
+    }
     const lds_c* kt = smem + buf * 2 * PF_TILE_BYTES;
     const unsigned vt = smem_u32 + buf * 2 * PF_TILE_BYTES + PF_TILE_BYTES;
 
@@ -344,12 +397,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile landed (issued a whole tile ago)
     __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
   };
-  // leading key blocks that every row of this workgroup sees completely need no masking at all; the diagonal /
-  // tail / hole blocks run the masked variant.  Two loops, so neither carries the other's state.
-  const int n_full = min(min(kv_len, offset + qb * QPB + 1), first_neg_key) / PF_KEYS;
   int kb_i = 0;
-  for (; kb_i < n_full; ++kb_i) key_block(std::false_type{}, kb_i);
-  for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, kb_i);
+  for (; kb_i + 1 < n_fast; ++kb_i) key_block(std::false_type{}, std::true_type{}, kb_i);     // the hot loop
+  for (; kb_i < n_full; ++kb_i) key_block(std::false_type{}, std::false_type{}, kb_i);
+  for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, std::false_type{}, kb_i);
 
   // ---- finish: reduce the row sums over the 4 lane groups, normalise, store ----------------------------------
 #pragma unroll
@@ -446,6 +497,8 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   a.max_pages = static_cast<int>(max_blocks_per_seq);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.abab = layout_abab ? 1 : 0;
+  const char* fs = getenv("MOJO_HIP_PREFILL_FAST_STAGE");                       // "0": general staging everywhere (tests)
+  a.fast_stage = (a.page_shift >= 4 && cache_token_stride * 16 * 2 + 256 < (int64_t{1} << 31) && !(fs && fs[0] == '0')) ? 1 : 0;
   int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
   const int G = static_cast<int>(q_heads / kv_heads);
   return dtype == MOJO_BF16 ? dispatch_g<bf16_t>(a, G, batch, max_q, s) : dispatch_g<f16_t>(a, G, batch, max_q, s);

@@ -116,3 +116,24 @@ def test_prefill_full_size_properties():
         qs = q[2048 + lo: 2048 + hi]
         want = ref(qs, k, v, cu([n]), table[1:2], cu_total_seq_lens=cu([2048 + hi]))
         assert_close_tree(to_cpu(out[2048 + lo: 2048 + hi]), want, ATOL, RTOL)
+
+
+@pytest.mark.parametrize("page,layout_nhd", [(16, False), (64, False), (128, True), (32, True)])
+def test_prefill_fast_staging_is_bit_identical_to_general_staging(page, layout_nhd, monkeypatch):
+    """Tiles in front of the diagonal are staged from a scalar page id + loop-invariant lane offsets when pages hold >= 16
+    keys; the bytes that land in LDS are the same, so the outputs must be bit-identical to the per-key staging path.
+    Ragged lengths, a cached prefix, a hole in one table, and a token-major (strided) cache view."""
+    q_lens, cached = [700, 1, 333, 1024], [900, 515, 0, 77]
+    q, k, v, cu_q, table, cu_kv, _ = make_prefill_inputs(q_lens, cached, 16, 4, 128, page, seed=23)
+    table[0, 5] = -1
+    k, v = k.to(DEV), v.to(DEV)
+    if layout_nhd:                          # [blocks, page, heads, dim] storage seen through a [blocks, heads, page, dim] view
+        k = k.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+        v = v.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    args = (q.to(DEV), k, v, cu_q.to(DEV), table.to(DEV))
+    monkeypatch.setenv("MOJO_HIP_PREFILL_FAST_STAGE", "0")
+    want = op(*args, cu_total_seq_lens=cu_kv.to(DEV))
+    monkeypatch.setenv("MOJO_HIP_PREFILL_FAST_STAGE", "1")
+    got = op(*args, cu_total_seq_lens=cu_kv.to(DEV))
+    assert torch.equal(got, want)
