@@ -140,7 +140,11 @@ def bench_prefill(device):
     out = {}
     hq, hkv, d, page = 32, 8, 128, 16
     op = hip("MojoPagedPrefillGQA")()
-    for name, (q_lens, cached) in {"4x2048_nocache": ([2048] * 4, [0] * 4), "4x2048_cached2048": ([2048] * 4, [2048] * 4)}.items():
+    g = torch.Generator().manual_seed(20260716)
+    ragged = torch.randint(512, 1025, (16,), generator=g).tolist()
+    for name, (q_lens, cached) in {"4x2048_nocache": ([2048] * 4, [0] * 4), "4x2048_cached2048": ([2048] * 4, [2048] * 4),
+                                   "16_ragged_512_1024_nocache": (ragged, [0] * 16),
+                                   "1x16384_nocache": ([16384], [0])}.items():
         kv = [a + b for a, b in zip(q_lens, cached)]
         k, v, table = _paged(device, kv, hkv, d, page)
         q = torch.randn(sum(q_lens), hq, d, device=device, dtype=torch.bfloat16)

@@ -1,7 +1,7 @@
 // MojoPagedPrefillGQA — flash attention (online softmax) over a paged KV cache on MFMA, gfx950.
 //
 // Work decomposition
-//   grid = (q blocks, Hkv, B); one 256-thread workgroup owns 128 "rows" = the G = Hq/Hkv query heads of one
+//   grid = q blocks x Hkv x B workgroups (longest first); one 256-thread workgroup owns 128 "rows" = the G = Hq/Hkv query heads of one
 //   kv-head times 128/G consecutive query positions, so every K/V tile is read once per kv-head.
 //   Each of the 4 waves owns 32 rows = two 16-row MFMA tiles.
 //   K/V advance in tiles of 64 keys, double-buffered in LDS (2 x (16 + 16) KiB), filled by direct-to-LDS
@@ -41,6 +41,7 @@ struct PrefillArgs {
   const int32_t* tables;
   int64_t table_stride, c_blk, c_head, c_tok;
   int hq, hkv, dim, page, page_shift, max_pages;
+  int batch, n_qb;           // grid = n_qb * hkv * batch workgroups (see the kernel for the order)
   float scale_log2;
   int abab;
   int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
@@ -69,8 +70,15 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem_generic[];
   lds_c* smem = (lds_c*)smem_generic;
 
-  // longest first: the last query block of a sequence sees the most keys, and workgroups are dispatched in blockIdx order
-  const int b = blockIdx.z, kvh = blockIdx.y, qb = gridDim.x - 1 - blockIdx.x;
+  // Longest first over the WHOLE grid: workgroups are dispatched in blockIdx order and a query block's key count grows
+  // with its position, so the block index is the slow coordinate, descending, and (kv-head, sequence) the fast one.
+  // A sawtooth order (one descending ramp per sequence and head) left 30-40 % of the wave slots idle behind the long
+  // blocks of the last ramp.  Consecutive ids also land on consecutive XCDs, so with 8 kv-heads each XCD's L2 holds
+  // the K/V of one head.
+  const int inner = a.hkv * a.batch;
+  const int qb = a.n_qb - 1 - static_cast<int>(blockIdx.x / inner);
+  const int rem = static_cast<int>(blockIdx.x % inner);
+  const int kvh = rem % a.hkv, b = rem / a.hkv;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
@@ -369,6 +377,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
       }
     };
+    // V^T batch 0 is requested before the softmax (its LDS latency hides behind the vector work), batch 1 before batch
+    // 0's MFMAs; every wait is lgkmcnt(0) on data that has long landed.
+    s16x4 vb0[16], vb1[16];
+    issue_v(vb0, 0);
     softmax_tile(0);
     softmax_tile(1);
 
@@ -385,15 +397,11 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
           o[1][dt0 + i] = pf_mfma<T>::run(vf, pf[1][kk], o[1][dt0 + i]);
         }
     };
-    {
-      s16x4 vb[16];                                      // reuses the registers the scores just vacated
-      issue_v(vb, 0);
-      retire_v(vb);
-      pv_batch(vb, 0);
-      issue_v(vb, DT / 2);
-      retire_v(vb);
-      pv_batch(vb, DT / 2);
-    }
+    retire_v(vb0);
+    issue_v(vb1, DT / 2);                                // into the registers the scores just vacated
+    pv_batch(vb0, 0);
+    retire_v(vb1);
+    pv_batch(vb1, DT / 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile landed (issued a whole tile ago)
     __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
   };
@@ -443,9 +451,13 @@ static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
 }
 
 template <typename T>
-static int dispatch_g(const PrefillArgs& a, int G, int64_t batch, int64_t max_q, hipStream_t s) {
+static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStream_t s) {
   const int qpb = 128 / G;
-  dim3 grid(static_cast<unsigned>(ceil_div(max_q, qpb)), static_cast<unsigned>(a.hkv), static_cast<unsigned>(batch));
+  const int64_t n_qb = ceil_div(max_q, qpb);
+  MOJO_REQUIRE(n_qb * a.hkv * batch < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
+  a.batch = static_cast<int>(batch);
+  a.n_qb = static_cast<int>(n_qb);
+  dim3 grid(static_cast<unsigned>(n_qb * a.hkv * batch));
   switch (G) {
     case 1: return dispatch_dk<T, 1>(a, grid, s);
     case 2: return dispatch_dk<T, 2>(a, grid, s);
@@ -479,7 +491,6 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   MOJO_REQUIRE(cache_token_stride % 8 == 0 && cache_head_stride % 8 == 0 && cache_block_stride % 8 == 0 &&
                    aligned_to(key_cache, 16) && aligned_to(value_cache, 16) && aligned_to(query, 16) && aligned_to(out, 8),
                MOJO_EUNSUPPORTED, "paged_prefill_gqa: tensors must be 16-byte aligned with 16-byte row strides");
-  MOJO_REQUIRE(batch <= 65535 && kv_heads <= 65535, MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
   // rows that no workgroup writes (empty sequences, padding tokens) must read as zeros
   const int64_t eb = 2;
   if (hipMemsetAsync(out, 0, static_cast<size_t>(total_tokens * q_heads * head_dim * eb), s) != hipSuccess) {
