@@ -45,6 +45,7 @@ struct PrefillArgs {
   float scale_log2;
   int abab;
   int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
+  int ablate;                // timing-only (MOJO_HIP_PREFILL_ABLATE): 1 no staging in the loop, 2 no exp, 4 no barrier/wait
 };
 
 template <typename T> struct pf_mfma;
@@ -56,6 +57,38 @@ template <> struct pf_mfma<f16_t> {
   typedef f16x8 frag;
   static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
+
+#ifdef PF_STAMPS
+// In-kernel stamps (build with MOJO_HIP_EXTRA_CXXFLAGS=-DPF_STAMPS): lane i of `tacc` accumulates the cycles between
+// stamp i-1 and stamp i of the hot loop; read back with mojo_hip_debug_prefill_stamps.  Timing tool only.
+__device__ unsigned g_pf_stamps[8192 * 4 * 16];
+#define PF_STAMP(i)                                                              \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    const unsigned long long t_ = __builtin_readcyclecounter();                  \
+    const unsigned d_ = static_cast<unsigned>(t_ - t_prev);                      \
+    t_prev = t_;                                                                 \
+    tacc += (lane == (i)) ? d_ : 0u;                                             \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#else
+#define PF_STAMP(i)
+#endif
+
+constexpr float PF_LAZY_LOG2 = 8.f;          // the reference maximum may lag the true one by this many powers of two
+
+// max over lanes l, l^16, l^32, l^48 without leaving the vector unit.  v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows
+// of the second; fed two copies of x they leave {x[l], x[l ^ 32]} resp. {x[l], x[l ^ 16]} in the pair.  asm: hipcc folds
+// max(swap(x, x)) of the builtin form to x.  The s_nop covers the VALU-write -> permlane read hazard.
+__device__ __forceinline__ float xor_max_16_32(float x) {
+  float p = x, q = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  const float h = fmaxf(p, q);
+  p = h; q = h;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  return fmaxf(p, q);
+}
 
 constexpr int PF_KEYS = 64;                  // keys per tile
 constexpr int PF_TILE_BYTES = PF_KEYS * 256; // 16 KiB per K or V tile
@@ -194,17 +227,26 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     voff_k[i] = rowb + ck * 16;
     voff_v[i] = rowb + cv * 16;
   }
+  // The page id is requested by an asm scalar load (hipcc sinks a load it can see to the point of use, i.e. behind the
+  // DMA instructions, and then waits for it in front of the MFMAs) and retired by page_ready() at the top of the next tile.
   auto page_of_tile = [&](int kb) -> int {               // scalar: page id of this wave's 16 keys of tile kb
     int lp = (kb * PF_KEYS + wave * 16) >> a.page_shift;
     lp = min(lp, a.max_pages - 1);
-    // constant address space: a plain global load next to LDS-DMA writes is never selected as s_load by hipcc
-    return ((const __attribute__((address_space(4))) int*)table)[lp];
+    const int32_t* p = table + lp;
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+    return v;
   };
-  auto stage_fast = [&](int kb, int buf, int phys) {
+  auto page_ready = [&](int& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory"); };
+  // split in two so that the scalar address arithmetic (which waits for the page id's scalar load) runs before the K
+  // fragment reads are requested and the DMA instructions behind them
+  auto stage_fast_base = [&](int kb, int phys) -> int64_t {
     const int key_w = kb * PF_KEYS + wave * 16;
-    const int64_t sb = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key_w & (a.page - 1)) * a.c_tok;
-    const char* kp = reinterpret_cast<const char*>(kbase + sb);
-    const char* vp = reinterpret_cast<const char*>(vbase + sb);
+    return (static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key_w & (a.page - 1)) * a.c_tok) * static_cast<int64_t>(sizeof(T));
+  };
+  auto stage_fast_issue = [&](int buf, int64_t sb) {
+    const char* kp = reinterpret_cast<const char*>(kbase) + sb;
+    const char* vp = reinterpret_cast<const char*>(vbase) + sb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       lds_c* dk = smem + buf * 2 * PF_TILE_BYTES + (wave * 16 + i * 4) * 256;
@@ -227,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  const float lazy_raw = PF_LAZY_LOG2 / a.scale_log2;    // the lag in raw-score units (scale > 0)
   const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
   // V^T transposed-read lane offset: lane 4q+p of a 16-group -> key row (4*grp + q), 8 bytes at column 4p
   const int tq = l15 >> 2, tp = l15 & 3;
@@ -241,32 +284,56 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+#ifdef PF_STAMPS
+  unsigned tacc = 0;
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   auto key_block = [&](auto masked_tag, auto fast_tag, int kb) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     constexpr bool FAST = decltype(fast_tag)::value;     // the NEXT tile is complete and staged the fast way
+    if constexpr (FAST) { PF_STAMP(0); }
     const int buf = kb & 1;
+    int64_t stage_base = 0;
     if constexpr (FAST) {
-      stage_fast(kb + 1, buf ^ 1, phys_next);
-      phys_next = page_of_tile(kb + 2);
-    } else {
-      if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
+      page_ready(phys_next);
+      stage_base = stage_fast_base(kb + 1, phys_next);
+      asm volatile("" : "+s"(stage_base));               // computed here, not sunk behind the reads
+      phys_next = page_of_tile(kb + 2);                  // lands long before the next tile asks for it
     }
     const lds_c* kt = smem + buf * 2 * PF_TILE_BYTES;
     const unsigned vt = smem_u32 + buf * 2 * PF_TILE_BYTES + PF_TILE_BYTES;
 
     // ---- S^T = K Q^T : 4 key tiles x 2 q tiles -------------------------------------------------------------
     f32x4 s[2][4];
+    // all K fragments of the tile are requested before the first MFMA: each feeds only two MFMAs (32 cycles), so a
+    // read issued two steps ahead (what hipcc schedules for a read-then-use loop) leaves the LDS latency exposed on
+    // every step
+    frag kf[4][DK];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int key_row = t * 16 + l15;
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         const int chunk = (ks * 4 + grp) ^ (key_row & 15);
-        const frag kf = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(kt + key_row * 256 + chunk * 16);
-        s[0][t] = pf_mfma<T>::run(kf, qf[0][ks], s[0][t]);
-        s[1][t] = pf_mfma<T>::run(kf, qf[1][ks], s[1][t]);
+        kf[t][ks] = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(kt + key_row * 256 + chunk * 16);
+      }
+    }
+    // the next tile's DMA goes out behind the reads: its issue time covers their latency
+    if constexpr (FAST) {
+      if (!(a.ablate & 1)) stage_fast_issue(buf ^ 1, stage_base);
+    } else {
+      if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FAST) { PF_STAMP(1); }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) {
+        s[0][t] = pf_mfma<T>::run(kf[t][ks], qf[0][ks], s[0][t]);
+        s[1][t] = pf_mfma<T>::run(kf[t][ks], qf[1][ks], s[1][t]);
       }
     }
     // ---- V^T fragments: transposed reads, 4 per d tile, issued in two batches of DT/2 d tiles.
@@ -334,33 +401,47 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     frag pf[2][2];                                                                   // [q tile][32-key step]
     // p = 2^(s*scale_log2 - m): the maximum is taken over the RAW scores (scale > 0) and the scale is folded into
     // one fma per element.  The masked variant (diagonal / tail / hole tiles) is a separate wave-uniform path.
+    // Lazy reference maximum: every lane takes the maximum of its own 16 scores (vector unit only); the cross-lane
+    // reduction, the new reference and the rescale of O run only when some lane's maximum exceeds the reference by more
+    // than 2^PF_LAZY_LOG2 (one wave-uniform branch on a ballot).  Any reference within that distance of the true
+    // maximum gives the same result up to rounding: the final division uses sums taken against the same reference.
+    // The reduction itself swaps lane rows in the vector unit (v_permlane32_swap / v_permlane16_swap): a ds_bpermute
+    // queues behind the V^T reads just requested and cost ~300 cycles apiece, four times per tile.
     auto softmax_tile = [&](int qt) {
       f32x4 (&sc)[4] = s[qt];
-      float mx = m[qt];                                                              // running max of raw scores
+      if constexpr (MASKED) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (MASKED) {
+          for (int r = 0; r < 4; ++r) {
             const int key = key0 + 16 * t + r;
             if (has_hole && key >= first_neg_key) sc[t][r] = 0.f;                   // zero K rows: score 0
             if (key > offset + row_pos[qt] || key >= kv_len) sc[t][r] = -INFINITY;
           }
-          mx = fmaxf(mx, sc[t][r]);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float ms = (mx == -INFINITY ? 0.f : mx) * a.scale_log2;
-      const float alpha = fast_exp2(m[qt] * a.scale_log2 - ms);
-      m[qt] = mx;
+      }
+      float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+      for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
+      if (__any(mx > m[qt] + lazy_raw)) {                                            // m = -inf: any finite score triggers
+        mx = xor_max_16_32(mx);
+        mx = fmaxf(mx, m[qt]);
+        const float ms_new = (mx == -INFINITY ? 0.f : mx) * a.scale_log2;
+        const float alpha = fast_exp2(m[qt] * a.scale_log2 - ms_new);
+        m[qt] = mx;
+        lsum[qt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+      }
+      const float ms = (m[qt] == -INFINITY ? 0.f : m[qt]) * a.scale_log2;
       float ps = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         frag f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p0 = fast_exp2(fmaf(sc[2 * kk][r], a.scale_log2, -ms));
-          float p1 = fast_exp2(fmaf(sc[2 * kk + 1][r], a.scale_log2, -ms));
+          float p0 = fmaf(sc[2 * kk][r], a.scale_log2, -ms);
+          float p1 = fmaf(sc[2 * kk + 1][r], a.scale_log2, -ms);
+          if (!(a.ablate & 2)) { p0 = fast_exp2(p0); p1 = fast_exp2(p1); }
           ps += p0 + p1;
           if constexpr (MASKED) {                                                    // zero V rows: no contribution
             if (has_hole && key0 + 32 * kk + r >= first_neg_key) p0 = 0.f;
@@ -371,18 +452,16 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         }
         pf[qt][kk] = f;
       }
-      lsum[qt] = lsum[qt] * alpha + ps;
-      if (!__all(alpha == 1.0f)) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
-      }
+      lsum[qt] += ps;
     };
     // V^T batch 0 is requested before the softmax (its LDS latency hides behind the vector work), batch 1 before batch
     // 0's MFMAs; every wait is lgkmcnt(0) on data that has long landed.
     s16x4 vb0[16], vb1[16];
+    if constexpr (FAST) { PF_STAMP(2); }
     issue_v(vb0, 0);
     softmax_tile(0);
     softmax_tile(1);
+    if constexpr (FAST) { PF_STAMP(3); }
 
     // ---- O^T += V^T P^T -------------------------------------------------------------------------------------------
     auto pv_batch = [&](const s16x4 (&src)[16], int dt0) {
@@ -399,14 +478,29 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     };
     retire_v(vb0);
     issue_v(vb1, DT / 2);                                // into the registers the scores just vacated
+    if constexpr (FAST) { PF_STAMP(4); }
     pv_batch(vb0, 0);
+    if constexpr (FAST) { PF_STAMP(5); }
     retire_v(vb1);
+    if constexpr (FAST) { PF_STAMP(6); }
     pv_batch(vb1, DT / 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile landed (issued a whole tile ago)
-    __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
+    if constexpr (FAST) { PF_STAMP(7); }
+    if (!(a.ablate & 4)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next tile landed (issued a whole tile ago)
+      if constexpr (FAST) { PF_STAMP(8); }
+      __builtin_amdgcn_s_barrier();                       // ... and everyone is done reading this one
+      if constexpr (FAST) { PF_STAMP(9); }
+    }
   };
   int kb_i = 0;
   for (; kb_i + 1 < n_fast; ++kb_i) key_block(std::false_type{}, std::true_type{}, kb_i);     // the hot loop
+  if (a.fast_stage) page_ready(phys_next);               // retire the last request before its register is reused
+#ifdef PF_STAMPS
+  if (blockIdx.x < 8192) {
+    if (lane < 15) g_pf_stamps[(blockIdx.x * 4 + wave) * 16 + lane] = tacc;
+    if (lane == 15) g_pf_stamps[(blockIdx.x * 4 + wave) * 16 + 15] = static_cast<unsigned>(kb_i);
+  }
+#endif
   for (; kb_i < n_full; ++kb_i) key_block(std::false_type{}, std::false_type{}, kb_i);
   for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, std::false_type{}, kb_i);
 
@@ -510,7 +604,16 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   a.abab = layout_abab ? 1 : 0;
   const char* fs = getenv("MOJO_HIP_PREFILL_FAST_STAGE");                       // "0": general staging everywhere (tests)
   a.fast_stage = (a.page_shift >= 4 && cache_token_stride * 16 * 2 + 256 < (int64_t{1} << 31) && !(fs && fs[0] == '0')) ? 1 : 0;
+  static const int abl = [] { const char* e = getenv("MOJO_HIP_PREFILL_ABLATE"); return e ? atoi(e) : 0; }();
+  a.ablate = abl;
   int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
   const int G = static_cast<int>(q_heads / kv_heads);
   return dtype == MOJO_BF16 ? dispatch_g<bf16_t>(a, G, batch, max_q, s) : dispatch_g<f16_t>(a, G, batch, max_q, s);
 }
+
+#ifdef PF_STAMPS
+extern "C" int mojo_hip_debug_prefill_stamps(unsigned* host_out, int64_t count) {
+  if (hipDeviceSynchronize() != hipSuccess) return MOJO_ELAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mojo::g_pf_stamps), static_cast<size_t>(count) * 4) == hipSuccess ? MOJO_OK : MOJO_ELAUNCH;
+}
+#endif
