@@ -45,7 +45,6 @@ struct PrefillArgs {
   float scale_log2;
   int abab;
   int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
-  int ablate;                // timing-only (MOJO_HIP_PREFILL_ABLATE): 1 no staging in the loop, 2 no exp, 4 no barrier/wait
 };
 
 template <typename T> struct pf_mfma;
@@ -244,18 +243,12 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     const int key_w = kb * PF_KEYS + wave * 16;
     return (static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key_w & (a.page - 1)) * a.c_tok) * static_cast<int64_t>(sizeof(T));
   };
-  auto stage_fast_issue = [&](int buf, int64_t sb) {
-    const char* kp = reinterpret_cast<const char*>(kbase) + sb;
-    const char* vp = reinterpret_cast<const char*>(vbase) + sb;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      lds_c* dk = smem + buf * 2 * PF_TILE_BYTES + (wave * 16 + i * 4) * 256;
-      lds_c* dv = dk + PF_TILE_BYTES;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + voff_k[i]),
-                                       (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + voff_v[i]),
-                                       (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
-    }
+  // piece i of the 8 DMA instructions of a tile: K (even i) or V (odd i) of the 4 keys i/2 of this wave's 16
+  auto stage_fast_piece = [&](int buf, int64_t sb, int i) {
+    const char* src = reinterpret_cast<const char*>((i & 1) ? vbase : kbase) + sb + ((i & 1) ? voff_v[i >> 1] : voff_k[i >> 1]);
+    lds_c* dst = smem + buf * 2 * PF_TILE_BYTES + (i & 1) * PF_TILE_BYTES + (wave * 16 + (i >> 1) * 4) * 256;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
 
   // ---- state ----------------------------------------------------------------------------------------------
@@ -318,12 +311,18 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         kf[t][ks] = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(kt + key_row * 256 + chunk * 16);
       }
     }
-    // the next tile's DMA goes out behind the reads: its issue time covers their latency
-    if constexpr (FAST) {
-      if (!(a.ablate & 1)) stage_fast_issue(buf ^ 1, stage_base);
-    } else {
+    // General staging goes out behind the reads (its issue time covers their latency).  Fast staging is issued one DMA
+    // instruction at a time between the softmax's vector instructions, where a piece costs a third of what it costs
+    // next to LDS reads.
+    if constexpr (!FAST) {
       if (kb + 1 < n_kb) stage(kb + 1, buf ^ 1);
     }
+    auto dma_piece = [&](int i) {
+      if constexpr (FAST) {
+        stage_fast_piece(buf ^ 1, stage_base, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FAST) { PF_STAMP(1); }
 #pragma unroll
@@ -439,9 +438,8 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         frag f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p0 = fmaf(sc[2 * kk][r], a.scale_log2, -ms);
-          float p1 = fmaf(sc[2 * kk + 1][r], a.scale_log2, -ms);
-          if (!(a.ablate & 2)) { p0 = fast_exp2(p0); p1 = fast_exp2(p1); }
+          float p0 = fast_exp2(fmaf(sc[2 * kk][r], a.scale_log2, -ms));
+          float p1 = fast_exp2(fmaf(sc[2 * kk + 1][r], a.scale_log2, -ms));
           ps += p0 + p1;
           if constexpr (MASKED) {                                                    // zero V rows: no contribution
             if (has_hole && key0 + 32 * kk + r >= first_neg_key) p0 = 0.f;
@@ -449,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
           }
           f[r] = static_cast<T>(p0);
           f[4 + r] = static_cast<T>(p1);
+          if (r & 1) dma_piece(qt * 4 + kk * 2 + (r >> 1));
         }
         pf[qt][kk] = f;
       }
@@ -485,12 +484,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     if constexpr (FAST) { PF_STAMP(6); }
     pv_batch(vb1, DT / 2);
     if constexpr (FAST) { PF_STAMP(7); }
-    if (!(a.ablate & 4)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // next tile landed (issued a whole tile ago)
-      if constexpr (FAST) { PF_STAMP(8); }
-      __builtin_amdgcn_s_barrier();                       // ... and everyone is done reading this one
-      if constexpr (FAST) { PF_STAMP(9); }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // next tile landed
+    if constexpr (FAST) { PF_STAMP(8); }
+    __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
+    if constexpr (FAST) { PF_STAMP(9); }
   };
   int kb_i = 0;
   for (; kb_i + 1 < n_fast; ++kb_i) key_block(std::false_type{}, std::true_type{}, kb_i);     // the hot loop
@@ -604,8 +601,6 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   a.abab = layout_abab ? 1 : 0;
   const char* fs = getenv("MOJO_HIP_PREFILL_FAST_STAGE");                       // "0": general staging everywhere (tests)
   a.fast_stage = (a.page_shift >= 4 && cache_token_stride * 16 * 2 + 256 < (int64_t{1} << 31) && !(fs && fs[0] == '0')) ? 1 : 0;
-  static const int abl = [] { const char* e = getenv("MOJO_HIP_PREFILL_ABLATE"); return e ? atoi(e) : 0; }();
-  a.ablate = abl;
   int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
   const int G = static_cast<int>(q_heads / kv_heads);
   return dtype == MOJO_BF16 ? dispatch_g<bf16_t>(a, G, batch, max_q, s) : dispatch_g<f16_t>(a, G, batch, max_q, s);

@@ -30,7 +30,7 @@ assert rc == 0
 a = buf.reshape(4096 * 4, 16).astype(np.float64)
 tiles = a[:, 15]
 sel = tiles > 32
-names = ["barrier->top(+scalar wait)", "K reads + DMA issue + wait", "QK mfma issue", "V0 issue + softmax", "V0 wait + V1 issue",
+names = ["barrier->top(+scalar wait)", "K reads (+ DMA issue, general staging)", "QK mfma issue", "V0 issue + softmax (+ DMA pieces)", "V0 wait + V1 issue",
          "PV0 mfma", "V1 wait", "PV1 mfma", "vmcnt(0)", "barrier"]
 per = a[sel, :10] / tiles[sel, None]
 print("waves", int(sel.sum()), "mean tiles", tiles[sel].mean())
