@@ -41,7 +41,8 @@ struct PrefillArgs {
   const int32_t* tables;
   int64_t table_stride, c_blk, c_head, c_tok;
   int hq, hkv, dim, page, page_shift, max_pages;
-  int batch, n_qb;           // grid = n_qb * hkv * batch workgroups (see the kernel for the order)
+  int batch, n_qb;           // grid = n_qb * hkv * batch workgroups (see the kernel for the order) + the zero-fill tail
+  int64_t total_tokens;
   float scale_log2;
   int abab;
   int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
@@ -90,9 +91,10 @@ __device__ __forceinline__ float xor_max_16_32(float x) {
 }
 
 constexpr int PF_KEYS = 64;                  // keys per tile
+constexpr int PF_ZERO_TOKENS = 32;           // padding tokens one trailing workgroup zeroes
 constexpr int PF_TILE_BYTES = PF_KEYS * 256; // 16 KiB per K or V tile
 constexpr int PF_TABLE = 1024;                // block-table entries cached in LDS
-constexpr int PF_LDS = 4 * PF_TILE_BYTES + PF_TABLE * 4;    // K0 V0 K1 V1 | table slice
+constexpr int PF_LDS = 4 * PF_TILE_BYTES + PF_TABLE * 4 + 16;    // K0 V0 K1 V1 | table slice | first negative page
 
 template <typename T, int G /* q heads per kv head */, int DK /* head_dim / 32 */>
 __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
@@ -108,13 +110,41 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   // blocks of the last ramp.  Consecutive ids also land on consecutive XCDs, so with 8 kv-heads each XCD's L2 holds
   // the K/V of one head.
   const int inner = a.hkv * a.batch;
+  if (static_cast<int>(blockIdx.x) >= a.n_qb * inner) {
+    // Trailing workgroups zero the padding tokens behind the last sequence (rows no sequence owns must read as zeros);
+    // they sit at the end of the grid, i.e. in the tail of the launch, and replace a memset of the whole output.
+    const int64_t t0 = max(static_cast<int64_t>(a.cu_q[a.batch]), (static_cast<int64_t>(blockIdx.x) - a.n_qb * inner) * PF_ZERO_TOKENS);
+    const int64_t t1 = min(a.total_tokens, (static_cast<int64_t>(blockIdx.x) - a.n_qb * inner + 1) * PF_ZERO_TOKENS);
+    const int64_t row_elems = static_cast<int64_t>(a.hq) * a.dim;            // dim % 8 == 0: 16-byte pieces
+    typedef typename vec_of<T, 8>::type V8;
+    V8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = static_cast<T>(0.f);
+    for (int64_t i = t0 * row_elems + threadIdx.x * 8; i < t1 * row_elems; i += 256 * 8)
+      *reinterpret_cast<V8*>(static_cast<T*>(a.out) + i) = z;
+    return;
+  }
   const int qb = a.n_qb - 1 - static_cast<int>(blockIdx.x / inner);
   const int rem = static_cast<int>(blockIdx.x % inner);
   const int kvh = rem % a.hkv, b = rem / a.hkv;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
-  if (qb * QPB >= q_len || kv_len <= 0) return;        // rows of skipped sequences stay zero (memset by the caller)
+  if (qb * QPB >= q_len) return;
+  if (kv_len <= 0) {                                     // a sequence without keys: its rows read as zeros
+    typedef typename vec_of<T, 8>::type V8;
+    V8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = static_cast<T>(0.f);
+    const int chunks8 = a.dim / 8;
+    const int n_pos = min(q_len - qb * QPB, QPB);
+    for (int i = threadIdx.x; i < n_pos * G * chunks8; i += 256) {
+      const int c = i % chunks8, g = (i / chunks8) % G, pos = qb * QPB + i / (chunks8 * G);
+      const int head = a.abab ? g * a.hkv + kvh : kvh * G + g;
+      *reinterpret_cast<V8*>(static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + pos) * a.hq + head) * a.dim + c * 8) = z;
+    }
+    return;
+  }
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
 
   const int lane = threadIdx.x & 63;
@@ -122,36 +152,13 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int grp = lane >> 4, l15 = lane & 15;
   const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
 
-  // first negative page id (golden: rows behind it read as zero K/V)
   const int pos_hi = min(q_len, (qb + 1) * QPB) - 1;    // last query position of this block
   int kv_hi = min(kv_len, offset + pos_hi + 1);          // keys [0, kv_hi) are visible to some row
   if (kv_hi < 1) kv_hi = 1;
-  int first_neg_key = 0x7fffffff;
-  {
-    int p1 = (kv_hi + a.page - 1) / a.page;
-    int fn = 0x7fffffff;
-    if (p1 > a.max_pages) { fn = a.max_pages; p1 = a.max_pages; }
-    for (int base = 0; base < p1; base += 64) {
-      const int idx = base + lane;
-      const int v = idx < p1 ? table[idx] : 0;
-      const unsigned long long neg = __ballot(v < 0);
-      if (neg) { fn = base + __builtin_ctzll(neg); break; }
-    }
-    if (fn != 0x7fffffff) first_neg_key = fn * a.page;
-  }
   const int n_kb = (kv_hi + PF_KEYS - 1) / PF_KEYS;
-  // A window of PF_TABLE page ids of this sequence lives in LDS (refilled when the key loop walks past it), so the
-  // staging code never issues a dependent global load in front of its LDS-DMA — and never a FLAT load, which hipcc
-  // emits for "LDS or global" pointer selects and guards with vmcnt(0)/lgkmcnt(0), draining the whole pipeline.
-  int* s_table = reinterpret_cast<int*>(smem_generic + 4 * PF_TILE_BYTES);
-  int win_base = 0;
-  auto fill_window = [&](int p0) {
-    for (int i = threadIdx.x; i < PF_TABLE; i += 256) s_table[i] = (p0 + i < a.max_pages) ? table[p0 + i] : -1;
-    win_base = p0;
-    __syncthreads();
-  };
-  fill_window(0);
 
+  // The prologue is a chain of dependent memory round trips (1.5-2 us each on a busy chip) in front of a workgroup that
+  // may own only a handful of tiles, so it is kept to two: {Q fragments, page-id window} together, then the first tile.
   // ---- this wave's rows: two 16-row tiles; row -> (head g, query position) -------------------------------
   int row_pos[2], row_head[2];
   const T* qptr[2];
@@ -170,6 +177,53 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int ks = 0; ks < DK; ++ks) qf[qt][ks] = *reinterpret_cast<const frag*>(qptr[qt] + ks * 32 + grp * 8);
+
+
+  // A window of PF_TABLE page ids of this sequence lives in LDS (refilled when the key loop walks past it), so the
+  // staging code never issues a dependent global load in front of its LDS-DMA — and never a FLAT load, which hipcc
+  // emits for "LDS or global" pointer selects and guards with vmcnt(0)/lgkmcnt(0), draining the whole pipeline.
+  // The same pass finds the first negative page id (golden: rows behind it read as zero K/V).
+  int* s_table = reinterpret_cast<int*>(smem_generic + 4 * PF_TILE_BYTES);
+  int win_base = 0;
+  auto fill_window = [&](int p0) {
+    for (int i = threadIdx.x; i < PF_TABLE; i += 256) s_table[i] = (p0 + i < a.max_pages) ? table[p0 + i] : -1;
+    win_base = p0;
+    __syncthreads();
+  };
+  int first_neg_key = 0x7fffffff;
+  {
+    int p1 = (kv_hi + a.page - 1) / a.page;
+    int fn = 0x7fffffff;
+    if (p1 > a.max_pages) { fn = a.max_pages; p1 = a.max_pages; }
+    int* s_fn = s_table + PF_TABLE;
+    if (threadIdx.x == 0) *s_fn = 0x7fffffff;
+    int ids[PF_TABLE / 256];
+#pragma unroll
+    for (int j = 0; j < PF_TABLE / 256; ++j) {
+      const int i = threadIdx.x + j * 256;
+      ids[j] = i < a.max_pages ? table[i] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PF_TABLE / 256; ++j) {
+      const int i = threadIdx.x + j * 256;
+      s_table[i] = ids[j];
+      if (ids[j] < 0 && i < p1) atomicMin(s_fn, i);
+    }
+    __syncthreads();
+    const int wfn = *s_fn;
+    if (wfn != 0x7fffffff) {
+      fn = wfn;
+    } else {
+      for (int base = PF_TABLE; base < p1; base += 64) {   // contexts past the first window (rare, and long enough to amortise it)
+        const int idx = base + lane;
+        const int v = idx < p1 ? table[idx] : 0;
+        const unsigned long long neg = __ballot(v < 0);
+        if (neg) { fn = base + __builtin_ctzll(neg); break; }
+      }
+    }
+    if (fn != 0x7fffffff) first_neg_key = fn * a.page;
+  }
 
   // ---- staging ------------------------------------------------------------------------------------------
   // wave w fills keys [16w, 16w+16) of a tile with 4 LDS-DMA instructions per tensor (4 keys x 256 B each);
@@ -545,10 +599,11 @@ template <typename T>
 static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStream_t s) {
   const int qpb = 128 / G;
   const int64_t n_qb = ceil_div(max_q, qpb);
-  MOJO_REQUIRE(n_qb * a.hkv * batch < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
+  const int64_t n_zero = ceil_div(a.total_tokens, static_cast<int64_t>(PF_ZERO_TOKENS));
+  MOJO_REQUIRE(n_qb * a.hkv * batch + n_zero < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
   a.batch = static_cast<int>(batch);
   a.n_qb = static_cast<int>(n_qb);
-  dim3 grid(static_cast<unsigned>(n_qb * a.hkv * batch));
+  dim3 grid(static_cast<unsigned>(n_qb * a.hkv * batch + n_zero));
   switch (G) {
     case 1: return dispatch_dk<T, 1>(a, grid, s);
     case 2: return dispatch_dk<T, 2>(a, grid, s);
@@ -580,17 +635,18 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   MOJO_REQUIRE(block_size % 4 == 0, MOJO_EUNSUPPORTED, "paged_prefill_gqa: block_size %lld must be a multiple of 4",
                (long long)block_size);
   MOJO_REQUIRE(cache_token_stride % 8 == 0 && cache_head_stride % 8 == 0 && cache_block_stride % 8 == 0 &&
-                   aligned_to(key_cache, 16) && aligned_to(value_cache, 16) && aligned_to(query, 16) && aligned_to(out, 8),
+                   aligned_to(key_cache, 16) && aligned_to(value_cache, 16) && aligned_to(query, 16) && aligned_to(out, 16),
                MOJO_EUNSUPPORTED, "paged_prefill_gqa: tensors must be 16-byte aligned with 16-byte row strides");
-  // rows that no workgroup writes (empty sequences, padding tokens) must read as zeros
-  const int64_t eb = 2;
-  if (hipMemsetAsync(out, 0, static_cast<size_t>(total_tokens * q_heads * head_dim * eb), s) != hipSuccess) {
-    set_error("paged_prefill_gqa: memset failed");
-    return MOJO_ELAUNCH;
+  if (batch == 0) {                                      // no sequences: every row is padding
+    if (hipMemsetAsync(out, 0, static_cast<size_t>(total_tokens * q_heads * head_dim * 2), s) != hipSuccess) {
+      set_error("paged_prefill_gqa: memset failed");
+      return MOJO_ELAUNCH;
+    }
+    return MOJO_OK;
   }
-  if (batch == 0) return MOJO_OK;
   PrefillArgs a;
   a.q = query; a.kc = key_cache; a.vc = value_cache; a.out = out; a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens;
+  a.total_tokens = total_tokens;
   a.tables = block_tables; a.table_stride = block_table_stride; a.c_blk = cache_block_stride;
   a.c_head = cache_head_stride; a.c_tok = cache_token_stride;
   a.hq = static_cast<int>(q_heads); a.hkv = static_cast<int>(kv_heads); a.dim = static_cast<int>(head_dim);
