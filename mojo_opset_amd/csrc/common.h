@@ -106,6 +106,20 @@ __device__ __forceinline__ float block_sum(float x, float* smem /* >= NWAVES flo
 // softmax terms that small contribute nothing, and -inf -> 0 holds for the raw instruction too)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// max over lanes l, l^16, l^32, l^48 without leaving the vector unit.  v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows
+// of the second; fed two copies of x they leave {x[l], x[l ^ 32]} resp. {x[l], x[l ^ 16]} in the pair.  asm: hipcc folds
+// max(swap(x, x)) of the builtin form to x.  The s_nop covers the VALU-write -> permlane read hazard.
+__device__ __forceinline__ float xor_max_16_32(float x) {
+  float p = x, q = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  const float h = fmaxf(p, q);
+  p = h; q = h;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  return fmaxf(p, q);
+}
+
+
 // element traits ----------------------------------------------------------------------------
 template <typename T> struct elt;
 template <> struct elt<float> {

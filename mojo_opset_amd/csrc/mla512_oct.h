@@ -11,6 +11,23 @@
 
 namespace mojo {
 
+#ifdef MLA_STAMPS
+// In-kernel stamps (build with MOJO_HIP_EXTRA_CXXFLAGS=-DMLA_STAMPS): lane i of `tacc` accumulates the cycles between stamp
+// i-1 and stamp i of the tile loop; read back with mojo_hip_debug_mla_stamps.  Timing tool only.
+__device__ unsigned g_mla_stamps[1024 * 8 * 16];
+#define MLA_STAMP(i)                                                             \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    const unsigned long long t_ = __builtin_readcyclecounter();                  \
+    const unsigned d_ = static_cast<unsigned>(t_ - t_prev);                      \
+    t_prev = t_;                                                                 \
+    tacc += (lane == (i)) ? d_ : 0u;                                             \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+#else
+#define MLA_STAMP(i)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
   typedef typename mla_mfma<T>::frag frag;
@@ -169,18 +186,24 @@ __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+#ifdef MLA_STAMPS
+  unsigned tacc = 0;
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   for (int kt = 0; kt < n_kt; ++kt) {
     const int buf = kt & 1;
     const bool prefetch = kt + 1 < n_kt;
     StagePlan sp{};
+    MLA_STAMP(0);
     if (prefetch) sp = stage_prep(kt + 1, buf ^ 1);
+    MLA_STAMP(1);
     if (prefetch && !active) {
 #pragma unroll
       for (int i = 0; i < PIECES; ++i) stage_piece(sp, i);
     }
     const unsigned vt = smem_u32 + buf * TILE;
     frag pf[2];                                          // [own / partner]
-    float alpha = 1.f;
+    float alpha = 1.f, ref_own = -INFINITY, ps = 0.f;
     if (active) {
       // ---- S^T (own 32 keys x 16 heads) = K_lat Q_lat^T: 36 fragment reads in 9 batches, one DMA piece behind each ----
       f32x4 s[2];
@@ -211,7 +234,8 @@ __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
           if (prefetch) stage_piece(sp, B);
         });
       }
-      // ---- row maxima of the own half, exchanged with the partner ----------------------------------------------------
+      MLA_STAMP(2);
+      // ---- own-half maxima and probabilities -------------------------------------------------------------------------
       const int key0 = k_begin + kt * MLA_KEYS + 32 * half + 4 * grp;
       if (k_begin + (kt + 1) * MLA_KEYS > k_end) {
 #pragma unroll
@@ -220,26 +244,22 @@ __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
           for (int r = 0; r < 4; ++r)
             if (key0 + 16 * tt + r >= k_end) s[tt][r] = -INFINITY;
       }
+      // The pair no longer agrees on a reference maximum BEFORE the exponentials (that took an LDS round trip, a workgroup
+      // barrier and a second round trip per tile): each wave takes the maximum of its own 32 keys in the vector unit
+      // (lane-row swaps, no ds_bpermute), keeps or advances its OWN reference (lazily, by > 2^8), and publishes reference
+      // and probabilities together.  Behind the one barrier both waves form the same joint reference max(own, partner's);
+      // the side whose reference was lower rescales its bf16 probabilities (a wave-uniform branch, taken on the first tile
+      // and on the rare tiles where a maximum moves).
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(max_mine), "v"(mx) : "memory");
-      __builtin_amdgcn_s_barrier();                                                        // (1) maxima visible
-      float mo;
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(mo) : "v"(max_other) : "memory");
-      mx = fmaxf(fmaxf(mx, mo), m);
-      // lazy reference maximum (see mla512_pair_kernel): both waves of a pair take the same decision
-      if (!((mx - m) * a.scale_log2 > 8.0f)) mx = m;
-      // ---- probabilities of the own half ---------------------------------------------------------------------------
+      mx = xor_max_16_32(mx);
+      ref_own = m;
+      if ((mx - m) * a.scale_log2 > 8.0f) ref_own = mx;       // m = -inf: any finite score; NaN (-inf - -inf): keep
       {
-        const float ms = (mx == -INFINITY ? 0.f : mx) * a.scale_log2;
-        alpha = fast_exp2(m * a.scale_log2 - ms);
-        m = mx;
-        float ps = 0.f;
+        const float ms = (ref_own == -INFINITY ? 0.f : ref_own) * a.scale_log2;
         frag f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -250,26 +270,44 @@ __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
           f[4 + r] = static_cast<T>(p1);
         }
         pf[0] = f;
-        lsum = lsum * alpha + ps;
       }
       {
         const u32x4 w0 = __builtin_bit_cast(u32x4, pf[0]);
-        asm volatile("ds_write_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(p_mine), "v"(w0) : "memory");
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b32 %2, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : : "v"(p_mine), "v"(w0), "v"(max_mine), "v"(ref_own) : "memory");
       }
-    } else {
-      __builtin_amdgcn_s_barrier();                                                        // (1)
+      MLA_STAMP(5);
     }
-    __builtin_amdgcn_s_barrier();                                                          // (2) probabilities visible
+    __builtin_amdgcn_s_barrier();                                                          // (2) references and probabilities visible
+    MLA_STAMP(6);
     if (active) {
       {
         u32x4 r0;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0) : "v"(p_other) : "memory");
+        float ref_oth;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(ref_oth) : "v"(p_other), "v"(max_other) : "memory");
         pf[1] = __builtin_bit_cast(frag, r0);
+        const float ref = fmaxf(ref_own, ref_oth);
+        const float f_own = ref_own == ref ? 1.f : fast_exp2((ref_own - ref) * a.scale_log2);   // -inf vs finite: 0
+        const float f_oth = ref_oth == ref ? 1.f : fast_exp2((ref_oth - ref) * a.scale_log2);
+        if (!__all(f_own == 1.f)) {
+          ps *= f_own;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[0][e] = static_cast<T>(static_cast<float>(pf[0][e]) * f_own);
+        }
+        if (!__all(f_oth == 1.f)) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[1][e] = static_cast<T>(static_cast<float>(pf[1][e]) * f_oth);
+        }
+        alpha = m == ref ? 1.f : fast_exp2((m - ref) * a.scale_log2);                            // m = -inf: 0 (O and the sum are 0)
+        m = ref;
+        lsum = lsum * alpha + ps;
       }
       if (!__all(alpha == 1.0f)) {
 #pragma unroll
         for (int dt = 0; dt < 16; ++dt) o[dt] *= alpha;
       }
+      MLA_STAMP(7);
       // ---- O^T (own 256 d) += C_kv^T P^T over all 64 keys: 8 batches of 8 transposed reads, double-buffered ----------
       // batch J = d tiles 2J, 2J+1;   regs [i*4 + which*2 + {lo,hi}], which = 0: own key half, 1: partner's
       const unsigned v_own = vt + own_off, v_oth = vt + oth_off;
@@ -307,10 +345,22 @@ __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
 #undef MLAO_ISSUE
 #undef MLAO_RETIRE
 #undef MLAO_PV
+      MLA_STAMP(8);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MLA_STAMP(9);
     __builtin_amdgcn_s_barrier();                                                          // (3) next tile staged, this one free
+    MLA_STAMP(10);
   }
+#ifdef MLA_STAMPS
+  {
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg < 1024) {
+      if (lane < 15) g_mla_stamps[(wg * 8 + wave) * 16 + lane] = tacc;
+      if (lane == 15) g_mla_stamps[(wg * 8 + wave) * 16 + 15] = static_cast<unsigned>(n_kt);
+    }
+  }
+#endif
 
   // ---- epilogue: the pair's row sums are added through the maxima slots, each wave stores its 256 d ------------------
   float lt = lsum;

@@ -505,3 +505,10 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride,
   return dtype == MOJO_BF16 ? dispatch_mla<bf16_t>(a, r, rope, s) : dispatch_mla<f16_t>(a, r, rope, s);
 }
 
+
+#ifdef MLA_STAMPS
+extern "C" int mojo_hip_debug_mla_stamps(unsigned* host_out, int64_t count) {
+  if (hipDeviceSynchronize() != hipSuccess) return MOJO_ELAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mojo::g_mla_stamps), static_cast<size_t>(count) * 4) == hipSuccess ? MOJO_OK : MOJO_ELAUNCH;
+}
+#endif

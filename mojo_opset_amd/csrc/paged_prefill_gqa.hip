@@ -77,19 +77,6 @@ __device__ unsigned g_pf_stamps[8192 * 4 * 16];
 
 constexpr float PF_LAZY_LOG2 = 8.f;          // the reference maximum may lag the true one by this many powers of two
 
-// max over lanes l, l^16, l^32, l^48 without leaving the vector unit.  v_permlane32_swap exchanges the upper half of its
-// first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows
-// of the second; fed two copies of x they leave {x[l], x[l ^ 32]} resp. {x[l], x[l ^ 16]} in the pair.  asm: hipcc folds
-// max(swap(x, x)) of the builtin form to x.  The s_nop covers the VALU-write -> permlane read hazard.
-__device__ __forceinline__ float xor_max_16_32(float x) {
-  float p = x, q = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
-  const float h = fmaxf(p, q);
-  p = h; q = h;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
-  return fmaxf(p, q);
-}
-
 constexpr int PF_KEYS = 64;                  // keys per tile
 constexpr int PF_ZERO_TOKENS = 32;           // padding tokens one trailing workgroup zeroes
 constexpr int PF_TILE_BYTES = PF_KEYS * 256; // 16 KiB per K or V tile

@@ -75,6 +75,17 @@ def test_prefill_padding_tokens_and_empty_sequences_are_zero():
     assert_close_tree(got, want, ATOL, RTOL)
 
 
+def test_prefill_sequence_without_keys_reads_zero():
+    """q_len > 0 with kv_len == 0 (golden: `continue`, rows stay zero) — the workgroups of that sequence write the zeros."""
+    q, k, v, cu_q, table, cu_kv, _ = make_prefill_inputs([37, 20], [0, 30], 8, 2, 128, 16)
+    cu_kv = torch.tensor([0, 0, 50], dtype=torch.int32)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    got = to_cpu(op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), cu_total_seq_lens=cu_kv.to(DEV)))
+    want = torch_cls("MojoPagedPrefillGQA")()(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv)
+    assert torch.count_nonzero(got[:37]) == 0 and torch.count_nonzero(want[:37]) == 0
+    assert_close_tree(got, want, ATOL, RTOL)
+
+
 def test_prefill_fp16_and_contract():
     q, k, v, cu_q, table, cu_kv, _ = make_prefill_inputs([33, 70], [12, 0], 8, 2, 64, 16, dtype=torch.float16)
     op = hip_cls("MojoPagedPrefillGQA")()
