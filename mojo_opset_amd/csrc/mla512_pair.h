@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void mla512_pair_kernel(MlaArgs a) {
     }
     const unsigned vt = smem_u32 + buf * TILE;
     frag pf[2][2];                                       // [own / partner][head tile]
-    float alpha[2] = {1.f, 1.f};
+    float alpha[2] = {1.f, 1.f}, ref_own[2] = {-INFINITY, -INFINITY}, ps[2] = {0.f, 0.f};
     if (active) {
       // ---- S^T (own 32 keys) = K_lat Q_lat^T: 36 fragment reads in 9 batches, each fragment feeds both head tiles ----
       f32x4 s[2][2];
@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256, 1) void mla512_pair_kernel(MlaArgs a) {
           for (int r = 0; r < 4; ++r)
             if (key0 + 16 * tt + r >= k_end) { s[tt][0][r] = -INFINITY; s[tt][1][r] = -INFINITY; }
       }
-      float mx[2];
+      // One exchange barrier per tile (see mla512_oct_kernel): each wave keeps its own lazy reference per head tile, taken
+      // from its own 32 keys in the vector unit, and publishes it with its probabilities; behind the barrier both waves
+      // form the same joint reference and the side that was lower rescales its bf16 probabilities.
 #pragma unroll
       for (int ht = 0; ht < 2; ++ht) {
         float v = -INFINITY;
@@ -290,56 +292,58 @@ __global__ __launch_bounds__(256, 1) void mla512_pair_kernel(MlaArgs a) {
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v = fmaxf(v, s[tt][ht][r]);
-        v = fmaxf(v, __shfl_xor(v, 16));
-        v = fmaxf(v, __shfl_xor(v, 32));
-        mx[ht] = v;
-      }
-      asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : : "v"(max_mine), "v"(mx[0]), "v"(mx[1]) : "memory");
-      __builtin_amdgcn_s_barrier();                                                        // (1) maxima visible
-      float mo0, mo1;
-      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:64\n\ts_waitcnt lgkmcnt(0)" : "=&v"(mo0), "=&v"(mo1) : "v"(max_other) : "memory");
-      mx[0] = fmaxf(fmaxf(mx[0], mo0), m[0]);
-      mx[1] = fmaxf(fmaxf(mx[1], mo1), m[1]);
-      // Lazy reference maximum: the reference only moves when the tile maximum exceeds it by more than 2^8 (the
-      // probabilities then stay below 256: harmless in bf16/fp16 P and fp32 sums, and (m, l, O) stays self-consistent).
-      // Moving it costs a pass over all 128 accumulator registers through VGPRs; with exact tracking some head of the
-      // wave moves on most tiles.  Both waves of a pair see the same maxima, so they take the same decision.
-#pragma unroll
-      for (int ht = 0; ht < 2; ++ht)
-        if (!((mx[ht] - m[ht]) * a.scale_log2 > 8.0f)) mx[ht] = m[ht];
-      // ---- probabilities of the own half ---------------------------------------------------------------------------
-#pragma unroll
-      for (int ht = 0; ht < 2; ++ht) {
-        const float ms = (mx[ht] == -INFINITY ? 0.f : mx[ht]) * a.scale_log2;
-        alpha[ht] = fast_exp2(m[ht] * a.scale_log2 - ms);
-        m[ht] = mx[ht];
-        float ps = 0.f;
+        v = xor_max_16_32(v);
+        ref_own[ht] = m[ht];
+        if ((v - m[ht]) * a.scale_log2 > 8.0f) ref_own[ht] = v;
+        const float ms = (ref_own[ht] == -INFINITY ? 0.f : ref_own[ht]) * a.scale_log2;
+        float sum = 0.f;
         frag f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p0 = fast_exp2(fmaf(s[0][ht][r], a.scale_log2, -ms));
           const float p1 = fast_exp2(fmaf(s[1][ht][r], a.scale_log2, -ms));
-          ps += p0 + p1;
+          sum += p0 + p1;
           f[r] = static_cast<T>(p0);
           f[4 + r] = static_cast<T>(p1);
         }
         pf[0][ht] = f;
-        lsum[ht] = lsum[ht] * alpha[ht] + ps;
+        ps[ht] = sum;
       }
       {
         const u32x4 w0 = __builtin_bit_cast(u32x4, pf[0][0]), w1 = __builtin_bit_cast(u32x4, pf[0][1]);
-        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : : "v"(p_mine), "v"(w0), "v"(w1) : "memory");
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:1024\n\t"
+                     "ds_write_b32 %3, %4\n\tds_write_b32 %3, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                     : : "v"(p_mine), "v"(w0), "v"(w1), "v"(max_mine), "v"(ref_own[0]), "v"(ref_own[1]) : "memory");
       }
-    } else {
-      __builtin_amdgcn_s_barrier();                                                        // (1)
     }
-    __builtin_amdgcn_s_barrier();                                                          // (2) probabilities visible
+    __builtin_amdgcn_s_barrier();                                                          // (2) references and probabilities visible
     if (active) {
       {
         u32x4 r0, r1;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r0), "=&v"(r1) : "v"(p_other) : "memory");
+        float ro[2];
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\t"
+                     "ds_read_b32 %2, %5\n\tds_read_b32 %3, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(ro[0]), "=&v"(ro[1]) : "v"(p_other), "v"(max_other) : "memory");
         pf[1][0] = __builtin_bit_cast(frag, r0);
         pf[1][1] = __builtin_bit_cast(frag, r1);
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+          const float ref = fmaxf(ref_own[ht], ro[ht]);
+          const float f_own = ref_own[ht] == ref ? 1.f : fast_exp2((ref_own[ht] - ref) * a.scale_log2);
+          const float f_oth = ro[ht] == ref ? 1.f : fast_exp2((ro[ht] - ref) * a.scale_log2);
+          if (!__all(f_own == 1.f)) {
+            ps[ht] *= f_own;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[0][ht][e] = static_cast<T>(static_cast<float>(pf[0][ht][e]) * f_own);
+          }
+          if (!__all(f_oth == 1.f)) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[1][ht][e] = static_cast<T>(static_cast<float>(pf[1][ht][e]) * f_oth);
+          }
+          alpha[ht] = m[ht] == ref ? 1.f : fast_exp2((m[ht] - ref) * a.scale_log2);
+          m[ht] = ref;
+          lsum[ht] = lsum[ht] * alpha[ht] + ps[ht];
+        }
       }
       if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
         // (fenced in groups of four fragments: left alone, the scheduler hoists all 128 accumulator reads to the top
