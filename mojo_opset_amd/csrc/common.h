@@ -81,11 +81,22 @@ __device__ __forceinline__ float row8_sum(float x) {
   return x;
 }
 
+// x[l] + x[l ^ 16], then + the same of lane l ^ 32, by lane-row swaps in the vector unit (v_permlane16_swap exchanges the
+// odd 16-lane rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first
+// with the lower half of the second; fed two copies of x they leave {x[l], x[l ^ 16]} resp. {x[l], x[l ^ 32]} in the
+// pair).  Same operands and association as the __shfl_xor form it replaces (bit-identical), without the two LDS-crossbar
+// round trips of ds_bpermute.  asm: hipcc folds op(swap(x, x)) of the builtin form to x.  s_nop: VALU write -> permlane read.
+__device__ __forceinline__ float xor_sum_16_32(float x) {
+  float p = x, q = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  const float h = p + q;
+  p = h; q = h;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  return p + q;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
-  x = row16_sum(x);
-  x += __shfl_xor(x, 16);
-  x += __shfl_xor(x, 32);
-  return x;
+  return xor_sum_16_32(row16_sum(x));
 }
 
 // block-wide sum for blockDim.x == 64 * NWAVES; result valid in every thread
