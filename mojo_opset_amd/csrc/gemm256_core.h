@@ -48,14 +48,17 @@ struct PolI8 {
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(half_of(w, ks), half_of(a, ks), c, 0, 0, 0);
   }
 };
-struct PolF8 {   // OCP e4m3, v_mfma_f32_16x16x32_fp8_fp8: 8 bytes of K per lane per instruction, bf16 MFMA rate.
-  // (The block-scaled 16x16x128 form would double the rate, but hipcc does not accumulate it in place and
-  //  the 256-VGPR budget of this tile shape spills; left for a later round.)
-  typedef uint8_t elem; typedef f32x4 acc_t; static constexpr int EB = 1, KS = 4;
-  static __device__ __forceinline__ acc_t mma(const frag32& w, const frag32& a, acc_t c, int ks) {
-    typedef long i64x4 __attribute__((ext_vector_type(4)));
-    const i64x4 wl = __builtin_bit_cast(i64x4, w), al = __builtin_bit_cast(i64x4, a);
-    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[ks], al[ks], c, 0, 0, 0);
+struct PolF8 {   // OCP e4m3 on v_mfma_f32_16x16x128_f8f6f4 (the CDNA4 form: a whole 128-byte K-tile per instruction, 2x the bf16 rate)
+  // A lane's 32 bytes are the four 8-byte pieces the K=32 form took one per instruction; the K=128 form sums over all of
+  // them, and since the activation and the weight fragment are cut from their rows the same way, every product pairs the
+  // same k on both sides (the order inside the sum is free).  asm with the accumulator as "+v": through the builtin
+  // (mfma_scale with zero scales, which the backend turns into this instruction) hipcc does not accumulate in place and
+  // the 128 accumulator registers of this tile shape spill.  s_nop 1: a fragment register freshly written by the vector
+  // unit (the [K,N] path assembles its fragments) must not be read by an MFMA in the next two states.
+  typedef uint8_t elem; typedef f32x4 acc_t; static constexpr int EB = 1, KS = 1;
+  static __device__ __forceinline__ acc_t mma(const frag32& w, const frag32& a, acc_t c, int) {
+    asm("s_nop 1\n\tv_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(a));
+    return c;
   }
 };
 
@@ -409,7 +412,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   }
   if (t < nkt) ktile(t, 0);
   if (wm == 0) __builtin_amdgcn_s_barrier();            // pair the stagger barrier
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (the nops: an MFMA issued from asm is not padded by hipcc in front of the first vector read of its result)
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
   // ---- epilogue ---------------------------------------------------------------------------------------
   if (a.splitk > 1) {                                  // raw accumulators of this K slice -> slab[kslice][m][n]

@@ -1,9 +1,8 @@
-cd /root/repo; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_hip_quant_gemm.py -x -q -m gpu > gpurun_out/t.log 2>&1; grep -E "passed|failed|Error|^E " gpurun_out/t.log | head
+export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests/test_hip_quant_gemm.py -m gpu -q -x 2>&1 | tail -3 || exit 1
 python - <<'PY'
-import json, torch, sys
+import sys, torch
 sys.path.insert(0, '.')
 from benchmarks.extras import bench_quant_gemm
-r = bench_quant_gemm(torch.device('cuda', 0))
-for k, v in r.items(): print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()})
+for k, v in bench_quant_gemm(torch.device("cuda", 0)).items(): print(k, {a: round(b, 3) for a, b in v.items()})
 PY
