@@ -179,6 +179,30 @@ def bench_mla_decode(device):
     return {"B64_H128_ctx4096_page16": res}
 
 
+def bench_mla_prefill(device):
+    """MojoPagedPrefillMLA, DeepSeek-V3 dims: 4 sequences x 512 new tokens, with and without 2048 cached tokens."""
+    h, nope, rope, vd, r, page = 128, 128, 64, 128, 512, 16
+    op = hip("MojoPagedPrefillMLA")(h, nope, rope, vd, r).to(torch.bfloat16).to(device)
+    with torch.no_grad():
+        op.kv_b_proj.copy_(torch.randn_like(op.kv_b_proj) * 0.02)
+    out = {}
+    for name, (q_lens, cached) in {"4x512_nocache": ([512] * 4, [0] * 4), "4x512_cached2048": ([512] * 4, [2048] * 4)}.items():
+        kv = [a + b for a, b in zip(q_lens, cached)]
+        need = [(n + page - 1) // page for n in kv]
+        total = sum(need) + 4
+        ckv = torch.randn(total, 1, page, r, device=device, dtype=torch.bfloat16)
+        kpe = torch.randn(total, 1, page, rope, device=device, dtype=torch.bfloat16)
+        table = torch.randperm(total, dtype=torch.int32)[: sum(need)].view(len(kv), need[0]).to(device)
+        cu = lambda l: torch.tensor([0] + torch.tensor(l).cumsum(0).tolist(), dtype=torch.int32, device=device)  # noqa: E731
+        cu_q, cu_kv = cu(q_lens), cu(kv)
+        q = torch.randn(sum(q_lens), h, nope + rope, device=device, dtype=torch.bfloat16)
+        t = _time(lambda: op(q, ckv, kpe, cu_q, table, cu_total_seq_lens=cu_kv), 5, 1)
+        vis = sum(a * b - a * (a - 1) / 2.0 for a, b in zip(q_lens, kv))          # visible (query, key) pairs
+        flops = 2.0 * h * vis * (2 * r + rope) + 2.0 * sum(q_lens) * h * r * (nope + vd)
+        out[name] = _mfma(t, flops)
+    return out
+
+
 def bench_streaming(device):
     out = {}
     rows, d = 2048, 4096
@@ -231,6 +255,20 @@ def bench_streaming(device):
     cu = torch.arange(0, 8192 + 1, 2048, dtype=torch.int32, device=device)
     ctx4 = torch.zeros(4, dtype=torch.int32, device=device)
     out["store_paged_kv_prefill_8192x8x128"] = _hbm(_time(lambda: store(ks, vs, kc, vc, table[:4], cu, ctx4), 50, 5), 4 * 8192 * hkv * dd * 2)
+    del kc, vc, ks, vs
+    # MLA latent-cache store (DeepSeek-V3: 512 + 64 per token), prefill of 4 x 2048 tokens
+    r_, rope_, page = 512, 64, 16
+    pages = 4 * (2048 // page)
+    ckv_c = torch.zeros(pages + 4, 1, page, r_, device=device, dtype=torch.bfloat16)
+    kpe_c = torch.zeros(pages + 4, 1, page, rope_, device=device, dtype=torch.bfloat16)
+    tbl = torch.randperm(pages, dtype=torch.int32).view(4, pages // 4).to(device)
+    ckv_n, kpe_n = torch.randn(8192, r_, device=device, dtype=torch.bfloat16), torch.randn(8192, rope_, device=device, dtype=torch.bfloat16)
+    smla = hip("MojoStorePagedMLAKVCache")()
+    out["store_paged_mla_kv_prefill_8192x576"] = _hbm(_time(lambda: smla(ckv_n, kpe_n, ckv_c, kpe_c, tbl, cu, ctx4), 50, 5), 2 * 8192 * (r_ + rope_) * 2)
+    # RotaryEmbedding: cached cos/sin gather for 8192 packed tokens (4 x 2048), rope_dim 128 -> two fp32 [8192, 128] outputs
+    rot = hip("MojoRotaryEmbedding")(10000.0, 128, init_max_length=32768, device=device)
+    xq = torch.empty(8192, 4096, device=device, dtype=torch.bfloat16)
+    out["rotary_embedding_cached_8192x128"] = _hbm(_time(lambda: rot(xq, cu_q_lens=cu, total_seq_lens=None), 50, 5), 2 * 2 * 8192 * 128 * 4)
     return out
 
 
@@ -356,6 +394,7 @@ def run_extras(device, world, rank=0):
     out = {}
     for name, fn in (("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
+                     ("MojoPagedPrefillMLA_bf16", bench_mla_prefill),
                      ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),
                      ("dense_gemm_decode_bf16", bench_dense_decode)):
         try:
