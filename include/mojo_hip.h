@@ -140,6 +140,16 @@ int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const 
                         int64_t num_groups, int trans_weight, int dtype, void* workspace,
                         int64_t workspace_bytes, mojo_stream_t stream);
 
+/*      MojoExperts' first projection with the SwiGLU fused into the epilogue (mojo_opset/core/operators/moe.py:402-449:
+ *      GroupGemm -> SwiGLU -> GroupGemm): weight [G, 2*inter, K] (trans_weight) or [G, K, 2*inter], columns [gate | up];
+ *      out [m_total, inter] = round(round(silu(round(gate))) * round(up)) — the roundings of the two-op golden path — so
+ *      the [m_total, 2*inter] product never goes to HBM.  bf16 / fp16, inter % 128 == 0 and the 256x256 MFMA kernel's
+ *      layout preconditions; MOJO_EUNSUPPORTED otherwise (callers fall back to group_gemm + swiglu_rows).               */
+int mojo_hip_group_gemm_swiglu(const void* input, const void* weight, void* out, const void* group_list,
+                               int group_list_is_i64, int64_t m_total, int64_t k, int64_t inter,
+                               int64_t num_groups, int trans_weight, int dtype, void* workspace,
+                               int64_t workspace_bytes, mojo_stream_t stream);
+
 /*      Same kernel with explicit strides (elements): input row stride lda, output row stride ldc, weight
  *      element (g,k,n) at weight + g*w_group_stride + k*w_k_stride + n*w_n_stride, and optional row maps
  *      {rc, ml, off, mul} (NULL = identity): logical row m reads input row (m/rc)*ml + off + (m%rc)*mul and

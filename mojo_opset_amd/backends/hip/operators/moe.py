@@ -1,5 +1,7 @@
 """HIP<Op> classes of the MoE routing ops: gating, dispatch, experts, combine.
 No host synchronisation anywhere: token counts stay on the device and feed the grouped GEMM as they are."""
+import os
+
 import torch
 
 from ....core.operators.moe import MojoExperts, MojoMoE, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
@@ -101,6 +103,22 @@ class HIPExperts(MojoExperts):
                                         L.dtype_code(x.dtype), L.ptr(ws), ws.numel(), L.stream_of(x)), "HIPExperts gemm")
         return out
 
+    def _fused_up_swiglu(self, x, w, counts, act, inter) -> bool:
+        """First projection with the SwiGLU applied to the accumulators (same rounding points as the two-kernel path: the
+        [M, 2I] product never goes to HBM).  False when the shape is outside the fused kernel's preconditions."""
+        if os.environ.get("MOJO_HIP_EXPERTS_FUSED", "1") == "0" or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[0] == 0:
+            return False
+        lib = L.load()
+        groups = w.shape[0]
+        ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(groups), dtype=torch.uint8, device=x.device)
+        rc = lib.mojo_hip_group_gemm_swiglu(L.ptr(x), L.ptr(w), L.ptr(act), L.ptr(counts),
+                                            1 if counts.dtype == torch.int64 else 0, x.shape[0], x.shape[1], inter, groups, 1,
+                                            L.dtype_code(x.dtype), L.ptr(ws), ws.numel(), L.stream_of(x))
+        if rc == L.MOJO_EUNSUPPORTED:
+            return False
+        L.check(rc, "HIPExperts fused gemm + swiglu")
+        return True
+
     def forward(self, sorted_hidden_states: torch.Tensor, tokens_per_expert: torch.Tensor) -> torch.Tensor:
         up_w, down_w = self.up_proj_weight.detach(), self.down_proj_weight.detach()
         L.require_cuda(sorted_hidden_states, up_w, down_w)
@@ -112,8 +130,10 @@ class HIPExperts(MojoExperts):
         counts = _dense(tokens_per_expert.to(x.device, non_blocking=True))
         assert counts.numel() == up_w.shape[0]
         inter = down_w.shape[2]
-        fc1 = self._group_gemm(x, _dense(up_w), counts)                               # [M, 2I] = [gate | up]
         act = torch.empty(x.shape[0], inter, dtype=x.dtype, device=x.device)
+        if self._fused_up_swiglu(x, _dense(up_w), counts, act, inter):                # SwiGLU in the GEMM epilogue
+            return self._group_gemm(act, _dense(down_w), counts)
+        fc1 = self._group_gemm(x, _dense(up_w), counts)                               # [M, 2I] = [gate | up]
         L.check(L.load().mojo_hip_swiglu_rows(L.ptr(fc1), L.c_void_p(fc1.data_ptr() + inter * fc1.element_size()),
                                               L.ptr(act), x.shape[0], inter, 2 * inter, 2 * inter, inter,
                                               L.dtype_code(x.dtype), 0.0, L.stream_of(x)), "HIPExperts swiglu")

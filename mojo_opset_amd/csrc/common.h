@@ -117,6 +117,13 @@ __device__ __forceinline__ float block_sum(float x, float* smem /* >= NWAVES flo
 // softmax terms that small contribute nothing, and -inf -> 0 holds for the raw instruction too)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// x * 1/(1 + 2^(-x*log2 e)): v_mul, v_exp, v_add, v_rcp, v_mul.  The library expf() and the IEEE division expand to
+// ~25 VALU instructions per element, which made the 16-bit kernels VALU-bound (4.4 of 6.3 TB/s); the hardware
+// exp/rcp are accurate to ~1 ulp of fp32, far inside one unit of the 16-bit output's last place.
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
 // max over lanes l, l^16, l^32, l^48 without leaving the vector unit.  v_permlane32_swap exchanges the upper half of its
 // first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows
 // of the second; fed two copies of x they leave {x[l], x[l ^ 32]} resp. {x[l], x[l ^ 16]} in the pair.  asm: hipcc folds

@@ -30,6 +30,10 @@ struct GemmArgs {
   // Optional split-K (dense problems with few output tiles, e.g. decode-sized M): the K range is cut into `splitk`
   // slices, slice s writes its raw fp32 / int32 accumulators to slab[s][M][N]; a finalize kernel sums the slices
   // in a fixed order (deterministic) and applies the epilogue.
+  // Fused SwiGLU (MojoExperts' first projection): W has N = 2*I columns [gate | up]; an output tile pairs gate columns
+  // n .. n+127 with up columns I+n .. I+n+127 and stores round(round(silu(round(gate))) * round(up)) to C [M, I] — the
+  // golden's rounding points — instead of the [M, 2I] product.  256x256 MFMA kernel only, I % 128 == 0, no split-K.
+  int glu = 0;
   int ablate = 0;            // timing-only: 1 = skip the C stores (MOJO_HIP_GEMM_ABLATE)
   int splitk = 1;
   void* slab = nullptr;
@@ -69,6 +73,7 @@ int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, i
 
 // fast MFMA path (256x256x64 tiles); returns MOJO_EUNSUPPORTED when its preconditions do not hold
 int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
+bool gemm_mfma256_glu_ok(const GemmArgs& a, int dtype);
 bool gemm_skinny_ok(const GemmArgs& a, int dtype);
 int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups);
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s);

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   lds_char* smem = (lds_char*)smem_generic;
 
   // ---- which tile ------------------------------------------------------------------------------------
-  const int n_tiles = (a.N + BN - 1) / BN;
+  // glu: a tile is 128 gate columns + the 128 up columns that pair with them (W half-tile 1 starts N/2 columns further)
+  const int n_tiles = a.glu ? (a.N / 2) / 128 : (a.N + BN - 1) / BN;
   const int m_tiles = gemm_m_tiles(a, BM);
   const int tiles_mn = m_tiles * n_tiles;
   const int total = tiles_mn * a.splitk;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   }
   int g, m0, m_end;                                  // m_end exclusive; m0 < m_end by construction
   gemm_locate_tile(a, mi, BM, g, m0, m_end);
-  const int n0 = ni * BN;
+  const int n0 = a.glu ? ni * 128 : ni * BN;
+  const int hoff = a.glu ? a.N / 2 : 128;              // column distance between the two W half-tiles
   const int nkt_all = a.K / BK;
   const int kt0 = static_cast<int>(static_cast<int64_t>(nkt_all) * kslice / a.splitk);
   const int nkt = static_cast<int>(static_cast<int64_t>(nkt_all) * (kslice + 1) / a.splitk) - kt0;   // K-tiles of this slice
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int n = n0 + h * 128 + wave * 16 + row;
+      int n = n0 + h * hoff + wave * 16 + row;
       if (n >= a.N) n = a.N - 1;
       srcW[h] = W + (static_cast<int64_t>(n) * a.w_n) * EB + chunk * 16;
     }
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     const int rr = ((lane & 15) >> 1) ^ ((wave & 1) ? 4 : 0);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int n = n0 + h * 128 + (lane >> 4) * 16 + (lane & 1) * 8;
+      const int n = n0 + h * hoff + (lane >> 4) * 16 + (lane & 1) * 8;
       const int n_a = n > a.N - 8 ? a.N - 8 : n;                     // partial n-tile: stay inside the row
       const int n_b = n + 64 > a.N - 8 ? a.N - 8 : n + 64;
       srcW[h] = W + (static_cast<int64_t>(wave * 8 + rr) * a.w_k + n_a) * 2;
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     const int nb = (lane >> 3) ^ (wave & 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int n = n0 + h * 128 + nb * 16;
+      int n = n0 + h * hoff + nb * 16;
       if (n > a.N - 16) n = a.N - 16;
       srcW[h] = W + static_cast<int64_t>(wave * 16 + rr) * a.w_k + n;
       w2_off[h] = static_cast<int>(8 * a.w_k);                      // k-block 2w+1: eight rows further down
@@ -430,6 +432,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     }
     return;
   }
+  if constexpr (EB == 2 && std::is_same<acc_t, f32x4>::value) {
+    if (a.glu) {                                       // accumulator tiles nt and nt + 2 hold gate and up of the same columns
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
+        if (m >= m_end) continue;
+        const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int n = n0 + wn * 32 + nt * 16 + (lane >> 4) * 4;
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gf = elt<E>::to_f(elt<E>::from_f(acc[mt][nt][e]));
+            const float uf = elt<E>::to_f(elt<E>::from_f(acc[mt][nt + 2][e]));
+            o[e] = elt<E>::to_f(elt<E>::from_f(silu_f(gf))) * uf;
+          }
+          epi.store(mc, n, a.N / 2, o);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
@@ -464,7 +489,7 @@ inline bool gemm256_layout_ok(const GemmArgs& a, int eb) {
 
 template <typename P, typename Epi>
 inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
-  const int64_t n_tiles = ceil_div(a.N, BN);
+  const int64_t n_tiles = a.glu ? (a.N / 2) / 128 : ceil_div(a.N, BN);
   const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles * a.splitk;   // upper bound; surplus blocks exit
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
   if (a.w_n == 1) {

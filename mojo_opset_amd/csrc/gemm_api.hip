@@ -68,6 +68,34 @@ extern "C" int mojo_hip_group_gemm(const void* input, const void* weight, void* 
                                      workspace, workspace_bytes, stream);
 }
 
+extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight, void* out, const void* group_list,
+                                          int group_list_is_i64, int64_t m_total, int64_t k, int64_t inter,
+                                          int64_t num_groups, int trans_weight, int dtype, void* workspace,
+                                          int64_t workspace_bytes, mojo_stream_t stream) {
+  MOJO_REQUIRE(num_groups > 0 && k > 0 && inter > 0 && m_total >= 0, MOJO_EINVAL, "group_gemm_swiglu: bad shape");
+  if (m_total == 0) return MOJO_OK;
+  MOJO_REQUIRE(input && weight && out && group_list, MOJO_EINVAL, "group_gemm_swiglu: null pointer");
+  MOJO_REQUIRE(dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED, "group_gemm_swiglu: dtype %d (bf16 / fp16 only)", dtype);
+  MOJO_REQUIRE(m_total < (1LL << 31) && k < (1LL << 31) && inter < (1LL << 30) && num_groups < (1 << 20), MOJO_EUNSUPPORTED,
+               "group_gemm_swiglu: dimension too large");
+  MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_group_gemm_workspace_bytes(num_groups) && aligned_to(workspace, 4),
+               MOJO_EWORKSPACE, "group_gemm_swiglu: workspace too small");
+  const int64_t n = 2 * inter;
+  GemmArgs a;
+  a.A = input; a.W = weight; a.C = out; a.bias = nullptr;
+  a.lda = k; a.ldc = inter; a.w_group = k * n; a.w_k = trans_weight ? 1 : n; a.w_n = trans_weight ? k : 1;
+  a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = static_cast<int>(num_groups);
+  a.glu = 1;
+  MOJO_REQUIRE(gemm_mfma256_glu_ok(a, dtype), MOJO_EUNSUPPORTED,
+               "group_gemm_swiglu: needs the 256x256 MFMA kernel's layout and an intermediate size that is a multiple of 128");
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  a.row_start = ws; a.tile_start = ws + (num_groups + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, 256, m_total, ws, ws + (num_groups + 1), s);
+  if (rc) return rc;
+  return launch_gemm_mfma256(a, dtype, m_total, s);
+}
+
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   const int sk = gemm_skinny_splitk(m, k, n, 1);
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);

@@ -30,8 +30,13 @@ bool gemm_mfma256_ok(const GemmArgs& a, int dtype) {
   return g256::gemm256_layout_ok(a, 2);
 }
 
+bool gemm_mfma256_glu_ok(const GemmArgs& a, int dtype) {
+  return gemm_mfma256_ok(a, dtype) && a.N % 256 == 0 && a.splitk == 1 && a.bias == nullptr;
+}
+
 int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
   MOJO_REQUIRE(gemm_mfma256_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: preconditions not met");
+  MOJO_REQUIRE(!a.glu || gemm_mfma256_glu_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: fused SwiGLU needs I %% 128 == 0");
   if (dtype == MOJO_BF16) {
     g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias)};
     return g256::gemm256_launch<g256::PolBF16>(a, epi, m_total, s);

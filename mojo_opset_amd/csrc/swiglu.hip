@@ -7,13 +7,6 @@
 
 namespace mojo {
 
-// x * 1/(1 + 2^(-x*log2 e)): v_mul, v_exp, v_add, v_rcp, v_mul.  The library expf() and the IEEE division expand to
-// ~25 VALU instructions per element, which made the 16-bit kernels VALU-bound (4.4 of 6.3 TB/s); the hardware
-// exp/rcp are accurate to ~1 ulp of fp32, far inside one unit of the 16-bit output's last place.
-__device__ __forceinline__ float silu_f(float x) {
-  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-}
-
 template <typename T, int VEC>
 __device__ __forceinline__ typename vec_of<T, VEC>::type swiglu_vec(const typename vec_of<T, VEC>::type& g,
                                                                    const typename vec_of<T, VEC>::type& u, float limit) {

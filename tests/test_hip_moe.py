@@ -165,6 +165,27 @@ def test_experts_reference_space(experts, hidden, inter, counts):
     op.forward_diff_with(ref, x.to(DEV), cnt.to(DEV), mixed_tol=True, ref_device="cpu")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("experts,hidden,inter,counts", [
+    (4, 256, 512, [3, 0, 5, 4]), (8, 1024, 2048, [300, 17, 0, 512, 256, 1, 90, 64]), (3, 512, 1280, [700, 0, 33]),
+])
+def test_experts_fused_swiglu_epilogue_is_bit_identical_to_the_two_kernel_path(experts, hidden, inter, counts, dtype, monkeypatch):
+    """The first projection applies SwiGLU to its accumulators (mojo_hip_group_gemm_swiglu) with the rounding points of
+    GroupGemm -> SwiGLU; MOJO_HIP_EXPERTS_FUSED=0 runs the two kernels.  Same bits, and the fused entry point really ran."""
+    torch.manual_seed(1)
+    op = hip_cls("MojoExperts")(num_experts=experts, hidden_size=hidden, intermediate_size=inter).to(dtype).to(DEV)
+    for p in op.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    x = torch.randn(sum(counts), hidden, dtype=dtype, device=DEV)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    act = torch.empty(x.shape[0], inter, dtype=dtype, device=DEV)
+    assert op._fused_up_swiglu(x, op.up_proj_weight.detach(), cnt, act, inter)
+    fused = op(x, cnt)
+    monkeypatch.setenv("MOJO_HIP_EXPERTS_FUSED", "0")
+    plain = op(x, cnt)
+    assert torch.equal(fused, plain)
+
+
 def test_moe_layer_end_to_end_matches_the_oracle_chain():
     """gating -> dispatch -> experts -> combine on the device against the same chain of oracle classes on the CPU
     (the composition `MojoMoE.forward` performs, core/operators/moe.py:86-130, ep_size = 1)."""
