@@ -69,9 +69,17 @@ def _hbm(t, nbytes):
     return {"us": t * 1e6, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
 
 
-def group_gemm_case(device, m, k, n, groups, trans, split="balanced", dtype=torch.bfloat16):
-    x = torch.randn(m, k, device=device, dtype=dtype)
-    w = torch.randn(groups, n, k, device=device, dtype=dtype) if trans else torch.randn(groups, k, n, device=device, dtype=dtype)
+def group_gemm_case(device, m, k, n, groups, trans, split="balanced", dtype=torch.bfloat16, data="randn"):
+    """data: "randn" (the figure to quote), "zeros" (same instruction stream, least switching power: shows how much of
+    the gap to the MFMA peak is the clock the chip holds under load), or "torch" (torch.matmul = hipBLASLt per group,
+    a calibration point for what a tuned library GEMM reaches on this chip — not a product path)."""
+    make = torch.zeros if data == "zeros" else torch.randn
+    x = make(m, k, device=device, dtype=dtype)
+    w = make(groups, n, k, device=device, dtype=dtype) if trans else make(groups, k, n, device=device, dtype=dtype)
+    if data == "torch":
+        per = m // groups
+        wt = w.transpose(1, 2) if trans else w
+        return _mfma(_time(lambda: [torch.matmul(x[g * per:(g + 1) * per], wt[g]) for g in range(groups)]), 2.0 * m * k * n)
     if split == "balanced":
         counts = torch.full((groups,), m // groups, dtype=torch.int32)
     else:  # one expert takes half of the rows

@@ -20,7 +20,8 @@ if __name__ == "__main__":
     ap.add_argument("--groups", type=int, default=8)
     ap.add_argument("--trans", action="store_true")
     ap.add_argument("--split", default="balanced")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "torch"])
     ns = ap.parse_args()
-    r = group_gemm_case(torch.device("cuda", 0), ns.m, ns.k, ns.n, ns.groups, ns.trans, ns.split)
+    r = group_gemm_case(torch.device("cuda", 0), ns.m, ns.k, ns.n, ns.groups, ns.trans, ns.split, data=ns.data)
     r["config"] = vars(ns)
     print(json.dumps(r))
