@@ -145,6 +145,37 @@ def _paged(device, lens, hkv, d, page, dtype=torch.bfloat16):
     return k, v, table.to(device)
 
 
+def bench_decode_variants(device):
+    """MojoPagedDecodeGQA at the other context lengths of SURVEY §8(d) config 2 (the headline is uniform ctx = 4096):
+    uniform 1024 / 16384 and ragged randint(ctx/2, ctx), seed 20260716; random page permutation, -1 padded tables."""
+    hq, hkv, d, page, bsz = 32, 8, 128, 16, 64
+    op = hip("MojoPagedDecodeGQA")(is_causal=True, gqa_layout="AABB")
+    g = torch.Generator().manual_seed(20260716)
+    out = {}
+    for name, lens in {"uniform_ctx1024": [1024] * bsz, "uniform_ctx16384": [16384] * bsz,
+                       "ragged_ctx2048_4096": torch.randint(2048, 4097, (bsz,), generator=g).tolist(),
+                       "ragged_ctx8192_16384": torch.randint(8192, 16385, (bsz,), generator=g).tolist()}.items():
+        sets = []
+        for _ in range(2 if max(lens) <= 4096 else 1):                      # 2 x >= 256 MB defeats the MALL at the short contexts
+            k, v, table = _paged(device, lens, hkv, d, page)
+            q = torch.randn(bsz, hq, d, device=device, dtype=torch.bfloat16)
+            sets.append((q, k, v, torch.tensor(lens, dtype=torch.int32, device=device), table))
+        it = [0]
+
+        def step():
+            q, k, v, ln, tb = sets[it[0] % len(sets)]
+            it[0] += 1
+            return op(q, k, v, ln, tb, max_total_seq_len=max(lens))
+        t = _time(step, 60, 40)                                             # long warm-up: the first ~50 launches run through the clock transient
+        nbytes = sum(lens) * hkv * d * 2 * 2 + 2 * bsz * hq * d * 2 + 4 * bsz * (sets[0][4].shape[1] + 1)
+        res = _hbm(t, nbytes)
+        res["tokens_per_s"] = bsz / t
+        out[name] = res
+        del sets
+        torch.cuda.empty_cache()
+    return out
+
+
 def bench_prefill(device):
     out = {}
     hq, hkv, d, page = 32, 8, 128, 16
@@ -400,7 +431,7 @@ def bench_dense_decode(device):
 
 def run_extras(device, world, rank=0):
     out = {}
-    for name, fn in (("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
+    for name, fn in (("MojoPagedDecodeGQA_bf16_other_contexts", bench_decode_variants), ("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
                      ("MojoPagedPrefillMLA_bf16", bench_mla_prefill),
                      ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),
