@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void quant_finalize_kernel(const ACC* __restri
 //   * grid = (N/64) x splitk with ~256 workgroups (each keeps 48 KiB of weights in flight); split-K slices write raw
 //     accumulators to their own slab, summed in slice order by quant_finalize_kernel (deterministic).
 // Algorithmic bytes: K*N (+ M*K + 4*M*N*splitk*2 of slab traffic when split).
-template <typename TO, bool FP8, int MT>
+template <typename TO, bool FP8, int MT, bool NT /* weights read once: non-temporal loads */>
 __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                            const float* __restrict__ rs, const bf16_t* __restrict__ cs,
                                                            TO* __restrict__ C, void* __restrict__ slab, int M, int K, int N,
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   const int l15 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64 + wave * 16;
   const int slice = blockIdx.y;
+  const int m0 = blockIdx.z * (MT * 16);                     // row block (grid.z > 1: more than MT * 16 rows)
   const int nkb = K / 256;
   const int kb0 = static_cast<int>(static_cast<int64_t>(nkb) * slice / splitk);
   const int kb1 = static_cast<int>(static_cast<int64_t>(nkb) * (slice + 1) / splitk);
@@ -112,7 +113,10 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   auto load_w = [&](int i, u32x4 (&wr)[4]) {
     const uint8_t* wp = wrow + static_cast<int64_t>(block_at(i)) * 256;
 #pragma unroll
-    for (int sx = 0; sx < 4; ++sx) wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + static_cast<int64_t>(sx) * 4 * K));
+    for (int sx = 0; sx < 4; ++sx) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(wp + static_cast<int64_t>(sx) * 4 * K);
+      if constexpr (NT) wr[sx] = __builtin_nontemporal_load(src); else wr[sx] = *src;
+    }
   };
   auto store_w = [&](int buf, const u32x4 (&wr)[4]) {
 #pragma unroll
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
 #pragma unroll
     for (int p = 0; p < MT; ++p) {
       const int idx = threadIdx.x + 256 * p;                 // 16-byte chunk of the activation block
-      const int row = min(idx >> 4, M - 1);
+      const int row = min(m0 + (idx >> 4), M - 1);
       ar[p] = *reinterpret_cast<const u32x4*>(A + static_cast<int64_t>(row) * K + k0 + (idx & 15) * 16);
     }
   };
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   const int n = n0 + 4 * g;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = mt * 16 + l15;
+    const int m = m0 + mt * 16 + l15;
     if (m >= M) continue;
     if (splitk > 1) {
       acc_t* dst = reinterpret_cast<acc_t*>(static_cast<char*>(slab) + ((static_cast<int64_t>(slice) * M + m) * N + n) * 4);
@@ -347,9 +351,9 @@ static bool quant_skinny_ok(int64_t m, const GemmArgs& a) {
          aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
 }
 
-static int quant_skinny_splitk(int k, int n) {
+static int quant_skinny_splitk(int k, int n, int64_t m) {
   if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return v; }
-  const int nkb = k / 256, tiles = n / 64;
+  const int nkb = k / 256, tiles = (n / 64) * (m > 64 ? 2 : 1);
   int sk = (256 + tiles - 1) / tiles;                    // one workgroup per CU, three weight blocks in flight each
   if (sk > nkb / 4) sk = nkb / 4;                        // at least four K blocks per slice
   if (sk > 64) sk = 64;
@@ -358,14 +362,17 @@ static int quant_skinny_splitk(int k, int n) {
 
 template <typename TO, bool FP8>
 static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t* cs, int64_t m, void* slab_ws, hipStream_t s) {
-  const int sk = quant_skinny_splitk(a.K, a.N);
-  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(sk));
+  const int sk = quant_skinny_splitk(a.K, a.N, m);
+  // More than 64 rows run as two row blocks of 64 (grid.z): a 128-row workgroup needs 104 KiB of LDS (one workgroup of four
+  // waves per CU) and reads its activation fragments from LDS eight times per weight byte; two 64-row workgroups fit a CU
+  // together, and the second reads the weight lines the first just pulled into L2.
+  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(sk), m > 64 ? 2u : 1u);
   const uint8_t* A = static_cast<const uint8_t*>(a.A);
   const uint8_t* W = static_cast<const uint8_t*>(a.W);
   TO* C = static_cast<TO*>(a.C);
   const int M = static_cast<int>(m);
-#define SKINNY(MT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk)
-  if (m <= 16) SKINNY(1); else if (m <= 32) SKINNY(2); else if (m <= 64) SKINNY(4); else SKINNY(8);
+#define SKINNY(MT_, NT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_, NT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk)
+  if (m <= 16) SKINNY(1, true); else if (m <= 32) SKINNY(2, true); else if (m <= 64) SKINNY(4, true); else SKINNY(4, false);
 #undef SKINNY
   MOJO_CHECK_LAUNCH("quant_gemm(skinny)");
   if (sk > 1) {
@@ -452,7 +459,7 @@ extern "C" int64_t mojo_hip_quant_gemm_workspace_bytes(int64_t m, int64_t k, int
   // the largest split any path may choose for this shape (the skinny path needs [N,K] weights, which is not known here)
   int sk = (k > 0 && k % 128 == 0) ? quant_splitk(m, static_cast<int>(k), static_cast<int>(n)) : 1;
   if (m <= 128 && k > 0 && k % 256 == 0 && n % 64 == 0) {
-    const int s2 = quant_skinny_splitk(static_cast<int>(k), static_cast<int>(n));
+    const int s2 = quant_skinny_splitk(static_cast<int>(k), static_cast<int>(n), m);
     if (s2 > sk) sk = s2;
   }
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
