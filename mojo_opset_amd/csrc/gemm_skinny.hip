@@ -25,7 +25,11 @@ template <> struct skinny_mfma<f16_t> {
   }
 };
 
-template <typename T, int MT>
+// RB = row blocks per group (1 or 2): groups of more than 64 rows run as two 64-row blocks — a 128-row workgroup needs
+// 104 KiB of LDS (one workgroup of four waves per CU) and reads its activation fragments from LDS eight times per weight
+// byte; two 64-row workgroups share a CU, and the second reads the weight lines the first just pulled into L2 (default
+// cache policy instead of non-temporal loads).
+template <typename T, int MT, int RB>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
   constexpr int KB = 128;                                    // elements of K per block
@@ -33,7 +37,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int grp = blockIdx.y;
+  const int grp = blockIdx.y / RB;
+  const int t0 = (blockIdx.y % RB) * (MT * 16);              // first row of this block inside the group
   const int R = a.uniform_rows;
   const int n0 = blockIdx.x * 64 + wave * 16;
   const int nkb = a.K / KB;
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
   for (int p = 0; p < MT; ++p) {
     const int idx = threadIdx.x + 256 * p;
-    const int t = min(idx >> 4, R - 1);
+    const int t = min(t0 + (idx >> 4), R - 1);
     arow[p] = A + static_cast<int64_t>(map_row(grp * R + t, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda + (idx & 15) * 8;
   }
   constexpr int DEPTH = 3;
@@ -62,7 +67,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   auto load_w = [&](int i, u32x4 (&wr)[4]) {
 #pragma unroll
     for (int sx = 0; sx < 4; ++sx)
-      wr[sx] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(sx) * 4 * a.w_n + (kb0 + i) * KB));
+    {
+      const u32x4* src = reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(sx) * 4 * a.w_n + (kb0 + i) * KB);
+      if constexpr (RB == 1) wr[sx] = __builtin_nontemporal_load(src); else wr[sx] = *src;
+    }
   };
   auto store_w = [&](int buf, const u32x4 (&wr)[4]) {
 #pragma unroll
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   typedef typename vec_of<T, 4>::type V4;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int t = mt * 16 + l15;
+    const int t = t0 + mt * 16 + l15;
     if (t >= R) continue;
     if (a.splitk > 1) {                                  // raw fp32 partials of this K slice (dense GEMMs only: G == 1)
       *reinterpret_cast<f32x4*>(static_cast<float*>(a.slab) + (static_cast<int64_t>(slice) * a.slab_rows + t) * a.N + n) = acc[mt];
@@ -187,12 +195,12 @@ bool gemm_skinny_ok(const GemmArgs& a, int dtype) {
 
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
   MOJO_REQUIRE(gemm_skinny_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_skinny: preconditions not met");
-  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G), static_cast<unsigned>(a.splitk));
   const int mt = (a.uniform_rows + 15) / 16;
-#define SKINNY(TY, MT_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_>), grid, dim3(256), 0, s, a)
+  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G * (mt > 4 ? 2 : 1)), static_cast<unsigned>(a.splitk));
+#define SKINNY(TY, MT_, RB_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_, RB_>), grid, dim3(256), 0, s, a)
 #define SKINNY_MT(TY)                                                                          \
   do {                                                                                         \
-    if (mt <= 1) SKINNY(TY, 1); else if (mt <= 2) SKINNY(TY, 2); else if (mt <= 4) SKINNY(TY, 4); else SKINNY(TY, 8); \
+    if (mt <= 1) SKINNY(TY, 1, 1); else if (mt <= 2) SKINNY(TY, 2, 1); else if (mt <= 4) SKINNY(TY, 4, 1); else SKINNY(TY, 4, 2); \
   } while (0)
   if (dtype == MOJO_BF16) SKINNY_MT(bf16_t); else SKINNY_MT(f16_t);
 #undef SKINNY_MT
