@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
   typedef typename vec_of<T, VEC>::type V;
   __shared__ float red[4];
   const int n_vec = a.dim / VEC;
+  const int tid = threadIdx.x;
   const T* hidden = static_cast<const T*>(a.hidden);
   const T* residual = static_cast<const T*>(a.residual);
   T* out_sum = static_cast<T*>(a.out_sum);
@@ -89,14 +90,36 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
       return x;
     };
     // ---- pass 1: sums, sum of squares ---------------------------------------------------------------------------
+    // The cached vectors are loaded in batches — all of hidden, then (one wave-uniform branch) all of residual — with
+    // the index clamped instead of a branch per vector: a branch around each load made hipcc wait for every vector before
+    // requesting the next (one 16-byte load in flight per lane, four dependent round trips per row).
+    {
+      V xr[CACHE];
 #pragma unroll
-    for (int c = 0; c < CACHE; ++c) {
-      const int v = threadIdx.x + c * 256;
-      if (v < n_vec) {
-        const V x = load_sum(v, y[c]);
-        if (out_sum) store_vec<T, VEC>(out_sum + base + v * VEC, x);
+      for (int c = 0; c < CACHE; ++c) xr[c] = load_vec<T, VEC>(hidden + base + min(tid + c * 256, n_vec - 1) * VEC);
+      if (residual) {
+        V rr[CACHE];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) ss = fmaf(y[c][j], y[c][j], ss);
+        for (int c = 0; c < CACHE; ++c) rr[c] = load_vec<T, VEC>(residual + base + min(tid + c * 256, n_vec - 1) * VEC);
+#pragma unroll
+        for (int c = 0; c < CACHE; ++c)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j)
+            vset<T, VEC>(xr[c], j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(xr[c], j)) + elt<T>::to_f(vget<T, VEC>(rr[c], j))));
+      }
+      if (out_sum) {
+#pragma unroll
+        for (int c = 0; c < CACHE; ++c)
+          if (tid + c * 256 < n_vec) store_vec<T, VEC>(out_sum + base + (tid + c * 256) * VEC, xr[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CACHE; ++c) {
+        const bool live = tid + c * 256 < n_vec;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          y[c][j] = live ? elt<T>::to_f(vget<T, VEC>(xr[c], j)) : 0.f;           // clamped duplicates count as zeros
+          ss = fmaf(y[c][j], y[c][j], ss);
+        }
       }
     }
     for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
@@ -146,11 +169,36 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     };
     // ---- pass 2: y, row maximum ----------------------------------------------------------------------------------
     float amax = 0.f;
+    // cached part: the per-column vectors are fetched in batches too (clamped index, one uniform branch per tensor)
+    if (a.weight) {
+      float w[CACHE][VEC];
+#pragma unroll
+      for (int c = 0; c < CACHE; ++c) load_f32(a.weight, min(tid + c * 256, n_vec - 1), w[c]);
+#pragma unroll
+      for (int c = 0; c < CACHE; ++c)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) y[c][j] = __fmul_rn(__fmul_rn(y[c][j], rstd), w[c][j]);
+      if (a.out_normed) {
+#pragma unroll
+        for (int c = 0; c < CACHE; ++c)
+          if (tid + c * 256 < n_vec) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a.out_normed[base + (tid + c * 256) * VEC + j] = y[c][j];
+          }
+      }
+    }
+    if (a.smooth) {
+      float sm[CACHE][VEC];
+#pragma unroll
+      for (int c = 0; c < CACHE; ++c) load_f32(a.smooth, min(tid + c * 256, n_vec - 1), sm[c]);
+#pragma unroll
+      for (int c = 0; c < CACHE; ++c)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) y[c][j] = __fmul_rn(y[c][j], sm[c][j]);
+    }
 #pragma unroll
     for (int c = 0; c < CACHE; ++c) {
-      const int v = threadIdx.x + c * 256;
-      if (v < n_vec) {
-        finish(v, y[c]);
+      if (tid + c * 256 < n_vec) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(y[c][j]));
       }
