@@ -217,11 +217,29 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     const float inv_scale = __fdiv_rn(1.0f, scale);
     // ---- pass 3: quantise ------------------------------------------------------------------------------------------
     auto emit = [&](int v, const float (&f)[VEC]) {
-      unsigned char q[VEC];
+      // round_half_even(y / scale) as rint(y * (1 / scale)); the exact-division fallback is decided once per VECTOR (a
+      // divergent branch per element costs more vector instructions than the arithmetic it guards).  |t - rint(t)| <= 0.5
+      // always, so "within 1e-3 of a rounding boundary" is "its maximum over the vector > 0.499".
+      float rq[VEC];
+      float near = 0.f;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        const float r = fminf(fmaxf(round_quotient(f[j], scale, inv_scale), a.q_min), a.q_max);
-        q[j] = a.fp8 ? to_fp8_e4m3(r) : static_cast<unsigned char>(static_cast<signed char>(static_cast<int>(r)));
+        const float t = f[j] * inv_scale;
+        rq[j] = rintf(t);
+        near = fmaxf(near, fabsf(t - rq[j]));
+      }
+      if (near > 0.499f) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rq[j] = round_quotient(f[j], scale, inv_scale);
+      }
+      unsigned char q[VEC];
+      if (a.fp8) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) q[j] = to_fp8_e4m3(fminf(fmaxf(rq[j], a.q_min), a.q_max));
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          q[j] = static_cast<unsigned char>(static_cast<signed char>(static_cast<int>(fminf(fmaxf(rq[j], a.q_min), a.q_max))));
       }
       unsigned char* dst = out_q + base + v * VEC;
       if constexpr (VEC == 8) {
