@@ -151,6 +151,105 @@ __global__ __launch_bounds__(256) void moe_gating_kernel(const T* __restrict__ x
   }
 }
 
+// Eight experts (Mixtral), 16-bit activations, hidden % 512 == 0: a STREAM of the activations with 8 x 8 fp32
+// accumulators per lane.  A block takes 8 tokens, its four waves every fourth 512-wide chunk of the hidden dimension;
+// lane l owns hidden elements 8l .. 8l+7 of a chunk, so an activation load is one coalesced 1 KiB instruction per token
+// and the matching weight rows (8 rows x 8 experts = 256 contiguous bytes per lane) are sixteen 16-byte loads reused by
+// all 8 tokens.  The 64 partial logits of a lane (index = token * 8 + expert) are summed across lanes by lane-row swaps
+// (v_permlane32_swap, v_permlane16_swap: the index set a lane keeps halves each time) and a DPP row sum, the four waves'
+// sums meet in LDS (added in wave order), and softmax + top-k of a token run inside one lane.
+// (The general kernel above assigns a lane per EXPERT: eight lanes load the same 16 bytes of x and every lane issues one
+// 4-byte weight load per multiply — 88 us for T = 8192, H = 4096 against 67 MB of activations.)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void moe_gating_e8_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               int32_t* __restrict__ out_idx, float* __restrict__ out_gate,
+                                                               int64_t tokens, int hidden, int top_k) {
+  constexpr int E = 8, TT = 8, VEC = 8;
+  typedef typename vec_of<T, VEC>::type V;
+  __shared__ float s_part[4][4][2 * E];                                  // [wave][lane row = token pair][token-in-pair * 8 + expert]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tok0 = static_cast<int64_t>(blockIdx.x) * TT;
+  float acc[TT * E];
+#pragma unroll
+  for (int i = 0; i < TT * E; ++i) acc[i] = 0.f;
+  const T* xr[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) xr[t] = x + min(tok0 + t, tokens - 1) * hidden + lane * VEC;   // clamped rows: computed, not stored
+  for (int h0 = wave * 64 * VEC; h0 < hidden; h0 += 4 * 64 * VEC) {
+    V xv[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) xv[t] = load_vec<T, VEC>(xr[t] + h0);
+    f32x4 wv[2 * VEC];                                                   // w[(h + j) * 8 + e] = wv[2 j + (e >> 2)][e & 3]
+    const float* wp = w + (static_cast<int64_t>(h0) + lane * VEC) * E;
+#pragma unroll
+    for (int i = 0; i < 2 * VEC; ++i) wv[i] = *reinterpret_cast<const f32x4*>(wp + 4 * i);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        const float xf = elt<T>::to_f(vget<T, VEC>(xv[t], j));
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[t * E + e] = fmaf(xf, wv[2 * j + (e >> 2)][e & 3], acc[t * E + e]);
+      }
+  }
+  // lanes l, l ^ 32: lanes < 32 keep indices i, lanes >= 32 keep i + 32
+  float r32[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    float p = acc[i], q = acc[i + 32];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+    r32[i] = p + q;
+  }
+  // lanes l, l ^ 16: even 16-lane rows keep i, odd rows i + 16  ->  row R holds indices 16 R .. 16 R + 15
+  const int row = lane >> 4, l15 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float p = r32[i], q = r32[i + 16];
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+    const float v = row16_sum(p + q);
+    if (l15 == 0) s_part[wave][row][i] = v;
+  }
+  __syncthreads();
+  // wave w, lanes 0 and 1: tokens 2w and 2w + 1 of the block
+  const int64_t token = tok0 + 2 * wave + lane;
+  if (lane >= 2 || token >= tokens) return;
+  float lg[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    lg[e] = ((s_part[0][wave][lane * E + e] + s_part[1][wave][lane * E + e]) + s_part[2][wave][lane * E + e]) + s_part[3][wave][lane * E + e];
+  float mx = lg[0];
+#pragma unroll
+  for (int e = 1; e < E; ++e) mx = fmaxf(mx, lg[e]);
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) { lg[e] = __expf(lg[e] - mx); sum += lg[e]; }
+#pragma unroll
+  for (int e = 0; e < E; ++e) lg[e] = lg[e] / sum;
+  float best_v[E];
+  int best_e[E];
+  float sel_sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {                                           // top_k <= 8 rounds; ties -> lowest expert id
+    float b = -1.f;
+    int be = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (lg[e] > b) { b = lg[e]; be = e; }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (e == be) lg[e] = -1.f;
+    best_v[r] = b;
+    best_e[r] = be;
+    if (r < top_k) sel_sum += b;
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r)
+    if (r < top_k) {
+      out_idx[token * top_k + r] = best_e[r];
+      out_gate[token * top_k + r] = best_v[r] / sel_sum;
+    }
+}
+
 // large expert counts: logits come from the MFMA GEMM (x @ w_hi + x @ w_lo, `parts` fp32 slabs of [tokens, e_pad]);
 // one wave per token
 __global__ __launch_bounds__(256) void moe_gate_select_kernel(const float* __restrict__ logits, int64_t part_stride, int parts,
@@ -405,6 +504,15 @@ static int pow2ceil_log2(int v) {
 template <typename T>
 static int launch_gating(const void* x, const float* w, int32_t* idx, float* gate, int64_t tokens, int hidden, int experts,
                          int top_k, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    static const bool no_e8 = [] { const char* e = getenv("MOJO_HIP_GATING_E8"); return e && e[0] == '0'; }();
+    if (experts == 8 && hidden % 512 == 0 && tokens >= 32 && aligned_to(w, 16) && !no_e8) {
+      hipLaunchKernelGGL((moe_gating_e8_kernel<T>), dim3(static_cast<unsigned>(ceil_div(tokens, static_cast<int64_t>(8)))), dim3(256), 0, s,
+                         static_cast<const T*>(x), w, idx, gate, tokens, hidden, top_k);
+      MOJO_CHECK_LAUNCH("moe_gating(e8)");
+      return MOJO_OK;
+    }
+  }
   const int ep_log2 = pow2ceil_log2(experts < 64 ? experts : 64);
   const int ep = 1 << ep_log2, subs = 64 / ep;
   const int ei = (experts + ep - 1) / ep;                       // experts per lane

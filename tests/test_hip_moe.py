@@ -241,6 +241,31 @@ def test_moe_layer_reference_space(experts, k, hidden, inter, tokens):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k,hidden,tokens", [(2, 4096, 1000), (1, 512, 33), (8, 1024, 70), (3, 2048, 4096)])
+def test_gating_eight_expert_kernel_agrees_with_general_kernel(k, hidden, tokens, dtype, monkeypatch):
+    """E = 8 takes a dedicated streaming kernel (a lane owns hidden elements, not an expert); MOJO_HIP_GATING_E8=0 runs the
+    general one.  Identical expert choice (up to near-ties), gates to 1e-5, and the oracle agrees with both."""
+    torch.manual_seed(5)
+    op = hip_cls("MojoMoEGating")(hidden_size=hidden, num_experts=8, top_k=k).to(DEV)
+    with torch.no_grad():
+        op.gate_weight.normal_(std=0.05)
+    x = torch.rand(tokens, hidden, dtype=dtype, device=DEV)
+    idx_s, g_s = op(x)
+    monkeypatch.setenv("MOJO_HIP_GATING_E8", "0")
+    idx_g, g_g = op(x)
+    same = idx_s == idx_g
+    assert float(same.float().mean()) >= 0.999
+    torch.testing.assert_close(g_s[same], g_g[same], atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(g_s.sum(-1), torch.ones(tokens, device=DEV), atol=1e-5, rtol=0)
+    ref = torch_cls("MojoMoEGating")(hidden_size=hidden, num_experts=8, top_k=k)
+    ref.load_state_dict({k_: v_.cpu() for k_, v_ in op.state_dict().items()})
+    want_idx, want_g = ref(x.cpu())
+    ok = idx_s.cpu() == want_idx
+    assert float(ok.float().mean()) >= 0.999
+    torch.testing.assert_close(g_s.cpu()[ok], want_g[ok], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_gating_mfma_route_agrees_with_vector_route(dtype, monkeypatch):
     """Same inputs through both routes of `mojo_hip_moe_gating`: identical expert choice (up to near-ties), gates to 1e-4."""
     torch.manual_seed(3)
