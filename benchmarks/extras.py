@@ -363,6 +363,7 @@ def bench_compute_comm(device, world, rank):
 def bench_moe(device):
     """Mixtral routing: T = 8192 tokens, 8 experts, top-2, hidden 4096, inter 14336."""
     out = {}
+    torch.manual_seed(20260716)                                   # the routing (rows per expert) decides the tile count: keep it fixed
     t_, e_, k_, h_, i_ = 8192, 8, 2, 4096, 14336
     x = torch.rand(t_, h_, device=device, dtype=torch.bfloat16)
     gating = hip("MojoMoEGating")(hidden_size=h_, num_experts=e_, top_k=k_).to(device)
