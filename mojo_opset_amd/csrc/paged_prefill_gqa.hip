@@ -58,10 +58,11 @@ template <> struct pf_mfma<f16_t> {
   static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-#ifdef PF_STAMPS
+#if defined(PF_STAMPS) || defined(PF_WG_STAMPS)
 // In-kernel stamps (build with MOJO_HIP_EXTRA_CXXFLAGS=-DPF_STAMPS): lane i of `tacc` accumulates the cycles between
 // stamp i-1 and stamp i of the hot loop; read back with mojo_hip_debug_prefill_stamps.  Timing tool only.
 __device__ unsigned g_pf_stamps[8192 * 4 * 16];
+#ifdef PF_STAMPS
 #define PF_STAMP(i)                                                              \
   do {                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                           \
@@ -73,6 +74,20 @@ __device__ unsigned g_pf_stamps[8192 * 4 * 16];
   } while (0)
 #else
 #define PF_STAMP(i)
+#endif
+#else
+#define PF_STAMP(i)
+#endif
+
+#ifdef PF_WG_STAMPS
+// Workgroup-level phases (-DPF_WG_STAMPS): prologue, hot loop, remaining loops, epilogue — one record per workgroup.
+#define PF_WG_MARK(slot)                                                                          \
+  do {                                                                                            \
+    const unsigned long long t_ = __builtin_readcyclecounter();                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_pf_stamps[blockIdx.x * 16 + (slot)] = static_cast<unsigned>(t_ - wg_t0); \
+  } while (0)
+#else
+#define PF_WG_MARK(slot)
 #endif
 
 constexpr float PF_LAZY_LOG2 = 8.f;          // the reference maximum may lag the true one by this many powers of two
@@ -133,6 +148,9 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     return;
   }
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
+#ifdef PF_WG_STAMPS
+  const unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -317,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   int phys_next = a.fast_stage ? page_of_tile(1) : 0;    // page id for the NEXT stage, loaded a tile ahead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  PF_WG_MARK(0);
 
 #ifdef PF_STAMPS
   unsigned tacc = 0;
@@ -539,8 +558,13 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     if (lane == 15) g_pf_stamps[(blockIdx.x * 4 + wave) * 16 + 15] = static_cast<unsigned>(kb_i);
   }
 #endif
+  PF_WG_MARK(1);
+#ifdef PF_WG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) { g_pf_stamps[blockIdx.x * 16 + 4] = kb_i; g_pf_stamps[blockIdx.x * 16 + 5] = n_kb; }
+#endif
   for (; kb_i < n_full; ++kb_i) key_block(std::false_type{}, std::false_type{}, kb_i);
   for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, std::false_type{}, kb_i);
+  PF_WG_MARK(2);
 
   // ---- finish: reduce the row sums over the 4 lane groups, normalise, store ----------------------------------
 #pragma unroll
@@ -560,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
       *reinterpret_cast<V4*>(dst + dt * 16 + grp * 4) = ov;
     }
   }
+  PF_WG_MARK(3);
 }
 
 template <typename T, int G, int DK>
@@ -649,7 +674,7 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   return dtype == MOJO_BF16 ? dispatch_g<bf16_t>(a, G, batch, max_q, s) : dispatch_g<f16_t>(a, G, batch, max_q, s);
 }
 
-#ifdef PF_STAMPS
+#if defined(PF_STAMPS) || defined(PF_WG_STAMPS)
 extern "C" int mojo_hip_debug_prefill_stamps(unsigned* host_out, int64_t count) {
   if (hipDeviceSynchronize() != hipSuccess) return MOJO_ELAUNCH;
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mojo::g_pf_stamps), static_cast<size_t>(count) * 4) == hipSuccess ? MOJO_OK : MOJO_ELAUNCH;
