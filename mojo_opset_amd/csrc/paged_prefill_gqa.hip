@@ -567,21 +567,39 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   PF_WG_MARK(2);
 
   // ---- finish: reduce the row sums over the 4 lane groups, normalise, store ----------------------------------
+  // O^T leaves the accumulators as 8-byte pieces at a row stride (a store instruction would touch 64 separate lines), so
+  // each wave transposes its 32 rows through a private LDS region (the tile buffers are free now; rows padded to 288 B:
+  // the 8-byte writes of 16 rows then spread over all banks) and stores whole 2 * dim-byte rows, 16 bytes per lane.
+  constexpr int OROW = 288;
+  lds_c* stage_o = smem + wave * (32 * OROW);
+  typedef typename vec_of<T, 4>::type V4;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = lsum[qt];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    if (row_pos[qt] >= q_len) continue;
-    const float inv = 1.0f / l;
-    T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + row_pos[qt]) * a.hq + row_head[qt]) * a.dim;
-    typedef typename vec_of<T, 4>::type V4;
+    const float inv = 1.0f / xor_sum_16_32(lsum[qt]);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       V4 ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov[r] = static_cast<T>(o[qt][dt][r] * inv);
-      *reinterpret_cast<V4*>(dst + dt * 16 + grp * 4) = ov;
+      *reinterpret_cast<__attribute__((address_space(3))) V4*>(stage_o + (qt * 16 + l15) * OROW + (dt * 16 + grp * 4) * 2) = ov;
+    }
+  }
+  {
+    typedef typename vec_of<T, 8>::type V8;
+    constexpr int CPR = DT * 2;                          // 16-byte chunks per row (dim / 8)
+    constexpr int RPI = 64 / CPR;                        // rows per store instruction
+    const int sub = lane / CPR, ch = lane % CPR;
+#pragma unroll
+    for (int i = 0; i < (32 + RPI - 1) / RPI; ++i) {
+      const int row = i * RPI + sub;                     // row of this wave (lanes past RPI * CPR idle: head_dim 96)
+      if (sub >= RPI || row >= 32) continue;
+      const int r = wave * 32 + row;
+      const int pos = qb * QPB + (r % QPB);
+      if (pos >= q_len) continue;
+      const int g = r / QPB;
+      const int head = a.abab ? g * a.hkv + kvh : kvh * G + g;
+      const V8 v = *reinterpret_cast<const __attribute__((address_space(3))) V8*>(stage_o + row * OROW + ch * 16);
+      *reinterpret_cast<V8*>(static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + pos) * a.hq + head) * a.dim + ch * 8) = v;
     }
   }
   PF_WG_MARK(3);
