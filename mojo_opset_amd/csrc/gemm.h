@@ -34,6 +34,7 @@ struct GemmArgs {
   // n .. n+127 with up columns I+n .. I+n+127 and stores round(round(silu(round(gate))) * round(up)) to C [M, I] — the
   // golden's rounding points — instead of the [M, 2I] product.  256x256 MFMA kernel only, I % 128 == 0, no split-K.
   int glu = 0;
+  int stage_rows = 0;        // 256x256 kernel, 16-bit C, ldc % 8 == 0, 16-byte aligned C: store whole 64-byte row pieces via LDS
   int ablate = 0;            // timing-only: 1 = skip the C stores (MOJO_HIP_GEMM_ABLATE)
   int splitk = 1;
   void* slab = nullptr;
