@@ -436,6 +436,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     return;
   }
   if constexpr (EB == 2 && std::is_same<acc_t, f32x4>::value) {
+    if (a.glu && a.stage_rows) {                       // row-staged (see below): 128 rows x 32 columns per wave, 64-byte pieces
+      __builtin_amdgcn_s_barrier();
+      lds_char* reg = smem + wave * 16384;
+      typedef typename vec_of<E, 4>::type V4;
+      typedef typename vec_of<E, 8>::type V8;
+      const int l15 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int row = (mt >> 2) * 64 + (mt & 3) * 16 + l15;
+        const int sw = ((row >> 1) & 3) << 2;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          V4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float gf = elt<E>::to_f(elt<E>::from_f(acc[mt][nt][e]));
+            const float uf = elt<E>::to_f(elt<E>::from_f(acc[mt][nt + 2][e]));
+            o[e] = elt<E>::from_f(elt<E>::to_f(elt<E>::from_f(silu_f(gf))) * uf);
+          }
+          *reinterpret_cast<__attribute__((address_space(3))) V4*>(reg + row * 128 + ((nt * 4 + g4) ^ sw) * 8) = o;
+        }
+      }
+      E* C = static_cast<E*>(a.C);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 16 + (lane >> 2), c = lane & 3;
+        const int m = m0 + (row >> 6) * 128 + wm * 64 + (row & 63);
+        if (m >= m_end) continue;
+        const V8 v = *reinterpret_cast<const __attribute__((address_space(3))) V8*>(reg + row * 128 + (c ^ (((row >> 1) & 3) << 1)) * 16);
+        const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul);
+        *reinterpret_cast<V8*>(C + static_cast<int64_t>(mc) * a.ldc + n0 + wn * 32 + c * 8) = v;
+      }
+      return;
+    }
     if (a.glu) {                                       // accumulator tiles nt and nt + 2 hold gate and up of the same columns
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {

@@ -40,7 +40,7 @@ int launch_gemm_mfma256(const GemmArgs& a_in, int dtype, int64_t m_total, hipStr
   GemmArgs a = a_in;
   MOJO_REQUIRE(gemm_mfma256_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: preconditions not met");
   static const bool no_stage = [] { const char* e = getenv("MOJO_HIP_GEMM_STAGE_ROWS"); return e && e[0] == '0'; }();
-  a.stage_rows = (!no_stage && !a.glu && a.splitk == 1 && a.ldc % 8 == 0 && aligned_to(a.C, 16)) ? 1 : 0;
+  a.stage_rows = (!no_stage && a.splitk == 1 && a.ldc % 8 == 0 && aligned_to(a.C, 16)) ? 1 : 0;
   MOJO_REQUIRE(!a.glu || gemm_mfma256_glu_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: fused SwiGLU needs I %% 128 == 0");
   if (dtype == MOJO_BF16) {
     g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias)};
