@@ -72,7 +72,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base
 template <typename T>
 struct EpiloguePlain {       // C = round_T(acc) (+ bias, added after the rounding: the golden runs two ops)
   static constexpr bool kRowStaged = sizeof(T) == 2;   // may go through the wave-private LDS transpose (see the kernel's epilogue)
+  typedef T out_t;
   T* C; int64_t ldc; const T* bias;
+  __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
+  __device__ __forceinline__ typename vec_of<T, 4>::type to4(int, f32x4 acc) const {
+    typename vec_of<T, 4>::type o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[e]);
+    return o;
+  }
   __device__ __forceinline__ void row_begin(int) {}
   __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
     typedef typename vec_of<T, 4>::type V4;
@@ -111,9 +119,21 @@ struct EpilogueF32 {         // C (fp32) = acc, or C += acc: two-pass products (
 
 template <typename TO, typename ACC>
 struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_scale[n] )   (golden: gemm.py:213-223)
-  static constexpr bool kRowStaged = false;
+  static constexpr bool kRowStaged = sizeof(TO) == 2;
+  typedef TO out_t;
   TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;
   float rs;
+  __device__ __forceinline__ bool has_bias() const { return false; }
+  __device__ __forceinline__ typename vec_of<TO, 4>::type to4(int n, ACC acc) const {   // full tiles only: n + 4 <= N
+    typename vec_of<TO, 4>::type o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), rs), static_cast<float>(col_scale[n + e]));
+      asm volatile("" : "+v"(v));                          // see store(): the fp32 product is a value of its own
+      o[e] = elt<TO>::from_f(v);
+    }
+    return o;
+  }
   __device__ __forceinline__ void row_begin(int m) { rs = row_scale[m]; }
   __device__ __forceinline__ void store(int m, int n, int n_limit, ACC acc) const {
     TO* dst = C + static_cast<int64_t>(m) * ldc + n;
@@ -492,33 +512,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
       return;
     }
   }
-  if constexpr (Epi::kRowStaged && EB == 2 && std::is_same<acc_t, f32x4>::value) {
+  if constexpr (Epi::kRowStaged) {
     // Row-staged stores.  The accumulators hold a row as 8-byte pieces (4 columns per lane), 64 store instructions per
     // wave touching 64 lines each; the epilogue is fully exposed (one workgroup per CU: 6 % of the kernel at K = 4096).
     // Each wave instead transposes its 128 rows x (2 x 32 columns) through a private 16 KiB LDS region (the tile buffers
     // are free behind the barrier) and stores 64-byte row pieces, 16 bytes per lane: 16 instructions.  LDS image: row
     // stride 128 B, 8-byte slot s of row r at s ^ (((r >> 1) & 3) << 2) (2-way = minimal conflicts for the writes,
     // 16-byte pairs stay together for the reads).
-    if (a.stage_rows && n0 + BN <= a.N && !epi.bias) {
+    if (a.stage_rows && n0 + BN <= a.N && !epi.has_bias()) {
       __builtin_amdgcn_s_barrier();                        // every wave is done with the tile buffers (and its DMA has landed)
       lds_char* reg = smem + wave * 16384;
-      typedef typename vec_of<E, 4>::type V4;
-      typedef typename vec_of<E, 8>::type V8;
+      typedef typename Epi::out_t OT;
+      typedef typename vec_of<OT, 4>::type V4;
+      typedef typename vec_of<OT, 8>::type V8;
       const int l15 = lane & 15, g4 = lane >> 4;
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const int row = (mt >> 2) * 64 + (mt & 3) * 16 + l15;
         const int sw = ((row >> 1) & 3) << 2;
+        epi.row_begin(min(m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15, m_end - 1));   // rows past the group: staged, never stored
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          V4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = static_cast<E>(acc[mt][nt][e]);
+          const V4 o = epi.to4(n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4, acc[mt][nt]);
           const int slot = ((nt >> 1) * 8 + (nt & 1) * 4 + g4) ^ sw;
           *reinterpret_cast<__attribute__((address_space(3))) V4*>(reg + row * 128 + slot * 8) = o;
         }
       }
-      E* C = epi.C;
+      OT* C = epi.C;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int piece = it * 16 + (lane >> 2);             // (row, column half) of this wave: 4 lanes x 16 B = 64 B

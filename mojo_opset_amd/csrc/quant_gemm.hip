@@ -430,6 +430,8 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
       MOJO_CHECK_LAUNCH("quant_gemm(finalize)");
       return MOJO_OK;
     }
+    static const bool no_stage = [] { const char* e = getenv("MOJO_HIP_GEMM_STAGE_ROWS"); return e && e[0] == '0'; }();
+    a.stage_rows = (!no_stage && sizeof(TO) == 2 && a.ldc % 8 == 0 && aligned_to(a.C, 16)) ? 1 : 0;   // row-staged stores (gemm256_core.h)
     if (fp8) {
       g256::EpilogueDequant<TO, f32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f};
       return g256::gemm256_launch<g256::PolF8>(a, epi, m, s);
