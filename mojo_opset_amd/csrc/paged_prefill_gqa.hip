@@ -1,8 +1,9 @@
 // MojoPagedPrefillGQA — flash attention (online softmax) over a paged KV cache on MFMA, gfx950.
 //
 // Work decomposition
-//   grid = q blocks x Hkv x B workgroups (longest first); one 256-thread workgroup owns 128 "rows" = the G = Hq/Hkv query heads of one
-//   kv-head times 128/G consecutive query positions, so every K/V tile is read once per kv-head.
+//   1-D grid of q blocks x Hkv x B workgroups, query block the slow coordinate and descending (longest first over the whole
+//   launch), plus trailing workgroups that zero the padding rows; one 256-thread workgroup owns 128 "rows" = the G = Hq/Hkv
+//   query heads of one kv-head times 128/G consecutive query positions, so every K/V tile is read once per kv-head.
 //   Each of the 4 waves owns 32 rows = two 16-row MFMA tiles.
 //   K/V advance in tiles of 64 keys, double-buffered in LDS (2 x (16 + 16) KiB), filled by direct-to-LDS
 //   loads straight from the pages (4 keys x 256 B per wave instruction, page ids looked up per 4 keys).
@@ -17,8 +18,10 @@
 // V: chunk c stored at c ^ ((r & 7) << 1); both conflict-free for their read pattern, applied on the
 // SOURCE address of the lane-linear LDS-DMA.
 //
-// Numerics: fp32 scores and statistics, probabilities rounded to the storage type for the PV product
-// (as the golden does), fp32 output accumulation.  Parity by tolerance: atol = rtol = 2e-2.
+// Numerics: fp32 scores and statistics (lazy reference maximum: it may lag the true one by 2^8, the final division uses sums
+// taken against the same reference), probabilities rounded to the storage type for the PV product (as the golden does),
+// fp32 output accumulation; the output leaves through a wave-private LDS transpose as whole rows.  Parity by tolerance:
+// atol = rtol = 2e-2.
 //
 // Algorithmic FLOPs (causal): sum_b 4 * Hq * D * (q_b * kv_b - q_b^2 / 2).   Bound: MFMA.
 #include <math.h>
