@@ -158,3 +158,21 @@ def test_group_gemm_full_size_linearity_mixtral():
     for lo, gi in ((0, 0), (8191, 0), (8192, 2), (8193, 3), (8193 + 2047, 4), (m - 1, 6)):
         want = x1[lo: lo + 1].to(DEV).float() @ w[gi].float()
         assert torch.equal(a[lo: lo + 1].float(), want)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("counts,k,n", [([300, 0, 17, 1000, 255, 1], 512, 768), ([2560] * 2, 1024, 512), ([513, 7], 448, 264 + 248)])
+def test_group_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(trans, dtype, counts, k, n, monkeypatch):
+    """The 256x256 kernel stores full N tiles through a wave-private LDS transpose (64-byte row pieces);
+    MOJO_HIP_GEMM_STAGE_ROWS=0 stores the accumulators' 8-byte pieces directly.  Same bits, ragged groups included."""
+    g = torch.Generator().manual_seed(11)
+    groups = len(counts)
+    x = torch.randn(sum(counts), k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(groups, n, k, generator=g) if trans else torch.randn(groups, k, n, generator=g)).to(dtype).to(DEV)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    op = hip_cls("MojoGroupGemm")(w, trans)
+    staged = op(x, cnt)
+    monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")
+    direct = op(x, cnt)
+    assert torch.equal(staged, direct)

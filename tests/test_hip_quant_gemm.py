@@ -107,3 +107,25 @@ def test_quant_gemm_fp8_small_integers_exact():
         op.weight_scale.fill_(1.0)
         out = to_cpu(op(x.to(f8).to(DEV), torch.ones(m, device=DEV)))
         assert torch.equal(out, x @ w.t())
+
+
+@pytest.mark.parametrize("quant_dtype", [torch.int8, torch.float8_e4m3fn])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n", [(300, 512, 768), (1024, 1024, 512), (257, 2048, 1280)])
+def test_quant_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(m, k, n, odt, quant_dtype, monkeypatch):
+    """Full N tiles of the 256x256 kernel leave through the row-staged epilogue (scales applied on the way into the
+    wave-private LDS transpose); MOJO_HIP_GEMM_STAGE_ROWS=0 stores directly.  Same bits."""
+    torch.manual_seed(13)
+    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=odt, trans_weight=True, quant_dtype=quant_dtype, weight_dtype=quant_dtype, device=DEV)
+    if quant_dtype == torch.int8:
+        op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=DEV))
+        x = torch.randint(-127, 128, (m, k), dtype=torch.int8, device=DEV)
+    else:
+        op.weight.copy_(torch.randn(n, k, device=DEV).to(quant_dtype))
+        x = torch.randn(m, k, device=DEV).to(quant_dtype)
+    op.weight_scale.copy_(torch.rand(n, device=DEV) * 0.02)
+    s_in = torch.rand(m, device=DEV)
+    staged = op(x, s_in)
+    monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")
+    direct = op(x, s_in)
+    assert torch.equal(staged, direct)
