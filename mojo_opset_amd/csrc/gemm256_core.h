@@ -15,7 +15,7 @@ constexpr int KT_BYTES = 128;                     // bytes of K per row per K-ti
 constexpr int HALF_BYTES = 128 * KT_BYTES;        // 16 KiB
 constexpr int KTILE_BYTES = 4 * HALF_BYTES;       // A0 A1 W0 W1
 constexpr int LDS_BYTES = 2 * KTILE_BYTES;        // 128 KiB
-constexpr int PANEL = 8;                          // n-tiles per panel
+constexpr int PANEL = 4;                          // n-tiles per panel (A/B: 4 beats 8 by 0.5-2.5 %, 2 and 16 lose)
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef i32x4 frag16;                             // 16 bytes of K for one row / column

@@ -17,7 +17,7 @@
 //   * MFMA operands are swapped (W fragment as "A", A fragment as "B") so that a lane owns 4 consecutive
 //     output columns of one row -> 8-byte stores.
 //   * blocks are mapped to tiles through an XCD-aware, panel-major order: the 32 blocks that run
-//     concurrently on one XCD cover 4 m-tiles x 8 n-tiles and share their operands in that XCD's L2.
+//     concurrently on one XCD cover 8 m-tiles x 4 n-tiles and share their operands in that XCD's L2.
 //
 // Algorithmic FLOPs per launch: 2 * M * K * N.   Bound: MFMA (bf16 dense peak ~2.5 PFLOP/s).
 #include <stdlib.h>
