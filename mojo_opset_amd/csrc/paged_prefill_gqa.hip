@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
 #ifdef PF_WG_STAMPS
   const unsigned long long wg_t0 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_pf_stamps[blockIdx.x * 16 + 6] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime());   // 100 MHz, chip-wide
 #endif
 
   const int lane = threadIdx.x & 63;
@@ -606,6 +607,9 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     }
   }
   PF_WG_MARK(3);
+#ifdef PF_WG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_pf_stamps[blockIdx.x * 16 + 7] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 template <typename T, int G, int DK>

@@ -34,5 +34,13 @@ for name, q_lens in {"16 ragged 512..1024": ragged, "4 x 2048": [2048] * 4}.item
     a = a[live]
     pro, hot, rest, end = a[:, 0], a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2]
     print(f"{name}: {int(live.sum())} live workgroups, tiles/WG {a[:, 5].mean():.1f} (hot-loop tiles {a[:, 4].mean():.1f})")
+    t0, t1 = a[:, 6] / 100.0, a[:, 7] / 100.0                      # us (100 MHz counter, low 32 bits)
+    base = t0.min()
+    t0, t1 = t0 - base, t1 - base
+    span = t1.max()
+    grid = np.linspace(0, span, 21)
+    occ = [int(((t0 <= g) & (t1 > g)).sum()) for g in grid]
+    print(f"   kernel span {span:6.1f} us; live workgroups resident at 5 % steps: {occ}")
+    print(f"   start of the last workgroup {t0.max():6.1f} us; sum of workgroup times / 512 slots = {(t1 - t0).sum() / 512:6.1f} us")
     print(f"   prologue {pro.mean():8.0f} cycles   hot loop {hot.mean():8.0f} ({(hot / np.maximum(a[:, 4], 1)).mean():6.0f}/tile)"
           f"   other loops {rest.mean():8.0f} ({(rest / np.maximum(a[:, 5] - a[:, 4], 1)).mean():6.0f}/tile)   epilogue {end.mean():6.0f}   total {a[:, 3].mean():8.0f}")
