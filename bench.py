@@ -19,10 +19,10 @@ import json
 import threading
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -31,6 +31,46 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s ac
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 B, HQ, HKV, D, PAGE, CTX = 64, 32, 8, 128, 16, 4096
+
+
+def launch_ranks(gpus, argv):
+    """``python bench.py --gpus N`` without a launcher: start ``torch.distributed.run`` with N ranks as a CHILD process
+    (this parent never touches the GPU — it has not even imported torch — so nothing that initialised HIP is replaced
+    or forked), relay the child's output and exit with its status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True)
+    got_line = False
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            got_line = True
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+        rc = 4
+    sys.exit(rc)
+
+
+def _early_launch():
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    ns, _ = ap.parse_known_args()
+    if ns.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(ns.gpus, sys.argv[1:])
+
+
+if __name__ == "__main__":
+    _early_launch()                # before torch is even imported: the parent of the ranks never initialises HIP
+
+import torch  # noqa: E402
 
 
 def build_decode_inputs(device, ctx=CTX, batch=B, seed=20260716, sets=2):
@@ -87,6 +127,9 @@ def main():
     ns = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if ns.gpus != world:
+        sys.exit(f"bench.py: --gpus {ns.gpus} but the launcher started WORLD_SIZE={world} ranks")
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
@@ -178,7 +221,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
-                     "kernel": "mojo::decode_split_kernel<bf16,4,nt,fused> (one launch per op call: the chunk partials are merged in LDS)"},
+                     "kernel": ("mojo::decode_split_kernel<bf16,4,nt,fused> (one launch per op call: the chunk partials are merged in LDS)"
+                                if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" else
+                                "mojo::decode_split_kernel<bf16,4,nt> + mojo::decode_merge_kernel (MOJO_HIP_DECODE_FUSE=0)")},
     }
     hung = False
     if not ns.no_extras:            # every rank takes part: the GEMM + collective cases contain collectives
@@ -200,6 +245,18 @@ def main():
         worker.join(ns.extras_deadline)
         hung = worker.is_alive()
         line["extras"] = {"error": f"extras did not finish within {ns.extras_deadline:.0f} s"} if hung else box.get("extras")
+        # second headline (BASELINE metric: "MojoGroupGemm TFLOPs vs roofline"): its own roofline block on the line
+        gg = (line["extras"] or {}).get("MojoGroupGemm_bf16", {}) if isinstance(line["extras"], dict) else {}
+        head = gg.get("mixtral_up_16384x4096x28672_G8_KN") if isinstance(gg, dict) else None
+        if isinstance(head, dict) and "tflops" in head:
+            line["roofline_group_gemm"] = {
+                "bound": "mfma", "achieved": head["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": head["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "flops_per_launch": 2.0 * 16384 * 4096 * 28672, "device_us_per_launch": head["us"],
+                "sustained_clock_mhz": head.get("sustained_clock_mhz"),
+                "workload": "MojoGroupGemm bf16, Mixtral up-projection: 16384 rows over 8 experts (balanced), K=4096, N=28672, "
+                            "weights [G,K,N], random data (BASELINE configs[2])",
+                "kernel": "mojo::g256::gemm256_kernel<bf16>"}
     if rank == 0 and world == 1 and not ns.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if rank == 0:                   # the line goes out before any further collective can get in its way
@@ -209,9 +266,10 @@ def main():
         closer.start()
         closer.join(60.0)
         hung = closer.is_alive()
-    if hung:                        # a stuck collective would also block interpreter shutdown
+    if hung:                        # a stuck collective would also block interpreter shutdown: leave, and say so
+        print(f"bench.py: rank {rank} abandoned a hung collective / extras thread", file=sys.stderr, flush=True)
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)
 
 
 if __name__ == "__main__":

@@ -79,7 +79,9 @@ int mojo_hip_swiglu_rows(const void* gate, const void* up, void* out, int64_t ro
 /* ---- MojoResidualAddRMSNorm / MojoRMSNorm (core/operators/normalization.py:308-362, :71-111;
  *      replaces fused_add_rmsnorm / rmsnorm launchers, backends/ttx/operators/normalization.py:35-47).
  *      residual == NULL: plain RMSNorm.  sum_out may be NULL (norm_pos="post").
- *      sum = round_dtype(hidden + residual); normed = round_dtype(sum * rsqrt(mean(sum^2)+eps) * w). */
+ *      sum = round_dtype(hidden + residual); normed = round_dtype(sum * rsqrt(mean(sum^2)+eps) * w).
+ *      normed_out may be the same buffer as hidden: MojoRMSNormInplace(inplace=True)
+ *      (experimental/operators/normalization.py:95-140).                                            */
 int mojo_hip_residual_add_rmsnorm(const void* hidden, const void* residual, const void* weight,
                                   void* normed_out, void* sum_out, int64_t rows, int64_t dim,
                                   int dtype, float eps, mojo_stream_t stream);
@@ -97,6 +99,24 @@ int mojo_hip_apply_rope(const void* q, const void* k, void* q_out, void* k_out,
                         int64_t cos_b_stride, int64_t cos_t_stride, int dtype,
                         mojo_stream_t stream);
 
+/* ---- Block allocator of the paged KV cache (replaces the host loop of PagedDummyCache.update,
+ *      modeling/qwen3/mojo_qwen3_dense.py:84-123: `.item()` per sequence + Python slices of the free list).
+ *      extend: every sequence i with seq_lens[i] >= 0 and new_i > 0 (new_lens[i], or new_len_uniform when new_lens is NULL)
+ *      gains ceil((len+new)/page) - ceil(len/page) blocks, taken from the END of free_blocks[0 .. num_free) sequence by
+ *      sequence, written to block_table[i, ceil(len/page) ...] — the tables the reference would build, entry for entry.
+ *      pool_state int32[4] = {num_free, error, high-water of used blocks, 0}; when the blocks (error 1) or the table
+ *      columns (error 2) do not suffice the launch changes nothing and sets `error` (sticky; the host resets it).
+ *      store_ctx_out (nullable, int32 [batch]) receives the `context_kv_lens` the KV store must be called with: the
+ *      row's length before the append, or -1 (= skip, kv_cache.py:56-74) for rows that append nothing / a refused launch.
+ *      advance: seq_lens[i] += new_i for the same rows (no-op while `error` is set).  No host sync: capturable.        */
+int mojo_hip_page_pool_extend(int32_t* block_table, int64_t block_table_stride, int64_t max_blocks_per_seq,
+                              const int32_t* seq_lens, const int32_t* new_lens, int64_t new_len_uniform,
+                              const int32_t* free_blocks, int32_t* pool_state, int32_t* store_ctx_out,
+                              int64_t batch, int64_t block_size, int64_t total_blocks,
+                              mojo_stream_t stream);
+int mojo_hip_page_pool_advance(int32_t* seq_lens, const int32_t* new_lens, int64_t new_len_uniform,
+                               const int32_t* pool_state, int64_t batch, mojo_stream_t stream);
+
 /* ---- MojoRotaryEmbedding (core/operators/position_embedding.py:9-95; replaces rot_pos_embed,
  *      backends/ttx/kernels/ilu/rope.py:634-675 — a host loop with .item() per sequence).
  *      mode 0: positions = position_ids[i];  mode 1: positions = i (padded prefill);
@@ -113,7 +133,12 @@ int mojo_hip_rotary_embedding(float* cos_out, float* sin_out, int64_t n_pos, int
 /* ---- MojoPagedDecodeGQA (core/operators/attention.py:113-232; replaces paged_attention_decode,
  *      backends/ttx/operators/attention.py:166-174).  Split-KV flash decoding; the q-heads of one
  *      kv-head share every K/V load.  layout_abab: 0 = "AABB", 1 = "ABAB".
- *      max_seq_len_hint <= 0: derive the split count from max_blocks_per_seq * block_size.       */
+ *      max_seq_len_hint <= 0: derive the split count from max_blocks_per_seq * block_size.  Lengths above
+ *      min(hint, block_size * max_blocks_per_seq) are truncated to that capacity (nothing is indexed past what
+ *      the launch was sized for).  leave_empty_rows: 0 = rows with total_seq_lens <= 0 are written as zeros (the
+ *      eager golden, attention.py:184-185); 1 = such rows of `out` are left untouched — the graph-replay contract
+ *      of padded rows (tests/accuracy/operators/test_attention.py:318-353; the reference's ILU kernel switches on
+ *      `not is_current_stream_capturing()`, backends/ttx/kernels/ilu/flash_attention.py:816,425-428).             */
 int64_t mojo_hip_paged_decode_gqa_workspace_bytes(int64_t batch, int64_t q_heads, int64_t kv_heads,
                                                   int64_t head_dim, int64_t block_size,
                                                   int64_t max_blocks_per_seq,
@@ -126,7 +151,7 @@ int mojo_hip_paged_decode_gqa(const void* query, const void* key_cache, const vo
                               int64_t block_table_stride, int64_t cache_block_stride,
                               int64_t cache_head_stride, int64_t cache_token_stride,
                               int64_t max_seq_len_hint, float softmax_scale, int layout_abab,
-                              int dtype, mojo_stream_t stream);
+                              int leave_empty_rows, int dtype, mojo_stream_t stream);
 
 /* ---- MojoGroupGemm (core/operators/gemm.py:59-124; replaces m_grouped_matmul,
  *      backends/ttx/operators/gemm.py:51-92).  out[rows of g] = input[rows of g] @ W[g];

@@ -8,6 +8,7 @@ registers the ``HIP<Op>`` backend classes.  Backend selection follows the refere
 from .core import *  # noqa: F401,F403
 from .core import __all__ as _core_all
 from . import backends  # noqa: F401  (registers HIP<Op> classes)
+from .paged_cache import PagedDummyCache  # noqa: E402  device-side block allocator
 
-__all__ = list(_core_all)
+__all__ = list(_core_all) + ["PagedDummyCache"]
 __version__ = "0.1.0"

@@ -49,9 +49,11 @@ SIGNATURES = {
     "mojo_hip_apply_rope": (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I64x3, _I64x3, _I64x3, _I64x3,
                                     _I, _I, c_int, _P]),
     "mojo_hip_rotary_embedding": (c_int, [_P, _P, _I, _I, c_int, _P, _P, _P, _I, _P, _P, _I, _P, c_float, _P]),
+    "mojo_hip_page_pool_extend": (c_int, [_P, _I, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "mojo_hip_page_pool_advance": (c_int, [_P, _P, _I, _P, _I, _P]),
     "mojo_hip_paged_decode_gqa_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I, _I, _I]),
     "mojo_hip_paged_decode_gqa": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
-                                          c_float, c_int, c_int, _P]),
+                                          c_float, c_int, c_int, c_int, _P]),
     "mojo_hip_paged_prefill_gqa": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                            c_float, c_int, c_int, _P]),
     "mojo_hip_group_gemm_workspace_bytes": (c_int64, [_I]),

@@ -16,8 +16,14 @@ def _validate_tables() -> bool:
     """Opt-in host check that reproduces the golden's ValueError for a row whose first page id is
     negative although its length is positive (`core/operators/attention.py:186-187`).  Off by default
     because it costs a device->host sync per call and cannot run under graph capture; without it such
-    a row is computed over zero K/V (the kernel's treatment of every negative page id)."""
+    a row is computed over zero K/V (the kernel's treatment of every negative page id).  The same switch checks the
+    ``max_total_seq_len`` / ``max_q_len`` hints against the device-side lengths (a length above its hint is truncated
+    to the hint by the kernels)."""
     return os.environ.get("MOJO_HIP_VALIDATE", "0") == "1"
+
+
+def _capturing(t: torch.Tensor) -> bool:
+    return t.is_cuda and torch.cuda.is_current_stream_capturing()
 
 
 def _check_cache_layout(key_cache, value_cache, what):
@@ -30,7 +36,7 @@ class HIPPagedDecodeGQA(MojoPagedDecodeGQA):
 
     def forward(self, query, key_cache, value_cache, total_seq_lens, block_tables,
                 softmax_scale: Optional[float] = None, mask: Optional[torch.Tensor] = None, *,
-                max_total_seq_len: Optional[int] = None):
+                max_total_seq_len: Optional[int] = None, leave_empty_rows: Optional[bool] = None):
         assert_paged_decode_contract(block_tables, total_seq_lens)
         if not self.is_causal or mask is not None:
             raise NotImplementedError("HIPPagedDecodeGQA supports causal attention without an explicit mask only")
@@ -43,6 +49,8 @@ class HIPPagedDecodeGQA(MojoPagedDecodeGQA):
         if _validate_tables() and batch > 0 and block_tables.shape[1] > 0:
             if bool(((total_seq_lens > 0) & (block_tables[:, 0] < 0)).any()):
                 raise ValueError("Paged decode requires a valid block table for rows with kv lens > 0.")
+            if max_total_seq_len is not None and int(total_seq_lens.max()) > int(max_total_seq_len):
+                raise ValueError("HIPPagedDecodeGQA: a total_seq_lens entry exceeds max_total_seq_len")
         q = query if query.is_contiguous() else query.contiguous()
         tables = block_tables if block_tables.stride(1) == 1 else block_tables.contiguous()
         lens = total_seq_lens if total_seq_lens.is_contiguous() else total_seq_lens.contiguous()
@@ -56,6 +64,8 @@ class HIPPagedDecodeGQA(MojoPagedDecodeGQA):
             L.ptr(q), L.ptr(key_cache), L.ptr(value_cache), L.ptr(lens), L.ptr(tables), L.ptr(out), L.ptr(ws),
             ws.numel(), batch, hq, hkv, dim, page, tables.shape[1], tables.stride(0), key_cache.stride(0),
             key_cache.stride(1), key_cache.stride(2), hint, scale, 1 if self.gqa_layout == "ABAB" else 0,
+            # replay contract of padded rows (seq_len <= 0): untouched while a graph is being captured, zeros eagerly
+            1 if (_capturing(q) if leave_empty_rows is None else leave_empty_rows) else 0,
             L.dtype_code(q.dtype), L.stream_of(q)), "HIPPagedDecodeGQA")
         return out
 

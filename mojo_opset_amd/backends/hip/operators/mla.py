@@ -1,5 +1,6 @@
 """HIP<Op> classes of the paged MLA pair (weight-absorbed formulation, see csrc/mla_attn.hip)."""
 import math
+import os
 from typing import Optional
 
 import torch
@@ -26,14 +27,44 @@ def _per_head_gemm(x: torch.Tensor, lda: int, out: torch.Tensor, proj: torch.Ten
 
 
 def _absorbed_k_major(op, proj: torch.Tensor, heads: int, nope: int, vdim: int, r: int) -> torch.Tensor:
-    """``W_kn[h]^T`` for every head, contiguous ``[H, r, nope]`` (weight repacking, not per-call compute)."""
-    key = (proj.data_ptr(), proj._version, proj.dtype, str(proj.device))
+    """``W_kn[h]^T`` for every head, contiguous ``[H, r, nope]`` (weight repacking, not per-call compute).
+
+    The copy is keyed on the parameter's storage, version counter, dtype and device, and dropped by everything that goes
+    through ``nn.Module`` machinery (``.to()/.cuda()/.half()`` -> ``_apply``, ``load_state_dict``).  A write that bypasses
+    the version counter (``param.data.copy_(w)``, a raw pointer write) is invisible to those: call
+    ``op.refresh_weights()`` after such an update.  ``MOJO_HIP_VALIDATE=1`` compares the copy with the live parameter
+    on every call (one device->host sync) and raises if it is stale."""
+    src = op.kv_b_proj                      # (``proj`` may be a per-call contiguous copy of a strided parameter)
+    key = (src.data_ptr(), src._version, src.dtype, str(src.device), tuple(src.stride()))
     cached = getattr(op, "_hip_w_kn_t", None)
     if cached is None or cached[0] != key:
         w = proj.view(heads, nope + vdim, r)[:, :nope, :].transpose(1, 2).contiguous()
         cached = (key, w)
         op._hip_w_kn_t = cached
+    elif os.environ.get("MOJO_HIP_VALIDATE", "0") == "1":
+        live = proj.view(heads, nope + vdim, r)[:, :nope, :].transpose(1, 2)
+        if not torch.equal(cached[1], live):
+            raise RuntimeError("HIP MLA: kv_b_proj changed without a version bump (e.g. through .data); call "
+                               "op.refresh_weights() after such an update")
     return cached[1]
+
+
+class _AbsorbedWeightCache:
+    """Mixin of the two HIP MLA classes: lifetime of the repacked ``W_kn`` copy (see `_absorbed_k_major`)."""
+
+    def refresh_weights(self) -> None:
+        """Drop the K-major copy of the absorbed key projection; the next decode-sized call rebuilds it."""
+        self._hip_w_kn_t = None
+
+    # (explicit base calls, not zero-argument super(): mojo_opset_amd.plugin re-bases these functions onto the
+    # reference's classes, where the defining class is no longer in the instance's MRO)
+    def _apply(self, fn, *args, **kwargs):
+        self._hip_w_kn_t = None
+        return torch.nn.Module._apply(self, fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._hip_w_kn_t = None
+        return torch.nn.Module._load_from_state_dict(self, *args, **kwargs)
 
 
 def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *, total_seq_lens=None, cu_q_lens=None,
@@ -51,7 +82,8 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     assert ckv_cache.shape[:3] == kpe_cache.shape[:3]
     if ckv_cache.stride(3) != 1 or kpe_cache.stride(3) != 1:
         raise NotImplementedError("hip mla: caches must be dense in their last dimension")
-    proj = proj if proj.is_contiguous() else proj.contiguous()
+    if not proj.is_contiguous():           # (a strided parameter is copied per call; the repack cache is keyed on the original)
+        proj = proj.contiguous()
     page = ckv_cache.shape[2]
     scale = 1.0 / math.sqrt(nope + rope) if softmax_scale is None else float(softmax_scale)
     dev = query.device
@@ -97,7 +129,7 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     return out
 
 
-class HIPPagedDecodeMLA(MojoPagedDecodeMLA):
+class HIPPagedDecodeMLA(_AbsorbedWeightCache, MojoPagedDecodeMLA):
     supported_platforms_list = _ROCM
 
     def forward(self, query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables,
@@ -107,7 +139,7 @@ class HIPPagedDecodeMLA(MojoPagedDecodeMLA):
                             total_seq_lens=total_seq_lens)
 
 
-class HIPPagedPrefillMLA(MojoPagedPrefillMLA):
+class HIPPagedPrefillMLA(_AbsorbedWeightCache, MojoPagedPrefillMLA):
     supported_platforms_list = _ROCM
 
     def forward(self, query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables,

@@ -8,7 +8,7 @@ import torch
 from ....core.operators.activation import MojoSwiGLU
 from ....core.operators.kv_cache import (MojoStorePagedKVCache, MojoStorePagedMLAKVCache,
                                            assert_paged_kv_layout_contract)
-from ....core.operators.normalization import MojoResidualAddRMSNorm, MojoRMSNorm
+from ....core.operators.normalization import MojoResidualAddRMSNorm, MojoRMSNorm, MojoRMSNormInplace
 from ....core.operators.position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
 from .. import lib as L
 
@@ -33,7 +33,7 @@ class HIPSwiGLU(MojoSwiGLU):
         return out
 
 
-def _rmsnorm(hidden, residual, weight, eps, want_sum):
+def _rmsnorm(hidden, residual, weight, eps, want_sum, out=None):
     L.require_cuda(hidden, residual, weight)
     if weight.dtype != hidden.dtype or (residual is not None and residual.dtype != hidden.dtype):
         raise NotImplementedError("hip rmsnorm: hidden, residual and weight must share one dtype")
@@ -43,7 +43,7 @@ def _rmsnorm(hidden, residual, weight, eps, want_sum):
     assert weight.shape == (dim,), f"weight shape {tuple(weight.shape)} does not match hidden size {dim}"
     h = _dense(hidden)
     r = None if residual is None else _dense(residual)
-    normed = torch.empty_like(h)
+    normed = torch.empty_like(h) if out is None else out
     summed = torch.empty_like(h) if want_sum else None
     rows = h.numel() // dim if dim else 0
     L.check(L.load().mojo_hip_residual_add_rmsnorm(L.ptr(h), L.ptr(r), L.ptr(_dense(weight.detach())), L.ptr(normed),
@@ -57,6 +57,22 @@ class HIPRMSNorm(MojoRMSNorm):
 
     def forward(self, hidden_state: torch.Tensor) -> torch.Tensor:
         return _rmsnorm(hidden_state, None, self.weight, self.variance_epsilon, False)[0]
+
+
+class HIPRMSNormInplace(MojoRMSNormInplace):
+    """``inplace=True``: the kernel's output pointer IS the input (each thread reads its elements of a row before the
+    row's reduction and writes the same elements after it, so no element is read after it was overwritten)."""
+
+    supported_platforms_list = _ROCM
+
+    def forward(self, hidden_state: torch.Tensor) -> torch.Tensor:
+        if not self.inplace:
+            return _rmsnorm(hidden_state, None, self.weight, self.variance_epsilon, False)[0]
+        if hidden_state.is_contiguous():
+            _rmsnorm(hidden_state, None, self.weight, self.variance_epsilon, False, out=hidden_state)
+        else:                                # a strided view (e.g. the q slice of a fused qkv): normalise a dense copy, write back
+            hidden_state.copy_(_rmsnorm(hidden_state, None, self.weight, self.variance_epsilon, False)[0])
+        return hidden_state
 
 
 class HIPResidualAddRMSNorm(MojoResidualAddRMSNorm):

@@ -5,7 +5,7 @@ from .gemm import MojoGroupGemm, MojoQuantGemm
 from .kv_cache import MojoStorePagedKVCache, MojoStorePagedMLAKVCache, build_paged_kv_chunk_metadata
 from .mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
 from .moe import MojoExperts, MojoMoE, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
-from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm
+from .normalization import MojoResidualAddRMSNorm, MojoRMSNorm, MojoRMSNormInplace
 from .position_embedding import MojoApplyRoPE, MojoRotaryEmbedding
 from .quantize import MojoDynamicQuant, MojoResidualAddRMSNormQuant
 
@@ -13,6 +13,6 @@ __all__ = [
     "MojoSwiGLU", "MojoPagedDecodeGQA", "MojoPagedPrefillGQA", "MojoAllGatherGemm", "MojoGemmAll2All",
     "MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoGroupGemm", "MojoQuantGemm", "MojoStorePagedKVCache",
     "build_paged_kv_chunk_metadata", "MojoPagedDecodeMLA", "MojoPagedPrefillMLA", "MojoResidualAddRMSNorm",
-    "MojoRMSNorm", "MojoApplyRoPE", "MojoRotaryEmbedding", "MojoMoEGating", "MojoMoEDispatch", "MojoExperts",
+    "MojoRMSNorm", "MojoRMSNormInplace", "MojoApplyRoPE", "MojoRotaryEmbedding", "MojoMoEGating", "MojoMoEDispatch", "MojoExperts",
     "MojoMoECombine", "MojoMoE", "MojoDynamicQuant", "MojoResidualAddRMSNormQuant", "MojoStorePagedMLAKVCache",
 ]

@@ -1,7 +1,8 @@
-"""API classes `MojoRMSNorm` / `MojoResidualAddRMSNorm`.
+"""API classes `MojoRMSNorm` / `MojoResidualAddRMSNorm` and `MojoRMSNormInplace` (§8 f3).
 
 Follows `mojo_opset/core/operators/normalization.py` (:71-111, :308-362): one learnable
-``weight [norm_size]`` created with the factory kwargs; ``norm_pos`` in {"pre","post"}.
+``weight [norm_size]`` created with the factory kwargs; ``norm_pos`` in {"pre","post"}; and
+`mojo_opset/experimental/operators/normalization.py:95-140` for the in-place variant.
 """
 import torch
 
@@ -19,6 +20,22 @@ class MojoRMSNorm(MojoOperator):
 
     def extra_repr(self) -> str:
         return f"norm_size={self.norm_size!r}, variance_epsilon={self.variance_epsilon!r}"
+
+
+class MojoRMSNormInplace(MojoOperator):
+    """forward(hidden_state [..., D]) -> rms_norm(hidden_state); with ``inplace=True`` the result is written back into
+    ``hidden_state`` and that same tensor is returned (`experimental/operators/normalization.py:95-140`; the q/k-norm in
+    front of RoPE in the Qwen3 stack, `modeling/qwen3/mojo_qwen3_dense.py:229-233`)."""
+
+    def __init__(self, norm_size: int, eps: float = 1e-5, inplace: bool = False, **kwargs):
+        super().__init__(**kwargs)
+        self.norm_size = norm_size
+        self.weight = torch.nn.Parameter(torch.empty(norm_size, **self.tensor_factory_kwargs))
+        self.variance_epsilon = eps
+        self.inplace = inplace
+
+    def extra_repr(self) -> str:
+        return f"norm_size={self.norm_size!r}, variance_epsilon={self.variance_epsilon!r}, inplace={self.inplace!r}"
 
 
 class MojoResidualAddRMSNorm(MojoOperator):

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include <type_traits>
 #include <utility>
 
@@ -182,6 +184,16 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// True the first time it is called on each device (per call site: pass a function-local static mask).  Used for
+// hipFuncSetAttribute, which applies to the kernel object of the CURRENT device only: a process driving several GPUs
+// must set it once per device, and the flag must be safe against concurrent callers.
+inline bool first_call_on_device(std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = uint64_t{1} << (dev & 63);
+  return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
 }
 
 }  // namespace mojo

@@ -68,9 +68,15 @@ __host__ __device__ inline int map_row(int m, int rc, int ml, int off, int mul =
 
 constexpr int GEMM_WS_INTS(int G) { return 2 * (G + 1); }
 
+// rows [sum(counts), m_total) of C (identity row map) to be zeroed by the prefix kernel; C == nullptr: nothing
+struct GemmTail {
+  void* C = nullptr;
+  long long ld_bytes = 0, row_bytes = 0;
+};
+
 // fills row_start / tile_start for tile height bm from int32 or int64 row counts
 int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
-                        int32_t* tile_start, hipStream_t s);
+                        int32_t* tile_start, hipStream_t s, GemmTail tail = GemmTail());
 
 // fast MFMA path (256x256x64 tiles); returns MOJO_EUNSUPPORTED when its preconditions do not hold
 int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);

@@ -592,13 +592,13 @@ inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hi
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
   if (a.w_n == 1) {
     auto* fn = gemm256_kernel<P, true, Epi>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); done = true; }
+    static std::atomic<uint64_t> attr_set{0};
+    if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
   } else {
     auto* fn = gemm256_kernel<P, false, Epi>;
-    static bool done = false;
-    if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); done = true; }
+    static std::atomic<uint64_t> attr_set{0};
+    if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
   }
   MOJO_CHECK_LAUNCH("gemm256");

@@ -53,7 +53,10 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
     a.uniform_rows = static_cast<int>(m_total / num_groups);
   } else {
     const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
-    int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s);
+    GemmTail tail;
+    const int64_t elt = dtype == MOJO_F32 ? 4 : 2;
+    if (!c_map) { tail.C = out; tail.ld_bytes = ldc * elt; tail.row_bytes = n * elt; }
+    int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s, tail);
     if (rc) return rc;
   }
   return run_gemm(a, dtype, m_total, s);
@@ -91,7 +94,9 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + (num_groups + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, 256, m_total, ws, ws + (num_groups + 1), s);
+  GemmTail tail;
+  tail.C = out; tail.ld_bytes = inter * 2; tail.row_bytes = inter * 2;
+  int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, 256, m_total, ws, ws + (num_groups + 1), s, tail);
   if (rc) return rc;
   return launch_gemm_mfma256(a, dtype, m_total, s);
 }

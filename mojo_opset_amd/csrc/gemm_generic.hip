@@ -9,7 +9,7 @@ namespace mojo {
 // tile counts (tile_start).  Counts are clamped so that no row beyond m_total is ever addressed.
 template <typename IdxT>
 __global__ __launch_bounds__(256) void prefix_kernel(const IdxT* counts, int G, int bm, long long m_total,
-                                                     int32_t* row_start, int32_t* tile_start) {
+                                                     int32_t* row_start, int32_t* tile_start, GemmTail tail) {
   __shared__ long long s_rows[256];
   __shared__ long long s_tiles[256];
   __shared__ long long carry[2];
@@ -57,21 +57,31 @@ __global__ __launch_bounds__(256) void prefix_kernel(const IdxT* counts, int G, 
     }
     __syncthreads();
   }
+  const long long e = carry[0] > m_total ? m_total : carry[0];
   if (tid == 0) {
-    long long e = carry[0] > m_total ? m_total : carry[0];
     row_start[G] = static_cast<int32_t>(e);
     tile_start[G] = static_cast<int32_t>(carry[1]);
+  }
+  // Rows behind the last group (sum(counts) < m_total) belong to no product: the golden does not return them
+  // (core/operators/gemm.py:111-117 concatenates the groups), the caller's [m_total, N] buffer reads as zeros there.
+  // Normally there are none and this loop does not run; the GEMM launch never touches these rows, so no ordering issue.
+  if (tail.C && e < m_total) {
+    const long long halves = tail.row_bytes >> 1;
+    for (long long i = tid; i < (m_total - e) * halves; i += 256) {
+      const long long r = e + i / halves, c = i % halves;
+      *reinterpret_cast<uint16_t*>(static_cast<char*>(tail.C) + r * tail.ld_bytes + c * 2) = 0;
+    }
   }
 }
 
 int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
-                        int32_t* tile_start, hipStream_t s) {
+                        int32_t* tile_start, hipStream_t s, GemmTail tail) {
   if (counts_are_i64)
     hipLaunchKernelGGL(prefix_kernel<int64_t>, dim3(1), dim3(256), 0, s, static_cast<const int64_t*>(counts), G, bm,
-                       static_cast<long long>(m_total), row_start, tile_start);
+                       static_cast<long long>(m_total), row_start, tile_start, tail);
   else
     hipLaunchKernelGGL(prefix_kernel<int32_t>, dim3(1), dim3(256), 0, s, static_cast<const int32_t*>(counts), G, bm,
-                       static_cast<long long>(m_total), row_start, tile_start);
+                       static_cast<long long>(m_total), row_start, tile_start, tail);
   MOJO_CHECK_LAUNCH("group_prefix");
   return MOJO_OK;
 }

@@ -385,8 +385,8 @@ static int launch_mla(const MlaArgs& a, hipStream_t s) {
   typedef mla_geom<R, ROPE> GE;
   constexpr int NQ = 1;
   auto* fn = mla_latent_kernel<T, R, ROPE, NQ>;
-  static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, GE::LDS_BYTES); done = true; }
+  static std::atomic<uint64_t> attr_set{0};
+  if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, GE::LDS_BYTES);
   hipLaunchKernelGGL(fn, dim3(a.n_tiles, a.n_splits), dim3(512 / NQ), GE::LDS_BYTES, s, a);
   MOJO_CHECK_LAUNCH("mla_latent");
   if (a.n_splits > 1) {

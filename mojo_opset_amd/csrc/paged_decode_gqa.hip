@@ -58,10 +58,26 @@ struct DecodeArgs {
   float* ws_ml;      // [B*Hkv][chunks][G][2]  (running max in log2 units, running sum)
   int hq, hkv, dim, page, page_shift, max_pages;
   int64_t table_stride, c_blk, c_head, c_tok;
-  int chunk_tokens, n_chunks;
+  int chunk_tokens, n_chunks;     // launch-wide bound: no sequence is cut into more than n_chunks pieces of <= chunk_tokens
   float scale_log2;
   int abab;
+  int leave_empty;                // rows with seq_len <= 0: 1 = leave the output row untouched (graph replay contract), 0 = zeros
 };
+
+// Chunking is PER SEQUENCE: a sequence of `len` tokens is cut into n_chunks equal pieces (whole tiles, at least 128 tokens,
+// never more than the launch-wide chunk_tokens), so the waves of a short row of a ragged batch all work (and finish early)
+// instead of some of them idling while the others walk max_len / n_chunks tokens.  Lengths beyond what the launch was sized
+// for (the caller's max_total_seq_len hint, or page * max_blocks) are truncated to that capacity: the grid, the LDS image and
+// the workspace hold n_chunks slots per row and nothing may index past them.
+__device__ __forceinline__ int decode_seq_len(const DecodeArgs& a, int b) {
+  return min(a.seq_lens[b], a.n_chunks * a.chunk_tokens);
+}
+__device__ __forceinline__ int decode_seq_chunk(const DecodeArgs& a, int seq_len) {
+  int c = (seq_len + a.n_chunks - 1) / a.n_chunks;
+  c = max(c, 128);
+  c = ((c + DEC_TILE - 1) / DEC_TILE) * DEC_TILE;
+  return min(c, a.chunk_tokens);
+}
 
 // FUSED: one workgroup = all chunks of one (sequence, kv-head), one wave per chunk (n_chunks <= 8); the partial states
 // meet in LDS and the workgroup writes the final output itself — no partials in HBM, no merge launch.
@@ -77,11 +93,12 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
   const int b = blockIdx.y / a.hkv;
   const int kvh = blockIdx.y % a.hkv;
 
-  const int seq_len = a.seq_lens[b];
-  const int tok_begin = chunk * a.chunk_tokens;
+  const int seq_len = decode_seq_len(a, b);
+  const int chunk_tokens = decode_seq_chunk(a, seq_len);
+  const int tok_begin = chunk * chunk_tokens;
   const bool has_work = seq_len > 0 && tok_begin < seq_len;
   if (!FUSED && !has_work) return;
-  const int tok_end = has_work ? min(seq_len, tok_begin + a.chunk_tokens) : tok_begin + 1;
+  const int tok_end = has_work ? min(seq_len, tok_begin + chunk_tokens) : tok_begin + 1;
   const bool dim_ok = j * 8 < a.dim;
   const int jd = dim_ok ? j * 8 : a.dim - 8;          // lanes past a short head re-read its last slice
 
@@ -260,7 +277,8 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
     }
     __syncthreads();
     // every thread of the workgroup takes (head g, 4 output elements) items
-    const int n_chunks_seq = seq_len <= 0 ? 0 : min((seq_len + a.chunk_tokens - 1) / a.chunk_tokens, static_cast<int>(blockDim.x >> 6));
+    const int n_chunks_seq = seq_len <= 0 ? 0 : min((seq_len + chunk_tokens - 1) / chunk_tokens, static_cast<int>(blockDim.x >> 6));
+    if (n_chunks_seq == 0 && a.leave_empty) return;      // (uniform over the workgroup, after its only barrier)
     const int per_head = a.dim / 4;
     typedef typename vec_of<T, 4>::type V4;
     for (int item = threadIdx.x; item < G * per_head; item += blockDim.x) {
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
     return;
   }
   if (r != 0 || !dim_ok) return;
-  const int n_chunks_seq = (seq_len + a.chunk_tokens - 1) / a.chunk_tokens;
+  const int n_chunks_seq = (seq_len + chunk_tokens - 1) / chunk_tokens;
   if (n_chunks_seq == 1) {
     // single chunk: finish here, the merge kernel skips this row
 #pragma unroll
@@ -319,8 +337,9 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int G) {
   const int b = blockIdx.x / a.hkv;
   const int kvh = blockIdx.x % a.hkv;
   const int g = blockIdx.y;
-  const int seq_len = a.seq_lens[b];
-  const int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + a.chunk_tokens - 1) / a.chunk_tokens;
+  const int seq_len = decode_seq_len(a, b);
+  const int chunk_tokens = decode_seq_chunk(a, seq_len);
+  const int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + chunk_tokens - 1) / chunk_tokens;   // <= a.n_chunks by construction
   if (n_chunks_seq == 1) return;
   const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
   const int d0 = threadIdx.x * 4;
@@ -328,6 +347,7 @@ __global__ __launch_bounds__(64) void decode_merge_kernel(DecodeArgs a, int G) {
   T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + d0;
   typedef typename vec_of<T, 4>::type V4;
   if (n_chunks_seq == 0) {
+    if (a.leave_empty) return;
     V4 z = {};
     *reinterpret_cast<V4*>(dst) = z;
     return;
@@ -435,7 +455,7 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
                                          int64_t max_blocks_per_seq, int64_t block_table_stride,
                                          int64_t cache_block_stride, int64_t cache_head_stride,
                                          int64_t cache_token_stride, int64_t max_seq_len_hint, float softmax_scale,
-                                         int layout_abab, int dtype, mojo_stream_t stream) {
+                                         int layout_abab, int leave_empty_rows, int dtype, mojo_stream_t stream) {
   if (batch == 0) return MOJO_OK;
   MOJO_REQUIRE(query && key_cache && value_cache && total_seq_lens && block_tables && out, MOJO_EINVAL,
                "paged_decode_gqa: null pointer");
@@ -466,6 +486,7 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
   a.n_chunks = static_cast<int>(ceil_div(max_len > 0 ? max_len : 1, a.chunk_tokens));
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.abab = layout_abab ? 1 : 0;
+  a.leave_empty = leave_empty_rows ? 1 : 0;
   const int G = static_cast<int>(q_heads / kv_heads);
   const int64_t slots = batch * kv_heads * a.n_chunks * G;
   const int64_t need = slots * (head_dim + 2) * static_cast<int64_t>(sizeof(float));

@@ -135,19 +135,25 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
-  if (qb * QPB >= q_len) return;
-  if (kv_len <= 0) {                                     // a sequence without keys: its rows read as zeros
+  // rows [pos0, pos1) of this sequence, the G heads of this kv-head, written as zeros
+  auto zero_rows = [&](int pos0, int pos1) {
     typedef typename vec_of<T, 8>::type V8;
     V8 z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = static_cast<T>(0.f);
     const int chunks8 = a.dim / 8;
-    const int n_pos = min(q_len - qb * QPB, QPB);
-    for (int i = threadIdx.x; i < n_pos * G * chunks8; i += 256) {
-      const int c = i % chunks8, g = (i / chunks8) % G, pos = qb * QPB + i / (chunks8 * G);
+    for (int i = threadIdx.x; i < (pos1 - pos0) * G * chunks8; i += 256) {
+      const int c = i % chunks8, g = (i / chunks8) % G, pos = pos0 + i / (chunks8 * G);
       const int head = a.abab ? g * a.hkv + kvh : kvh * G + g;
       *reinterpret_cast<V8*>(static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + pos) * a.hq + head) * a.dim + c * 8) = z;
     }
+  };
+  // A sequence longer than the caller's max_q_len hint has rows no query block of this launch covers: they are written
+  // as zeros (never left uninitialised) by the workgroup of the sequence's last covered block.
+  if (qb == a.n_qb - 1 && q_len > a.n_qb * QPB) zero_rows(a.n_qb * QPB, q_len);
+  if (qb * QPB >= q_len) return;
+  if (kv_len <= 0) {                                     // a sequence without keys: its rows read as zeros
+    zero_rows(qb * QPB, min(q_len, (qb + 1) * QPB));
     return;
   }
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
@@ -615,8 +621,8 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 template <typename T, int G, int DK>
 static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
   auto* fn = prefill_kernel<T, G, DK>;
-  static bool done = false;
-  if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS); done = true; }
+  static std::atomic<uint64_t> attr_set{0};
+  if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
   hipLaunchKernelGGL(fn, grid, dim3(256), PF_LDS, s, a);
 }
 

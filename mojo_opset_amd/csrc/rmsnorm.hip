@@ -13,8 +13,9 @@
 namespace mojo {
 
 template <typename T, int VEC, int TPR, int CACHE /* vectors cached per thread */>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ hidden, const T* __restrict__ residual,
-                                                      const T* __restrict__ weight, T* __restrict__ normed,
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const T* hidden /* may alias normed (in-place norm) */,
+                                                      const T* __restrict__ residual,
+                                                      const T* __restrict__ weight, T* normed,
                                                       T* __restrict__ summed, int64_t rows, int dim, float eps) {
   typedef typename vec_of<T, VEC>::type V;
   constexpr int ROWS_PER_BLOCK = 256 / TPR;

@@ -217,6 +217,14 @@ def gen_norm():
             w = torch.randn(d, dtype=dtype)
             recs.append(run_case("MojoRMSNorm", {"kwargs": {"norm_size": d, "eps": 1e-6, "dtype": dtype}},
                                  {"weight": w}, (x,), {}))
+            # experimental/operators/normalization.py:95-140 (q/k-norm of the Qwen3 stack: [T, heads, head_dim])
+            for inplace in (False, True):
+                torch.manual_seed(470 + ci)
+                x = torch.randn(rows, 4, d // 4 if d % 4 == 0 else d, dtype=dtype)
+                w = torch.randn(x.shape[-1], dtype=dtype)
+                recs.append(run_case("MojoRMSNormInplace",
+                                     {"kwargs": {"norm_size": x.shape[-1], "eps": 1e-6, "inplace": inplace, "dtype": dtype}},
+                                     {"weight": w}, (x,), {}))
     return recs
 
 
@@ -554,6 +562,56 @@ def gen_comm():
     return cases
 
 
+def gen_paged_cache():
+    """The reference's `PagedDummyCache` (modeling/qwen3/mojo_qwen3_dense.py:41-135) driven through a prefill and decode
+    steps on two layers; records every update's inputs and the state after it.  The restatement
+    (oracle/paged_cache_ref.py) must end in the identical state after every step."""
+    from types import SimpleNamespace
+
+    from mojo_opset.modeling.qwen3.mojo_qwen3_dense import PagedDummyCache as RefCache
+
+    from oracle.paged_cache_ref import PagedDummyCacheRef
+
+    recs = []
+    for ci, (layers, heads, dim, max_pos, batch, page, steps) in enumerate([
+        (2, 2, 16, 64, 3, 8, [5, 1, 1, 1, 1, 7, 1]), (1, 4, 32, 96, 5, 16, [16, 1, 1, 33, 1]), (3, 1, 8, 40, 2, 4, [3, 1, 1, 1, 1, 1, 1]),
+    ]):
+        torch.manual_seed(1700 + ci)
+        cfg = SimpleNamespace(num_hidden_layers=layers, num_key_value_heads=heads, head_dim=dim, max_position_embeddings=max_pos)
+        ref = RefCache(cfg, batch, "cpu", block_size=page)
+        mine_ = PagedDummyCacheRef(layers, heads, dim, max_pos, batch, block_size=page)
+        trace = []
+        for si, new_len in enumerate(steps):
+            for layer in range(layers):
+                k = torch.randn(batch, heads, new_len, dim).to(torch.bfloat16)
+                v = torch.randn(batch, heads, new_len, dim).to(torch.bfloat16)
+                ref.update(k.clone(), v.clone(), layer)
+                mine_.update(k.clone(), v.clone(), layer)
+                for a, b in ((ref.block_tables, mine_.block_tables), (ref.seq_lens, mine_.seq_lens), (ref.k_cache, mine_.k_cache),
+                             (ref.v_cache, mine_.v_cache)):
+                    if not torch.equal(a, b):
+                        raise SystemExit("restatement of PagedDummyCache is NOT identical to the reference")
+                assert ref.num_free_blocks == mine_.num_free_blocks
+                dk, dv, dt = ref.get_kv_for_decode(layer)
+                mk, mv, mt = mine_.get_kv_for_decode(layer)
+                assert torch.equal(dt, mt)
+                trace.append({"layer": layer, "k": k, "v": v, "block_tables": ref.block_tables.clone(), "seq_lens": ref.seq_lens.clone(),
+                              "num_free": ref.num_free_blocks, "decode_table": dt.clone()})
+        recs.append({"op": "PagedDummyCache", "config": dict(num_hidden_layers=layers, num_key_value_heads=heads, head_dim=dim,
+                                                             max_position_embeddings=max_pos),
+                     "batch": batch, "block_size": page, "trace": trace, "k_cache": ref.k_cache.clone(), "v_cache": ref.v_cache.clone()})
+    # exhaustion: the reference raises ValueError (:78-79)
+    cfg = SimpleNamespace(num_hidden_layers=1, num_key_value_heads=1, head_dim=8, max_position_embeddings=8)
+    ref = RefCache(cfg, 2, "cpu", block_size=4)
+    ref.update(torch.zeros(2, 1, 8, 8, dtype=torch.bfloat16), torch.zeros(2, 1, 8, 8, dtype=torch.bfloat16), 0)
+    try:
+        ref.update(torch.zeros(2, 1, 1, 8, dtype=torch.bfloat16), torch.zeros(2, 1, 1, 8, dtype=torch.bfloat16), 0)
+        raise SystemExit("reference did not raise on exhaustion")
+    except ValueError as e:
+        recs.append({"op": "PagedDummyCache.oom", "message": str(e)})
+    return recs
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -561,7 +619,7 @@ def main():
         "paged_decode_gqa": gen_decode_gqa, "paged_prefill_gqa": gen_prefill_gqa, "paged_mla": gen_mla, "rmsnorm": gen_norm,
         "swiglu": gen_swiglu, "rope": gen_rope, "group_gemm": gen_group_gemm, "quant_gemm": gen_quant_gemm, "moe": gen_moe,
         "moe_layer": gen_moe_layer, "quantizers": gen_quantizers, "store_paged_mla": gen_store_mla,
-        "compute_with_comm": gen_comm,
+        "compute_with_comm": gen_comm, "paged_cache": gen_paged_cache,
     }
     only = set(sys.argv[1:])                       # `python oracle/make_golden.py moe_layer` regenerates just that group
     groups = {name: make() for name, make in makers.items() if not only or name in only}

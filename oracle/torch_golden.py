@@ -26,7 +26,7 @@ _CPU = ["rocm", "cpu"]
 
 __all__ = [
     "TorchPagedDecodeGQA", "TorchPagedPrefillGQA", "TorchPagedDecodeMLA", "TorchPagedPrefillMLA",
-    "TorchRMSNorm", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
+    "TorchRMSNorm", "TorchRMSNormInplace", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
     "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
     "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
     "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine", "TorchMoE", "TorchDynamicQuant",
@@ -266,6 +266,19 @@ class TorchRMSNorm(_norm.MojoRMSNorm):
 
     def forward(self, hidden_state):
         return F.rms_norm(hidden_state, [hidden_state.shape[-1]], weight=self.weight, eps=self.variance_epsilon)
+
+
+class TorchRMSNormInplace(_norm.MojoRMSNormInplace):
+    """`experimental/operators/normalization.py:118-140`."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, hidden_state):
+        normalized = F.rms_norm(hidden_state, [hidden_state.shape[-1]], weight=self.weight, eps=self.variance_epsilon)
+        if self.inplace:
+            hidden_state.copy_(normalized)
+            return hidden_state
+        return normalized
 
 
 class TorchResidualAddRMSNorm(_norm.MojoResidualAddRMSNorm):

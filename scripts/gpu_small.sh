@@ -7,10 +7,3 @@ from benchmarks.extras import bench_moe
 r = bench_moe(torch.device('cuda', 0))
 print("ragged", {k: round(v["us"], 1) for k, v in r.items()}, r["moe_layer_decode_T64_E64_k8_H4096_I2048"])
 PY
-MOJO_HIP_GEMM_RAGGED_SKINNY=0 python - <<'PY'
-import json, torch, sys, os
-sys.path.insert(0, '.')
-from benchmarks.extras import bench_moe
-r = bench_moe(torch.device('cuda', 0))
-print("tile256", r["moe_layer_decode_T64_E64_k8_H4096_I2048"])
-PY

@@ -1,0 +1,158 @@
+"""One rank of the multi-process GPU test of the GEMM + collective operators (tests/test_hip_comm_ranks.py starts
+``WORLD_SIZE`` copies of this script as child processes).
+
+The test box has ONE MI355X, and RCCL refuses two ranks on one device, so the ranks share ``cuda:0`` and the process
+group is gloo (device tensors are staged by gloo) — the same arrangement the reference uses when it runs these ops
+on a host without its vendor collective library (`tests/dist_common.py:38-81`).  What runs is the product path:
+`HIP<Op>.forward` -> `mojo_opset_amd.comm` pipelines -> `mojo_hip_gemm_rowmap` through the C ABI, chunked, with the
+exchange step on the process group; with ``MOJO_HIP_COMM_DIRECT=1`` the all-reduce / reduce-scatter exchange is this
+repository's own pull-and-add kernel over HIP-IPC peer buffers instead.
+
+Checks (reference: tests/accuracy/operators/test_compute_with_comm.py):
+  * the reference's per-rank vectors (tests/golden/compute_with_comm.pt) at the reference's bounds (5e-3 / 1e-4);
+  * the oracle classes running over the same gloo group on CPU copies of the same per-rank inputs, at the
+    reference's shapes and seeds (:97-103, :141-146, :180-185, :215-247).
+Writes one JSON line per check to stdout; exits non-zero on the first failure.
+"""
+import json
+import os
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+DEV = "cuda"
+
+
+def _ulps(got, want):
+    from hip_utils import max_ulp_bf16ish
+    return max_ulp_bf16ish(got, want, atol=1e-3)
+
+
+def _report(rank, **kw):
+    if rank == 0:
+        print(json.dumps(kw), flush=True)
+
+
+def _compare(rank, name, got, want, tol):
+    """The reference's bound is atol = rtol = tol.  Both sides round each rank's product to the storage type and then
+    sum storage-type values, so they can differ only where the fp32 accumulation order flips a rounding: at most one
+    unit in the last place.  For bf16 one ulp is 0.39-0.78 % — above the reference's 5e-3 — so the bf16 bound is stated
+    as '<= 1 ulp everywhere and >= 99.5 % of the elements inside the reference's 5e-3'; fp16 / fp32 meet the
+    reference's bound outright."""
+    got, want = got.detach().cpu(), torch.as_tensor(want).detach().cpu()
+    assert got.shape == want.shape and got.dtype == want.dtype, (name, got.shape, want.shape, got.dtype, want.dtype)
+    diff = (got.double() - want.double()).abs()
+    inside = diff <= tol + tol * want.double().abs()
+    frac = float(inside.double().mean())
+    rec = {"check": name, "max_abs": float(diff.max()), "frac_inside_ref_tol": frac}
+    if got.dtype == torch.bfloat16:
+        rec["max_ulp"] = _ulps(got, want)
+        ok = rec["max_ulp"] <= 1 and frac >= 0.995
+    else:
+        ok = frac == 1.0
+    _report(rank, **rec)
+    assert ok, rec
+
+
+def check_vectors(rank, ws, group):
+    from conftest import load_golden
+    from hip_utils import hip_cls
+
+    for case in load_golden("compute_with_comm"):
+        if len(case["ranks"]) != ws:
+            continue
+        me = case["ranks"][rank]
+        x, w, want = me["x"].to(DEV), me["w"].to(DEV), me["out"]
+        op = hip_cls(case["op"])(w, None, True, process_group=group, **case["ctor_kwargs"])
+        got = op(x)
+        torch.cuda.synchronize()
+        _compare(rank, f"vector:{case['op']}:{case['name']}", got, want, 5e-3 if x.dtype != torch.float32 else 1e-4)
+
+
+def check_reference_shapes(rank, ws, group):
+    """The reference's own cases, same seeds; the oracle (CPU, over the same gloo group) is the other side."""
+    import torch.nn.functional as F
+
+    from hip_utils import hip_cls, torch_cls
+
+    # GemmAllReduce / GemmReduceScatter: test_compute_with_comm.py:141-146 / :180-185, per-rank seed 42 + rank
+    for m, k, n, dtype in ((4096, 4096, 4096, torch.float16), (2048, 8192, 4096, torch.float16),
+                           (8192, 4096, 2048, torch.float16), (4096, 4096, 4096, torch.bfloat16)):
+        kl = k // ws
+        torch.manual_seed(42 + rank)
+        x = torch.randn(m, kl, dtype=dtype)
+        w = torch.randn(kl, n, dtype=dtype)
+        for name, kw in (("MojoGemmAllReduce", {}), ("MojoGemmReduceScatter", {"scatter_dim": 0})):
+            want = torch_cls(name)(weight=w, bias=None, trans_weight=True, process_group=group, **kw)(x)
+            got = hip_cls(name)(weight=w.to(DEV), bias=None, trans_weight=True, process_group=group, **kw)(x.to(DEV))
+            torch.cuda.synchronize()
+            _compare(rank, f"oracle:{name}:{m}x{k}x{n}:{str(dtype)[6:]}", got, want, 5e-3)
+    # AllGatherGemm: :97-103, one seed for all ranks, [N, K] weights, bias in the fp16 cases
+    for m, k, n, dtype, use_bias in ((4096, 4096, 4096, torch.float16, True), (2048, 4096, 8192, torch.float16, True),
+                                     (8192, 2048, 4096, torch.float16, True), (4096, 4096, 4096, torch.bfloat16, False)):
+        torch.manual_seed(42)
+        x_full = torch.randn(m, k, dtype=dtype)
+        w = torch.randn(n, k, dtype=dtype)
+        b = torch.randn(n, dtype=dtype) if use_bias else None
+        ml = m // ws
+        x = x_full[rank * ml:(rank + 1) * ml].contiguous()
+        want = torch_cls("MojoAllGatherGemm")(weight=w, bias=b, trans_weight=False, gather_dim=0, process_group=group)(x)
+        got = hip_cls("MojoAllGatherGemm")(weight=w.to(DEV), bias=None if b is None else b.to(DEV), trans_weight=False,
+                                           gather_dim=0, process_group=group)(x.to(DEV))
+        torch.cuda.synchronize()
+        _compare(rank, f"oracle:MojoAllGatherGemm:{m}x{k}x{n}:{str(dtype)[6:]}", got, want, 5e-3)
+    # GemmAll2All: :215-247, fp32, the closed form the reference test builds without communication
+    torch.manual_seed(42)
+    m, k, n = 32, 64, 128
+    ml = m // ws
+    x_full, w, b = torch.randn(m, k), torch.randn(n, k), torch.randn(n)
+    shards = [x_full[i * ml:(i + 1) * ml].contiguous() for i in range(ws)]
+    outs = [F.linear(s, w, b) for s in shards]
+    want = torch.cat([outs[j].chunk(ws, dim=0)[rank] for j in range(ws)], dim=0)
+    got = hip_cls("MojoGemmAll2All")(weight=w.to(DEV), bias=b.to(DEV), trans_weight=False, scatter_dim=0, gather_dim=0,
+                                     process_group=group)(shards[rank].to(DEV))
+    torch.cuda.synchronize()
+    _compare(rank, "closed_form:MojoGemmAll2All:32x64x128:float32", got, want, 1e-4)
+
+
+def main():
+    rank, ws = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    group = dist.group.WORLD
+    rc = 0
+    try:
+        modes = [m for m in os.environ.get("MOJO_TEST_COMM_MODES", "chunks1,chunks4").split(",") if m]
+        for mode in modes:
+            os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+            if mode.startswith("chunks"):
+                os.environ["MOJO_HIP_COMM_CHUNKS"] = mode[6:]
+            elif mode.startswith("direct"):
+                os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+                os.environ["MOJO_HIP_COMM_CHUNKS"] = mode[6:] or "4"
+            _report(rank, mode=mode)
+            check_vectors(rank, ws, group)
+            check_reference_shapes(rank, ws, group)
+        dist.barrier()
+    except Exception:
+        traceback.print_exc()
+        rc = 1
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    # leave without running interpreter teardown: a peer that failed must not leave this rank waiting in a collective
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc)
+
+
+if __name__ == "__main__":
+    main()

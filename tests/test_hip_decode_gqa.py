@@ -125,3 +125,94 @@ def test_decode_full_size_properties():
     for b in (0, 17, B - 1):
         want = ref(q[b: b + 1], k, v, lens[b: b + 1], table[b: b + 1])
         assert_close_tree(to_cpu(out[b: b + 1]), want, ATOL, RTOL)
+
+
+def test_decode_length_above_the_hint_is_truncated_not_out_of_bounds():
+    """A `total_seq_lens` entry above the caller's `max_total_seq_len` hint: the launch (grid, LDS image, partials) was
+    sized for the hint, so the kernels truncate that row to the launch's capacity instead of indexing past it.  Both
+    the in-LDS merge (<= 8 chunks) and the split + merge-kernel route (forced by a small chunk) are exercised; with
+    MOJO_HIP_VALIDATE=1 the shim raises instead."""
+    lens = [700, 64, 3000, 1]
+    q, k, v, lens_t, table = make_decode_inputs(4, 8, 2, 128, 0, 16, lens=lens, seed=3)
+    dev = [t.to(DEV) for t in (q, k, v, lens_t, table)]
+    op = hip_cls("MojoPagedDecodeGQA")()
+    ref = torch_cls("MojoPagedDecodeGQA")()
+    import os
+    for chunk_env in (None, "64"):
+        if chunk_env:
+            os.environ["MOJO_HIP_DECODE_CHUNK"] = chunk_env
+        try:
+            hint = 1024                                              # row 2 (3000 tokens) is above it
+            out = op(*dev, max_total_seq_len=hint)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("MOJO_HIP_DECODE_CHUNK", None)
+        assert torch.isfinite(out.float()).all()
+        # rows inside the hint are untouched by the clamp
+        want = ref(q, k, v, lens_t, table)
+        for b in (0, 1, 3):
+            assert_close_tree(to_cpu(out[b: b + 1]), want[b: b + 1], ATOL, RTOL)
+        # the long row equals attention over a prefix of its context: the launch's capacity (>= the hint, whole chunks)
+        got = to_cpu(out[2:3]).float()
+        errs = {}
+        for cap in sorted({hint, *(c for c in range(hint, 3001, 16))}):
+            w = ref(q[2:3], k, v, torch.tensor([cap], dtype=torch.int32), table[2:3]).float()
+            errs[cap] = float((got - w).abs().max())
+            if errs[cap] <= ATOL:
+                break
+        assert min(errs.values()) <= ATOL, f"row above the hint matches no prefix: {min(errs.values())}"
+
+
+def test_decode_hint_violation_raises_when_validation_is_on(monkeypatch):
+    q, k, v, lens, table = [t.to(DEV) for t in make_decode_inputs(2, 8, 2, 128, 0, 16, lens=[100, 900])]
+    monkeypatch.setenv("MOJO_HIP_VALIDATE", "1")
+    with pytest.raises(ValueError):
+        hip_cls("MojoPagedDecodeGQA")()(q, k, v, lens, table, max_total_seq_len=512)
+
+
+@pytest.mark.parametrize("layout", ["ABAB", "AABB"])
+def test_decode_padded_rows_under_graph_replay(layout):
+    """The reference's `test_paged_decode_gqa_with_graph` (tests/accuracy/operators/test_attention.py:218-353): static
+    buffers are mutated in place between replays, padded rows get seq_len = 0 and block_tables = -1, and their output
+    rows must be LEFT UNCHANGED by the replay; eagerly the same rows are zeros (attention.py:184-185)."""
+    B, hq, hkv, d, page, max_len = 8, 16, 4, 128, 32, 1024
+    q, k, v, lens, table = make_decode_inputs(B, hq, hkv, d, max_len, page, seed=11)
+    width = (max_len + page - 1) // page
+    tbl = torch.full((B, width), -1, dtype=torch.int32)
+    tbl[:, : table.shape[1]] = table
+    pool = B * width + 10                                      # static pools hold any batch the generator can make
+    k_pool, v_pool = torch.zeros(pool, hkv, page, d, dtype=k.dtype), torch.zeros(pool, hkv, page, d, dtype=v.dtype)
+    k_pool[: k.shape[0]], v_pool[: v.shape[0]] = k, v
+    sq, sk, sv, sl, st = [t.to(DEV) for t in (q, k_pool, v_pool, lens, tbl)]
+    op = hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    ref = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    op(sq, sk, sv, sl, st, max_total_seq_len=max_len)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = op(sq, sk, sv, sl, st, max_total_seq_len=max_len)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_close_tree(to_cpu(out), ref(q, k, v, lens, tbl), ATOL, RTOL)
+    g = torch.Generator().manual_seed(5)
+    for step in range(4):
+        cur_b = int(torch.randint(1, B, (), generator=g))
+        cq, ck, cv, cl, ct = make_decode_inputs(cur_b, hq, hkv, d, max_len, page, seed=100 + step)
+        sk[: ck.shape[0]].copy_(ck.to(DEV))
+        sv[: cv.shape[0]].copy_(cv.to(DEV))
+        sq[:cur_b].copy_(cq.to(DEV))
+        sl[:cur_b].copy_(cl.to(DEV))
+        sl[cur_b:] = 0
+        st.fill_(-1)
+        st[:cur_b, : ct.shape[1]].copy_(ct.to(DEV))
+        keep = out[cur_b:].clone()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert_close_tree(to_cpu(out[:cur_b]), ref(cq, ck, cv, cl, ct), ATOL, RTOL)
+        assert torch.equal(out[cur_b:], keep), "padded rows were modified by the replay"
+        # eager call on the same buffers: padded rows are zeros (golden semantics); explicit flag overrides both ways
+        eager = op(sq, sk, sv, sl, st, max_total_seq_len=max_len)
+        assert torch.count_nonzero(eager[cur_b:]) == 0
+        torch.testing.assert_close(eager[:cur_b].float(), out[:cur_b].float(), atol=0, rtol=0)
+        forced = op(sq, sk, sv, sl, st, max_total_seq_len=max_len, leave_empty_rows=False)
+        assert torch.count_nonzero(forced[cur_b:]) == 0

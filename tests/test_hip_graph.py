@@ -76,7 +76,12 @@ def test_decode_attention_step_replays_on_static_buffers():
         v_cache.copy_(snap_v)
         want = step()
         torch.cuda.synchronize()
-        assert all(torch.equal(a, b_) for a, b_ in zip(got, want))
+        # Rows with total == 0 are padding: the captured attention leaves its output row as it was (the reference's
+        # replay contract, tests/accuracy/operators/test_attention.py:340-353) while the eager call writes zeros, so
+        # the layers behind it are compared on the live rows only.
+        live = (total > 0).nonzero().flatten()
+        assert live.numel() == (b - 1 if i % 2 else b)
+        assert all(torch.equal(a[live], b_[live]) for a, b_ in zip(got, want))
         assert torch.equal(got_k, k_cache) and torch.equal(got_v, v_cache)
 
 

@@ -254,3 +254,38 @@ def test_store_then_decode_round_trip_full_size():
     assert torch.equal(back, ks)
     back = vc[table.long()].permute(0, 1, 3, 2, 4).reshape(T, hkv, d)
     assert torch.equal(back, vs)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_rmsnorm_inplace_writes_into_its_input(dtype):
+    """MojoRMSNormInplace (experimental/operators/normalization.py:95-140), the q/k-norm in front of RoPE
+    (modeling/qwen3/mojo_qwen3_dense.py:229-233): inplace=True returns the SAME tensor holding the norm, bit-equal to the
+    out-of-place result; a strided view (the q slice of a fused qkv projection) is handled too; rows longer than the
+    kernel's register cache (second pass re-reads the row it is overwriting) included."""
+    torch.manual_seed(3)
+    for shape in ((37, 8, 128), (5, 4, 9000), (3, 2, 77)):
+        d = shape[-1]
+        w = torch.randn(d, dtype=dtype)
+        x = torch.randn(shape, dtype=dtype)
+        ops = {ip: hip_cls("MojoRMSNormInplace")(d, 1e-6, inplace=ip, dtype=dtype, device=DEV) for ip in (False, True)}
+        ref = torch_cls("MojoRMSNormInplace")(d, 1e-6, inplace=False, dtype=dtype)
+        with torch.no_grad():
+            ref.weight.copy_(w)
+            for op in ops.values():
+                op.weight.copy_(w)
+        xd = x.to(DEV)
+        want = ops[False](xd)
+        assert want.data_ptr() != xd.data_ptr() and torch.equal(xd.cpu(), x)          # out of place: input untouched
+        atol, rtol = (5e-2, 1e-2) if dtype != torch.float32 else (2e-5, 2e-5)
+        assert_close_tree(to_cpu(want), ref(x), atol=atol, rtol=rtol)
+        buf = xd.clone()
+        got = ops[True](buf)
+        assert got.data_ptr() == buf.data_ptr() and torch.equal(got, want)
+        # strided: normalise the first `heads` heads of a wider fused tensor in place, the rest must not change
+        fused = torch.randn(shape[0], shape[1] + 3, d, dtype=dtype).to(DEV)
+        before = fused.clone()
+        view = fused[:, : shape[1]]
+        out = ops[True](view)
+        assert out.data_ptr() == view.data_ptr()
+        assert torch.equal(fused[:, shape[1]:], before[:, shape[1]:])
+        assert torch.equal(fused[:, : shape[1]], ops[False](before[:, : shape[1]].contiguous()))
