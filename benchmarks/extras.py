@@ -316,46 +316,99 @@ def bench_streaming(device):
 
 
 def bench_compute_comm(device, world, rank):
-    """Llama-3-70B row/column-parallel projections at tp = world (config 4).  Every rank reports its own time;
-    rank 0's is kept.  speedup_vs_tp1 compares with the full-K (or full-N) GEMM on one GPU in the same run."""
+    """Llama-3-70B row/column-parallel projections at tp = world (SURVEY §8d config 4): M in {1024, 4096, 8192};
+    GemmAllReduce / GemmReduceScatter at (K, N) = (28672, 8192) and (8192, 8192), K split over the ranks; AllGatherGemm at
+    N_total in {10240, 57344}, N split; GemmAll2All at one Ulysses-style shape.  Every rank runs every case (they contain
+    collectives); rank 0's times are reported.  With world > 1 each reduce case is timed twice — the collective library's
+    ring under the chunked pipeline ("rccl") and the ring-free peer exchange ("direct", MOJO_HIP_COMM_DIRECT=1) — next to
+    the local GEMM alone and the full-K GEMM on one GPU (speedup_vs_tp1, target >= 6 at tp = 8)."""
+    from mojo_opset_amd.backends.hip.operators.compute_with_comm import _ENGINE
+
     out = {}
-    group = dist.group.WORLD if world > 1 else None
-    m = 4096
     dt = torch.bfloat16
-    # GemmAllReduce / GemmReduceScatter: down-proj K = 28672 split over ranks, N = 8192
-    k_total, n = 28672, 8192
-    kl = k_total // world
-    x = torch.randn(m, kl, device=device, dtype=dt)
-    w = torch.randn(kl, n, device=device, dtype=dt) * 0.02
-    for name, cls, kw in (("gemm_allreduce", "MojoGemmAllReduce", {}), ("gemm_reducescatter", "MojoGemmReduceScatter", {"scatter_dim": 0})):
-        op = hip(cls)(w, None, True, **kw)
-        t = _time(lambda: op(x), 10, 2)
-        out[f"{name}_M4096_K28672_N8192_tp{world}"] = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k_total * n / t / 1e12,
-                                                       "payload_MB_per_rank": m * n * 2 / 1e6}
-    if world > 1:
-        xf = torch.randn(m, k_total, device=device, dtype=dt)
-        wf = torch.randn(k_total, n, device=device, dtype=dt) * 0.02
-        full = hip("MojoGemmAllReduce")(wf, None, True, process_group=None)
-        from mojo_opset_amd.backends.hip.operators.compute_with_comm import _ENGINE
-        t1 = _time(lambda: _ENGINE(xf, wf, None, True), 10, 2)
-        for name in ("gemm_allreduce", "gemm_reducescatter"):
-            key = f"{name}_M4096_K28672_N8192_tp{world}"
-            out[key]["tp1_full_gemm_us"] = t1 * 1e6
-            out[key]["speedup_vs_tp1"] = t1 * 1e6 / out[key]["us"]
-        del xf, wf, full
-    # AllGatherGemm: x [M/tp, 8192], QKV projection N_total = 10240 split over ranks
-    k2, n_total = 8192, 10240
-    nl = n_total // world
-    xs = torch.randn(m // world, k2, device=device, dtype=dt)
-    w2 = torch.randn(k2, nl, device=device, dtype=dt) * 0.02
-    op = hip("MojoAllGatherGemm")(w2, None, True, gather_dim=0)
-    t = _time(lambda: op(xs), 10, 2)
-    out[f"allgather_gemm_M4096_K8192_N10240_tp{world}"] = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k2 * n_total / t / 1e12}
+    link_peak = 153.0                                   # GB/s per xGMI link (SURVEY §8d)
+
+    def timed(fn):
+        return _time(fn, 5, 2)
+
+    def with_direct(flag, fn):
+        old = os.environ.get("MOJO_HIP_COMM_DIRECT")
+        os.environ["MOJO_HIP_COMM_DIRECT"] = flag
+        try:
+            return fn()
+        finally:
+            if old is None:
+                os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+            else:
+                os.environ["MOJO_HIP_COMM_DIRECT"] = old
+
+    for k_total, n in ((28672, 8192), (8192, 8192)):
+        kl = k_total // world
+        w = torch.randn(kl, n, device=device, dtype=dt) * 0.02
+        wf = torch.randn(k_total, n, device=device, dtype=dt) * 0.02 if world > 1 else None
+        for m in (1024, 4096, 8192):
+            x = torch.randn(m, kl, device=device, dtype=dt)
+            t_local = timed(lambda: _ENGINE(x, w, None, True))
+            t1 = None
+            if world > 1:
+                xf = torch.randn(m, k_total, device=device, dtype=dt)
+                t1 = timed(lambda: _ENGINE(xf, wf, None, True))
+                del xf
+            payload = m * n * 2
+            for name, cls, kw in (("gemm_allreduce", "MojoGemmAllReduce", {}), ("gemm_reducescatter", "MojoGemmReduceScatter", {"scatter_dim": 0})):
+                op = hip(cls)(w, None, True, **kw)
+                phases = 2 if name == "gemm_allreduce" else 1
+                for variant in (("rccl", "direct") if world > 1 else ("rccl",)):
+                    key = f"{name}_M{m}_K{k_total}_N{n}_tp{world}" + ("" if world == 1 else f"_{variant}")
+                    try:
+                        t = with_direct("1" if variant == "direct" else "0", lambda: timed(lambda: op(x)))
+                        if variant == "direct":
+                            from mojo_opset_amd.comm import peer
+                            for ex in peer._CACHE.values():
+                                ex.check()
+                    except Exception as e:          # the direct exchange has never run on a multi-GPU node: report, keep going
+                        out[key] = {"error": repr(e)}
+                        continue
+                    rec = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k_total * n / t / 1e12, "local_gemm_us": t_local * 1e6,
+                           "exposed_exchange_us": max(t - t_local, 0.0) * 1e6, "payload_MB_per_rank": payload / 1e6}
+                    if world > 1:
+                        # bytes one rank moves over ONE link: ring = phases*(ws-1)/ws of the payload over its single ring link;
+                        # direct = phases * payload/ws from each of its ws-1 peers
+                        per_link = phases * payload * ((world - 1) / world if variant == "rccl" else 1.0 / world)
+                        rec.update({"tp1_full_gemm_us": t1 * 1e6, "speedup_vs_tp1": t1 / t,
+                                    "link_MB": per_link / 1e6, "link_GBps_over_whole_op": per_link / t / 1e9,
+                                    "link_GBps_over_exposed_time": per_link / max(t - t_local, 1e-6) / 1e9,
+                                    "link_peak_GBps": link_peak})
+                    out[key] = rec
+            del x
+        del w, wf
+        torch.cuda.empty_cache()
+    # AllGatherGemm: x [M/tp, 8192] gathered along rows, column-parallel weight [8192, N_total/tp]
+    k2 = 8192
+    for n_total in (10240, 57344):
+        nl = n_total // world
+        w2 = torch.randn(k2, nl, device=device, dtype=dt) * 0.02
+        for m in (1024, 4096, 8192):
+            xs = torch.randn(m // world, k2, device=device, dtype=dt)
+            op = hip("MojoAllGatherGemm")(w2, None, True, gather_dim=0)
+            t = timed(lambda: op(xs))
+            rec = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k2 * n_total / t / 1e12}
+            if world > 1:
+                xfull = torch.randn(m, k2, device=device, dtype=dt)
+                t_local = timed(lambda: _ENGINE(xfull, w2, None, True))
+                rec.update({"local_gemm_us": t_local * 1e6, "exposed_exchange_us": max(t - t_local, 0.0) * 1e6,
+                            "gathered_MB_per_rank": (world - 1) * (m // world) * k2 * 2 / 1e6})
+                del xfull
+            out[f"allgather_gemm_M{m}_K{k2}_N{n_total}_tp{world}"] = rec
+            del xs
+        del w2
+        torch.cuda.empty_cache()
     # GemmAll2All (Ulysses-style): x [M/tp, 8192] @ W [8192, 10240] then all-to-all rows -> columns
+    n_total, m = 10240, 4096
     xs2 = torch.randn(max(m // world, world), k2, device=device, dtype=dt)
     w3 = torch.randn(k2, n_total, device=device, dtype=dt) * 0.02
     op = hip("MojoGemmAll2All")(w3, None, True, scatter_dim=0, gather_dim=1)
-    t = _time(lambda: op(xs2), 10, 2)
+    t = timed(lambda: op(xs2))
     out[f"gemm_all2all_M{xs2.shape[0]}_K8192_N10240_tp{world}"] = {"us": t * 1e6, "aggregate_tflops": 2.0 * xs2.shape[0] * world * k2 * n_total / t / 1e12}
     return out
 

@@ -312,6 +312,41 @@ int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_
                                 int64_t kpe_src_token_stride, int64_t ckv_block_stride, int64_t ckv_token_stride,
                                 int64_t kpe_block_stride, int64_t kpe_token_stride, mojo_stream_t stream);
 
+/* ---- Direct reduce-scatter / all-gather over HIP-IPC peer buffers: the exchange step of MojoGemmAllReduce /
+ *      MojoGemmReduceScatter without a ring (core/operators/compute_with_comm.py:57-116, :264-340; role of
+ *      runtime/comm_context.py:107-153 `allocate_peer_mem` + the pull-and-add loops of
+ *      backends/ttx/kernels/npu/a2/gemm_allreduce.py:85-145 and gemm_reduce_scatter.py:108-156).
+ *      Set-up (the only entry points of this library that allocate or synchronise): each rank allocates ONE buffer
+ *      [2 x capacity data | 4 KiB | ctrl words], exports a 64-byte handle, opens every peer's handle.
+ *      peer_data[r] / peer_flags[r] = this process's pointer to rank r's data area / control words (own entry = local).
+ *      Exchange steps only enqueue kernels.  epoch grows by one per operator call (never reset); flag kind 0 = "partial
+ *      product of (rank, chunk) is in memory", kind 1 = "reduced share of (rank, chunk) is in memory".
+ *      reduce: dst[rows, n] = sum over ranks of the contiguous [rows, n] block at src_offset_bytes of every rank's data
+ *      area (fp32 sum in rank order, one rounding), after waiting for every rank's kind-0 flag of `chunk`; write_back = 1
+ *      also stores the result over the own block and raises this rank's kind-1 flag at every peer when the launch is done.
+ *      gather: for every other rank p, after its kind-1 flag: rows [rows*p/ws, rows*(p+1)/ws) of the [rows, n] chunk at
+ *      chunk_offset_bytes of rank p's data area -> the same rows of dst.
+ *      Every wait is bounded (MOJO_HIP_PEER_TIMEOUT_MS, default 20 s): on expiry the sticky error word is set, the
+ *      affected output is filled with NaN and the grid drains; mojo_hip_peer_error reads (and clears) the word.        */
+int64_t mojo_hip_peer_ctrl_bytes(void);
+int64_t mojo_hip_peer_max_ranks(void);
+int64_t mojo_hip_peer_max_chunks(void);
+int64_t mojo_hip_peer_handle_bytes(void);
+int mojo_hip_peer_alloc(void** ptr_out, int64_t bytes, int uncached);
+int mojo_hip_peer_free(void* ptr);
+int mojo_hip_peer_export(void* ptr, void* handle_out);
+int mojo_hip_peer_open(const void* handle, void** ptr_out);
+int mojo_hip_peer_close(void* ptr);
+int mojo_hip_peer_error(void* local_flags, int clear, int32_t* error_out);
+int mojo_hip_peer_signal(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
+                         int kind, int64_t chunk, uint32_t epoch, mojo_stream_t stream);
+int mojo_hip_peer_reduce(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
+                         int64_t chunk, uint32_t epoch, int64_t src_offset_bytes, int64_t rows, int64_t n,
+                         void* dst, int64_t ld_dst, int write_back, int dtype, mojo_stream_t stream);
+int mojo_hip_peer_gather(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
+                         int64_t chunk, uint32_t epoch, int64_t chunk_offset_bytes, int64_t rows, int64_t n,
+                         void* dst, int64_t ld_dst, int dtype, mojo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

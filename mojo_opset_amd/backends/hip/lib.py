@@ -66,6 +66,19 @@ SIGNATURES = {
     "mojo_hip_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "mojo_hip_gemm": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_gemm_rowmap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_int, _P, _I, _P]),
+    "mojo_hip_peer_ctrl_bytes": (c_int64, []),
+    "mojo_hip_peer_max_ranks": (c_int64, []),
+    "mojo_hip_peer_max_chunks": (c_int64, []),
+    "mojo_hip_peer_handle_bytes": (c_int64, []),
+    "mojo_hip_peer_alloc": (c_int, [_P, _I, c_int]),
+    "mojo_hip_peer_free": (c_int, [_P]),
+    "mojo_hip_peer_export": (c_int, [_P, _P]),
+    "mojo_hip_peer_open": (c_int, [_P, _P]),
+    "mojo_hip_peer_close": (c_int, [_P]),
+    "mojo_hip_peer_error": (c_int, [_P, c_int, _P]),
+    "mojo_hip_peer_signal": (c_int, [_P, _P, _I, _I, c_int, _I, ctypes.c_uint32, _P]),
+    "mojo_hip_peer_reduce": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint32, _I, _I, _I, _P, _I, c_int, c_int, _P]),
+    "mojo_hip_peer_gather": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint32, _I, _I, _I, _P, _I, c_int, _P]),
     "mojo_hip_quant_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "mojo_hip_quant_gemm": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
 }

@@ -3,6 +3,7 @@
 import torch
 
 from ....comm import GemmEngine, all_gather_gemm, gemm_all2all, gemm_all_reduce, gemm_reduce_scatter
+from ....comm import peer
 from ....core.operators.compute_with_comm import (MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllReduce,
                                                   MojoGemmReduceScatter, is_dist_initialized)
 from .. import lib as L
@@ -54,7 +55,15 @@ class HIPGemmAllReduce(MojoGemmAllReduce):
     supported_platforms_list = _ROCM
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return gemm_all_reduce(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self))
+        group = _group_of(self)
+        if peer.direct_enabled(group, input):                 # MOJO_HIP_COMM_DIRECT=1: ring-free exchange over peer buffers
+            x2 = input.reshape(-1, input.shape[-1])
+            x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+            n = _ENGINE.out_features(self.weight, self.trans_weight)
+            if peer.direct_supported(x2, n, x2.shape[0], 0):
+                out = peer.gemm_all_reduce_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
+                return out.reshape(*input.shape[:-1], n)
+        return gemm_all_reduce(_ENGINE, input, self.weight, self.bias, self.trans_weight, group)
 
 
 class HIPAllGatherGemm(MojoAllGatherGemm):
@@ -76,5 +85,17 @@ class HIPGemmReduceScatter(MojoGemmReduceScatter):
     supported_platforms_list = _ROCM
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return gemm_reduce_scatter(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self),
-                                   self.scatter_dim)
+        group = _group_of(self)
+        if peer.direct_enabled(group, input) and self.scatter_dim % input.dim() == 0:
+            import torch.distributed as dist
+
+            ws = dist.get_world_size(group)
+            x2 = input.reshape(-1, input.shape[-1])
+            x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+            n = _ENGINE.out_features(self.weight, self.trans_weight)
+            if input.shape[0] % ws == 0 and peer.direct_supported(x2, n, x2.shape[0] // ws, ws):
+                out = peer.gemm_reduce_scatter_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
+                shape = list(input.shape[:-1]) + [n]
+                shape[0] //= ws
+                return out.reshape(shape)
+        return gemm_reduce_scatter(_ENGINE, input, self.weight, self.bias, self.trans_weight, group, self.scatter_dim)

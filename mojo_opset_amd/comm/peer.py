@@ -1,0 +1,238 @@
+"""Symmetric peer buffers over HIP IPC and the direct (ring-free) exchange built on them.
+
+Role in the reference: `MojoSymmetricMemoryManager.allocate_peer_mem` (`runtime/comm_context.py:107-153`): one buffer per
+rank, the same size everywhere, every rank holding a pointer to every other rank's copy, cached per (group, size).  Here a
+buffer is a `hipExtMallocWithFlags(hipDeviceMallocUncached)` allocation (plain `hipMalloc` if that cannot be exported)
+shared with `hipIpcGetMemHandle` / `hipIpcOpenMemHandle`; the 64-byte handles travel through the process group itself
+(`all_gather_object`), so any backend — RCCL on a real node, gloo in the single-GPU tests — can set it up.
+
+`PeerExchange` then drives csrc/peer_comm.hip: per row chunk, GEMM -> signal on the caller's stream; pull-and-add
+(+ pull-gather for the all-reduce) on a side stream, so the xGMI traffic of chunk c overlaps the GEMM of chunk c + 1.
+Nothing here synchronises with the host after set-up.
+"""
+import ctypes
+import os
+import threading
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..backends.hip import lib as L
+
+_LOCK = threading.RLock()
+_CACHE: Dict[Tuple[int, int], "PeerExchange"] = {}
+
+
+class _DeviceBytes:
+    """`__cuda_array_interface__` view of raw device memory, so torch can alias it without owning it."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def _ptr_array(ptrs: List[int]):
+    arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+    return arr
+
+
+class PeerExchange:
+    """Symmetric data + control areas of one process group, and the per-call bookkeeping (epoch, parity)."""
+
+    def __init__(self, group, capacity_bytes: int):
+        self.group = group
+        self.ws = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        lib = L.load()
+        if self.ws > lib.mojo_hip_peer_max_ranks():
+            raise NotImplementedError(f"direct exchange supports up to {lib.mojo_hip_peer_max_ranks()} ranks per node")
+        self.capacity = (int(capacity_bytes) + 4095) // 4096 * 4096            # bytes of ONE parity half
+        self.ctrl_bytes = int(lib.mojo_hip_peer_ctrl_bytes())
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.max_chunks = int(lib.mojo_hip_peer_max_chunks())
+        total = 2 * self.capacity + 4096 + self.ctrl_bytes
+        self._local = ctypes.c_void_p()
+        uncached = os.environ.get("MOJO_HIP_PEER_UNCACHED", "1") != "0"
+        handle = (ctypes.c_char * int(lib.mojo_hip_peer_handle_bytes()))()
+        for attempt in ((1, 0) if uncached else (0,)):
+            L.check(lib.mojo_hip_peer_alloc(ctypes.byref(self._local), total, attempt), "peer buffer allocation")
+            rc = lib.mojo_hip_peer_export(self._local, handle)
+            if rc == 0:
+                self.uncached = bool(attempt)
+                break
+            lib.mojo_hip_peer_free(self._local)
+            self._local = ctypes.c_void_p()
+            if attempt == 0:
+                L.check(rc, "peer buffer export")
+        # exchange (handle, pid): a rank must not IPC-open its own allocation
+        mine = (bytes(handle), os.getpid(), total)
+        everyone: List[Optional[tuple]] = [None] * self.ws
+        dist.all_gather_object(everyone, mine, group=group)
+        if any(e[2] != total for e in everyone):
+            raise RuntimeError("peer buffers: ranks disagree on the buffer size (every rank must make the same calls)")
+        self._bases: List[int] = []
+        self._opened: List[ctypes.c_void_p] = []
+        for r, (h, _pid, _sz) in enumerate(everyone):
+            if r == self.rank:
+                self._bases.append(self._local.value)
+                continue
+            p = ctypes.c_void_p()
+            L.check(lib.mojo_hip_peer_open(ctypes.create_string_buffer(h, len(h)), ctypes.byref(p)), f"opening rank {r}'s peer buffer")
+            self._opened.append(p)
+            self._bases.append(p.value)
+        self._flag_off = 2 * self.capacity + 4096
+        self._data = _ptr_array(self._bases)
+        self._flags = _ptr_array([b + self._flag_off for b in self._bases])
+        self._alias = torch.as_tensor(_DeviceBytes(self._local.value, 2 * self.capacity), device=self.device)
+        self.epoch = 0
+        self.side = torch.cuda.Stream(device=self.device)
+        dist.barrier(group=group)               # every rank has opened every buffer (and cleared its own) before first use
+
+    # ---- per-call state -----------------------------------------------------------------------------------------
+    def begin_call(self) -> Tuple[int, int]:
+        """(epoch, byte offset of this call's half of the data area).  Every rank makes the same sequence of calls."""
+        self.epoch += 1
+        return self.epoch & 0xFFFFFFFF, (self.epoch & 1) * self.capacity
+
+    def local_view(self, byte_offset: int, rows: int, cols: int, dtype: torch.dtype) -> torch.Tensor:
+        n = rows * cols * torch.empty((), dtype=dtype).element_size()
+        return self._alias[byte_offset: byte_offset + n].view(dtype).view(rows, cols)
+
+    def signal(self, kind: int, chunk: int, epoch: int, stream) -> None:
+        L.check(L.load().mojo_hip_peer_signal(self._data, self._flags, self.ws, self.rank, kind, chunk, epoch, stream),
+                "peer signal")
+
+    def reduce(self, chunk, epoch, src_off, rows, n, dst: torch.Tensor, write_back: bool, stream) -> None:
+        L.check(L.load().mojo_hip_peer_reduce(self._data, self._flags, self.ws, self.rank, chunk, epoch, src_off, rows, n,
+                                              L.ptr(dst), dst.stride(0), 1 if write_back else 0, L.dtype_code(dst.dtype),
+                                              stream), "peer reduce")
+
+    def gather(self, chunk, epoch, chunk_off, rows, n, dst: torch.Tensor, stream) -> None:
+        L.check(L.load().mojo_hip_peer_gather(self._data, self._flags, self.ws, self.rank, chunk, epoch, chunk_off, rows, n,
+                                              L.ptr(dst), dst.stride(0), L.dtype_code(dst.dtype), stream), "peer gather")
+
+    def check(self, clear: bool = True) -> None:
+        """Raise if a wait of an earlier call timed out (its outputs were poisoned with NaN).  Synchronises."""
+        err = ctypes.c_int32(0)
+        L.check(L.load().mojo_hip_peer_error(ctypes.c_void_p(self._local.value + self._flag_off), 1 if clear else 0,
+                                             ctypes.byref(err)), "peer error word")
+        if err.value:
+            raise RuntimeError("direct peer exchange: a wait for a peer's flag timed out (MOJO_HIP_PEER_TIMEOUT_MS); the "
+                               "affected outputs were filled with NaN")
+
+    def close(self) -> None:
+        lib = L.load()
+        for p in self._opened:
+            lib.mojo_hip_peer_close(p)
+        self._opened = []
+        if self._local:
+            lib.mojo_hip_peer_free(self._local)
+            self._local = ctypes.c_void_p()
+
+
+def get_exchange(group, need_bytes: int) -> PeerExchange:
+    """The group's exchange with at least ``need_bytes`` per parity half; (re)built collectively when it must grow, so every
+    rank has to ask with the same sizes in the same order (they do: the ops are SPMD)."""
+    key = id(group)
+    with _LOCK:
+        for (k, cap), ex in list(_CACHE.items()):
+            if k == key and cap >= need_bytes:
+                return ex
+        for (k, cap) in [kc for kc in _CACHE if kc[0] == key]:
+            torch.cuda.synchronize()
+            dist.barrier(group=group)           # nobody may still be reading the buffer that is about to go away
+            _CACHE.pop((k, cap)).close()
+        cap = max(int(need_bytes), int(os.environ.get("MOJO_HIP_PEER_MIN_BYTES", str(64 << 20))))
+        ex = PeerExchange(group, cap)
+        _CACHE[(key, ex.capacity)] = ex
+        return ex
+
+
+def release_all() -> None:
+    with _LOCK:
+        for ex in _CACHE.values():
+            ex.close()
+        _CACHE.clear()
+
+
+def direct_enabled(group, x: torch.Tensor) -> bool:
+    """MOJO_HIP_COMM_DIRECT: "1" = use the peer exchange, "0"/unset = the collective library's ring (default until the
+    direct path has been measured on an 8-GPU node)."""
+    if group is None or not x.is_cuda:
+        return False
+    return os.environ.get("MOJO_HIP_COMM_DIRECT", "0") == "1" and dist.get_world_size(group) > 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the two operators whose exchange is a reduction
+# ---------------------------------------------------------------------------------------------------------------
+def _side_ptr(ex: PeerExchange):
+    return ctypes.c_void_p(ex.side.cuda_stream)
+
+
+def direct_supported(x: torch.Tensor, n: int, rows: int, ws: int) -> bool:
+    """Whole 16-byte vectors per row, 16-bit or fp32 data, and no more chunks than the flag area holds."""
+    es = x.element_size()
+    return x.dtype in (torch.bfloat16, torch.float16, torch.float32) and (n * es) % 16 == 0 and rows > 0
+
+
+def gemm_all_reduce_direct(engine, x2: torch.Tensor, weight, bias, trans_weight: bool, group) -> torch.Tensor:
+    """allreduce_sum(x2 @ W (+ bias)) with the direct exchange.  Per row chunk c (rows [lo, hi)):
+         main stream : GEMM -> partial in this rank's peer buffer; signal "partial (me, c) ready" to every peer
+         side stream : pull-and-add this rank's 1/ws share of the chunk from every rank (fp32 sum in rank order, one
+                       rounding), store it to `out` and back over the own partial; last workgroup signals "share ready";
+                       pull the other ranks' shares into `out`.
+    The golden sums storage-type values (`fc.all_reduce` of the rounded products, compute_with_comm.py:106-110); summing
+    the same rounded partials in fp32 and rounding once is at least as accurate and equal for ws = 2."""
+    from .pipelines import plan_row_chunks
+
+    n = engine.out_features(weight, trans_weight)
+    m = x2.shape[0]
+    es = x2.element_size()
+    ex = get_exchange(group, m * n * es)
+    epoch, base = ex.begin_call()
+    out = torch.empty(m, n, dtype=x2.dtype, device=x2.device)
+    main = torch.cuda.current_stream(x2.device)
+    chunks = plan_row_chunks(m)
+    assert len(chunks) <= ex.max_chunks
+    ws, rank = ex.ws, ex.rank
+    for c, (lo, hi) in enumerate(chunks):
+        off = base + lo * n * es
+        rows = hi - lo
+        engine(x2[lo:hi], weight, bias, trans_weight, out=ex.local_view(off, rows, n, x2.dtype))
+        ex.signal(0, c, epoch, L.stream_of(x2))
+        ex.side.wait_stream(main)
+        r0, r1 = rows * rank // ws, rows * (rank + 1) // ws
+        ex.reduce(c, epoch, off + r0 * n * es, r1 - r0, n, out[lo + r0: lo + r1], True, _side_ptr(ex))
+        ex.gather(c, epoch, off, rows, n, out[lo:hi], _side_ptr(ex))
+    main.wait_stream(ex.side)
+    return out
+
+
+def gemm_reduce_scatter_direct(engine, x2: torch.Tensor, weight, bias, trans_weight: bool, group) -> torch.Tensor:
+    """Rows [rank * M/ws, (rank + 1) * M/ws) of sum_ranks(x2 @ W (+ bias)): per chunk the GEMM's A-row map produces
+    "sub-chunk c of every rank's row block" contiguously ([dest rank][rc rows]) in the peer buffer; this rank pulls and adds
+    block `rank` of every rank's buffer."""
+    from .pipelines import plan_row_chunks
+
+    n = engine.out_features(weight, trans_weight)
+    m = x2.shape[0]
+    es = x2.element_size()
+    ex = get_exchange(group, m * n * es)
+    ws, rank = ex.ws, ex.rank
+    assert m % ws == 0
+    ml = m // ws
+    epoch, base = ex.begin_call()
+    out = torch.empty(ml, n, dtype=x2.dtype, device=x2.device)
+    main = torch.cuda.current_stream(x2.device)
+    chunks = plan_row_chunks(ml)
+    assert len(chunks) <= ex.max_chunks
+    for c, (lo, hi) in enumerate(chunks):
+        rc = hi - lo
+        off = base + ws * lo * n * es
+        engine(x2, weight, bias, trans_weight, out=ex.local_view(off, ws * rc, n, x2.dtype), rows=ws * rc, a_map=(rc, ml, lo))
+        ex.signal(0, c, epoch, L.stream_of(x2))
+        ex.side.wait_stream(main)
+        ex.reduce(c, epoch, off + rank * rc * n * es, rc, n, out[lo:hi], False, _side_ptr(ex))
+    main.wait_stream(ex.side)
+    return out

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
   const int b = blockIdx.y / a.hkv;
   const int kvh = blockIdx.y % a.hkv;
 
-  const int seq_len = decode_seq_len(a, b);
+  const int seq_len = a.max_pages > 0 ? decode_seq_len(a, b) : 0;      // (no table columns: nothing to attend over)
   const int chunk_tokens = decode_seq_chunk(a, seq_len);
   const int tok_begin = chunk * chunk_tokens;
   const bool has_work = seq_len > 0 && tok_begin < seq_len;
@@ -122,44 +122,55 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
   }
 
   const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
-  // The golden walks the pages in order and stops at the first negative id, leaving every later
-  // row zero (core/operators/attention.py:195-198).  Find that index for the pages up to the end
-  // of this chunk: 64 table entries per step, one ballot.
+  // The golden walks the pages in order and stops at the first negative id, leaving every later row zero
+  // (core/operators/attention.py:195-198).  `first_neg` = that page index among the pages up to the end of this chunk.
+  // The scan (64 table entries per load, one ballot each) does NOT gate the K/V loads: a load only needs its own table
+  // entry (a negative id is clamped to page 0, an address that certainly exists) and remembers its logical page; whether
+  // it must read as zero (logical page >= first_neg) is decided when the tile is consumed.  So the prologue is one
+  // round trip — scan batch, query and the first two tiles in flight together — instead of up to four dependent ones
+  // in front of the first K/V byte (measured fixed cost per call before: ~18 us).
+  int p1 = (tok_end + a.page - 1) / a.page;
   int first_neg = 0x7fffffff;
-  {
-    int p1 = (tok_end + a.page - 1) / a.page;
-    if (p1 > a.max_pages) { first_neg = a.max_pages; p1 = a.max_pages; }
-    for (int base = 0; base < p1; base += 64) {
-      const int idx = base + lane;
-      const int v = idx < p1 ? table[idx] : 0;
-      const unsigned long long neg = __ballot(v < 0);
-      if (neg) {
-        first_neg = base + __builtin_ctzll(neg);
-        break;
-      }
+  if (p1 > a.max_pages) { first_neg = a.max_pages; p1 = a.max_pages; }
+  constexpr int SCAN = 4;                               // table loads in flight per scan step (256 pages)
+  int scan_v[SCAN];
+  auto scan_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < SCAN; ++u) {
+      const int idx = base + u * 64 + lane;
+      scan_v[u] = idx < p1 ? table[idx] : 0;
     }
-  }
+  };
+  auto scan_reduce = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < SCAN; ++u) {
+      const unsigned long long neg = __ballot(scan_v[u] < 0);
+      if (neg && first_neg == 0x7fffffff) first_neg = base + u * 64 + __builtin_ctzll(neg);
+    }
+  };
+  if (has_work) scan_issue(0);
+
   const T* kbase = static_cast<const T*>(a.kc) + kvh * a.c_head + jd;
   const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head + jd;
   const int last_load = ((tok_end - 1) / DEC_TPL) * DEC_TPL;   // first token of the last non-empty load
+  const int last_page = a.max_pages - 1;
 
-  struct Tile { V8 k[DEC_LOADS]; V8 v[DEC_LOADS]; int zero_mask; };
+  struct Tile { V8 k[DEC_LOADS]; V8 v[DEC_LOADS]; int lp[DEC_LOADS]; };
 
   auto ld = [&](const T* p) -> V8 {
     if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V8*>(p));
     else return *reinterpret_cast<const V8*>(p);
   };
 
-  // Branch-free: every load is issued (clamped to an address that certainly exists); which of them
-  // must read as zero (negative page id) is remembered in a wave-uniform mask.
+  // Branch-free: every load is issued (clamped to an address that certainly exists); its logical page is kept so that
+  // `process` can tell which loads must read as zero (pages at or behind the first negative id).
   auto load_tile = [&](Tile& t, int t0) {
-    t.zero_mask = 0;
 #pragma unroll
     for (int u = 0; u < DEC_LOADS; ++u) {
       const int tu = min(t0 + u * DEC_TPL, last_load);    // wave-uniform; TPL | page
       const int lp = a.page_shift >= 0 ? (tu >> a.page_shift) : tu / a.page;
-      int phys = lp < first_neg ? table[lp] : -1;
-      if (phys < 0) { t.zero_mask |= 1 << u; phys = 0; }
+      t.lp[u] = lp;
+      const int phys = max(table[min(lp, last_page)], 0);
       const int64_t off = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - lp * a.page + r) * a.c_tok;
       t.k[u] = ld(kbase + off);
       t.v[u] = ld(vbase + off);
@@ -167,10 +178,10 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
   };
 
   auto process = [&](Tile& t, int t0) {
-    if (t.zero_mask) {                                   // rare: pages behind a hole read as zeros
+    if (t.lp[DEC_LOADS - 1] >= first_neg) {              // rare: pages behind a hole read as zeros (lp grows with u)
 #pragma unroll
       for (int u = 0; u < DEC_LOADS; ++u)
-        if (t.zero_mask & (1 << u)) { V8 z = {}; t.k[u] = z; t.v[u] = z; }
+        if (t.lp[u] >= first_neg) { V8 z = {}; t.k[u] = z; t.v[u] = z; }
     }
     const bool full = t0 + DEC_TILE <= tok_end;          // wave-uniform
     float s[DEC_LOADS][G];
@@ -229,6 +240,11 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
   if (has_work) {
   load_tile(ta, tok_begin);
   if (tok_begin + DEC_TILE < tok_end) load_tile(tb, tok_begin + DEC_TILE);
+  scan_reduce(0);
+  for (int base = 64 * SCAN; base < p1 && first_neg == 0x7fffffff; base += 64 * SCAN) {   // contexts past 256 pages
+    scan_issue(base);
+    scan_reduce(base);
+  }
   for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DEC_TILE) {
     if (t0 + 2 * DEC_TILE < tok_end) load_tile(tc, t0 + 2 * DEC_TILE);
     process(ta, t0);

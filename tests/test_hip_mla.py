@@ -192,3 +192,145 @@ def test_mla_decode_full_size_properties():
     table2 = inv[table.long()].to(torch.int32)
     out2 = op(dev[0], ckv[perm].to(DEV), kpe[perm].to(DEV), dev[3], table2.to(DEV))
     assert torch.equal(out, out2)
+
+
+# ---- the reference's own generators, verbatim recipe (test_attention.py:1131-1155, :1193-1233): kv_b_proj = randn ------
+def _ref_decode_data(batch, h, nope, rope, r, max_len, page):
+    q = torch.randn(batch, h, nope + rope, dtype=torch.bfloat16)
+    if max_len > 0:
+        lens = torch.randint(max_len // 2, max_len, (batch,), dtype=torch.int32).clamp(min=1)
+    else:
+        lens = torch.randperm(batch, dtype=torch.int32)
+    max_nb = (int(lens.max()) + page - 1) // page
+    total = int(torch.div(lens + page - 1, page, rounding_mode="floor").sum()) + 10
+    ckv = torch.randn(total, 1, page, r, dtype=torch.bfloat16)
+    kpe = torch.randn(total, 1, page, rope, dtype=torch.bfloat16)
+    table = torch.full((batch, max(max_nb, 1)), -1, dtype=torch.int32)
+    free = torch.randperm(total)
+    off = 0
+    for i in range(batch):
+        n = (int(lens[i]) + page - 1) // page
+        table[i, :n] = free[off:off + n]
+        off += n
+    return q, ckv, kpe, lens, table
+
+
+def _report_triple(name, got, golden, exact):
+    import json
+    import os
+    rec = {"case": name, "max_abs_exact": float(exact.abs().max()),
+           "hip_vs_golden": float((got.double() - golden.double()).abs().max()),
+           "hip_vs_fp64": float((got.double() - exact).abs().max()),
+           "golden_vs_fp64": float((golden.double() - exact).abs().max())}
+    print("MLA_ERROR_TRIPLE " + json.dumps(rec))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "mla_error_triples.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    return rec
+
+
+@pytest.mark.parametrize("cfg", [(4, 16, 96, 32, 128, 64, 256, 64), (2, 8, 64, 32, 64, 32, 128, 32), (3, 8, 64, 32, 64, 32, 0, 32)],
+                         ids=["REF0", "REF1", "REF_PADSEQ"])
+def test_mla_decode_on_the_references_own_inputs(cfg):
+    """`test_paged_decode_mla` (test_attention.py:1164-1187) with its generator and `w = randn_like(kv_b_proj)`.  The
+    reference states atol = rtol = 1e-2 but never ran it against a second implementation (its test skips: both sides are
+    the torch class).  At these magnitudes (|out| up to ~40) the golden's bf16 roundings of K/V, scores and probabilities
+    put the GOLDEN ITSELF ~1 away from the fp64 value of its own definition, so no accurate kernel can sit within 1e-2 of
+    it.  What is asserted on the reference's inputs: hip is closer to the exact value than the golden is, and hip differs
+    from the golden by no more than the golden's own error plus hip's.  The three numbers are printed and logged."""
+    b, h, nope, rope, vd, r, s, page = cfg
+    torch.manual_seed(0)
+    q, ckv, kpe, lens, table = _ref_decode_data(b, h, nope, rope, r, s, page)
+    ref = torch_cls("MojoPagedDecodeMLA")(h, nope, rope, vd, r).to(torch.bfloat16)
+    w = torch.randn_like(ref.kv_b_proj)
+    op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w, None, DEV)
+    with torch.no_grad():
+        ref.kv_b_proj.copy_(w)
+    golden = ref(q, ckv, kpe, lens, table)
+    got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens.to(DEV), table.to(DEV)))
+    exact = exact_mla(q, ckv, kpe, table, w, None, h, nope, rope, vd, r, lens.tolist())
+    rec = _report_triple(f"decode_mla_ref_inputs{cfg}", got, golden, exact)
+    assert got.shape == golden.shape and got.dtype == golden.dtype
+    slack = 2.0 ** -8 * max(rec["max_abs_exact"], 1.0)            # one bf16 ulp at the output's magnitude
+    assert rec["hip_vs_fp64"] <= rec["golden_vs_fp64"] + slack
+    assert rec["hip_vs_golden"] <= rec["golden_vs_fp64"] + rec["hip_vs_fp64"] + slack
+    # relative to the output's scale hip meets the reference's number against the TRUE value
+    assert rec["hip_vs_fp64"] <= 1e-2 * (1.0 + rec["max_abs_exact"])
+
+
+@pytest.mark.parametrize("cfg", [(2, 8, 64, 32, 64, 32, 48, 32), (3, 8, 64, 32, 64, 32, 0, 32)], ids=["REF0", "REF_PADSEQ"])
+def test_mla_prefill_on_the_references_own_inputs(cfg):
+    """`test_paged_prefill_mla` (test_attention.py:1235-1257), same statement as the decode case."""
+    b, h, nope, rope, vd, r, max_q, page = cfg
+    torch.manual_seed(0)
+    if max_q > 0:
+        q_lens = torch.randint(max_q // 2, max_q, (b,), dtype=torch.int32).clamp(min=1)
+    else:
+        q_lens = torch.randperm(b, dtype=torch.int32)
+    cu_q = torch.cat([torch.tensor([0], dtype=torch.int32), q_lens.cumsum(0, dtype=torch.int32)])
+    q = torch.randn(int(cu_q[-1]), h, nope + rope, dtype=torch.bfloat16)
+    max_nb = max((int(q_lens.max()) + page - 1) // page, 1)
+    total = int(torch.div(q_lens + page - 1, page, rounding_mode="floor").sum()) + 10
+    ckv = torch.zeros(total, 1, page, r, dtype=torch.bfloat16)
+    kpe = torch.zeros(total, 1, page, rope, dtype=torch.bfloat16)
+    table = torch.full((b, max_nb), -1, dtype=torch.int32)
+    free = torch.randperm(total)
+    off = 0
+    for i in range(b):
+        kl = int(q_lens[i])
+        nb = (kl + page - 1) // page
+        blocks = free[off:off + nb]
+        table[i, :nb] = blocks
+        off += nb
+        cd, pd = torch.randn(kl, r, dtype=torch.bfloat16), torch.randn(kl, rope, dtype=torch.bfloat16)
+        for j in range(nb):
+            s0, e0 = j * page, min((j + 1) * page, kl)
+            ckv[int(blocks[j]), 0, : e0 - s0] = cd[s0:e0]
+            kpe[int(blocks[j]), 0, : e0 - s0] = pd[s0:e0]
+    ref = torch_cls("MojoPagedPrefillMLA")(h, nope, rope, vd, r, is_causal=True).to(torch.bfloat16)
+    w = torch.randn_like(ref.kv_b_proj)
+    op = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, False, w, None, DEV, is_causal=True)
+    with torch.no_grad():
+        ref.kv_b_proj.copy_(w)
+    golden = ref(q, ckv, kpe, cu_q, table)
+    got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu_q.to(DEV), table.to(DEV)))
+    exact = exact_mla(q, ckv, kpe, table, w, None, h, nope, rope, vd, r, q_lens.tolist(), q_off=cu_q.tolist())
+    rec = _report_triple(f"prefill_mla_ref_inputs{cfg}", got, golden, exact)
+    slack = 2.0 ** -8 * max(rec["max_abs_exact"], 1.0)
+    assert rec["hip_vs_fp64"] <= rec["golden_vs_fp64"] + slack
+    assert rec["hip_vs_fp64"] <= 1e-2 * (1.0 + rec["max_abs_exact"])
+
+
+def test_mla_weight_repack_follows_the_parameter():
+    """The K-major copy of the absorbed key projection (decode-sized calls) must follow `kv_b_proj`: version-bumping
+    writes, `.to()`, `load_state_dict` and `refresh_weights()` all rebuild it; MOJO_HIP_VALIDATE=1 catches a `.data` write."""
+    import os
+    h, nope, rope, vd, r, page = 8, 128, 64, 128, 64, 16
+    ckv, kpe, table, w1, _ = make_mla([40, 7], h, nope, rope, vd, r, page, seed=1)
+    g = torch.Generator().manual_seed(5)
+    w2 = (torch.randn(h * (nope + vd), r, generator=g) * 0.2).to(torch.bfloat16)
+    q = torch.randn(2, h, nope + rope, generator=g).to(torch.bfloat16)
+    lens = torch.tensor([40, 7], dtype=torch.int32)
+    dev = [t.to(DEV) for t in (q, ckv, kpe, lens, table)]
+    op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w1, None, DEV)
+    fresh2 = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w2, None, DEV)
+    want1, want2 = op(*dev), fresh2(*dev)
+    assert not torch.equal(want1, want2)
+    with torch.no_grad():
+        op.kv_b_proj.copy_(w2.to(DEV))                       # bumps the version counter
+    assert torch.equal(op(*dev), want2)
+    op.load_state_dict({"kv_b_proj": w1.to(DEV)})
+    assert torch.equal(op(*dev), want1)
+    op.kv_b_proj.data.copy_(w2.to(DEV))                      # invisible to the version counter ...
+    os.environ["MOJO_HIP_VALIDATE"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="refresh_weights"):
+            op(*dev)
+    finally:
+        os.environ.pop("MOJO_HIP_VALIDATE", None)
+    op.refresh_weights()                                     # ... until the caller says so
+    assert torch.equal(op(*dev), want2)

@@ -129,3 +129,100 @@ def test_quant_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(m, k, 
     monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")
     direct = op(x, s_in)
     assert torch.equal(staged, direct)
+
+
+# ---- BASELINE config 5 at full size (DeepSeek-V3 dense projections, M = 4096) -------------------------------------------
+FULL_SHAPES = [(4096, 7168, 36864), (4096, 18432, 7168)]
+
+
+def _sample_rows(m, g):
+    return torch.cat([torch.arange(0, 16), torch.arange(m - 16, m), torch.randint(16, m - 16, (96,), generator=g)]).unique()
+
+
+@pytest.mark.parametrize("m,k,n", FULL_SHAPES)
+def test_quant_gemm_int8_full_size_exact(m, k, n):
+    """int8 at the benchmarked shapes.  The exact integer formula is evaluated on the host for a sample of whole rows
+    (first / last 16 and 96 random ones: 128 x K x N in float64) and must match at atol = rtol = 0 in all three output
+    dtypes' worth of rounding (bf16 checked, fp32 with unit scales for the checksum); every other element is covered by a
+    checksum of checksums: with unit scales and fp32 output each element is the exact integer sum, so the column sums of
+    the whole [M, N] result must equal (sum_m x[m, :]) @ W exactly."""
+    g = torch.Generator().manual_seed(k + n)
+    xq, xs = _quantize(torch.randn(m, k, generator=g))
+    wq, ws = _quantize(torch.randn(n, k, generator=g))
+    rows = _sample_rows(m, g)
+    op = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.bfloat16, trans_weight=True, device=DEV)
+    op.weight.copy_(wq)
+    op.weight_scale.copy_(ws.to(torch.bfloat16))
+    out = op(xq.to(DEV), xs.to(DEV))
+    expect = quant_gemm_formula(xq[rows], wq.t(), xs[rows], ws.to(torch.bfloat16), torch.bfloat16)
+    torch.testing.assert_close(to_cpu(out[rows.to(DEV)]), expect, atol=0, rtol=0)
+    del out
+    op32 = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.float32, trans_weight=True, device=DEV)
+    op32.weight.copy_(wq)
+    op32.weight_scale.fill_(1.0)
+    raw = op32(xq.to(DEV), torch.ones(m, device=DEV))
+    assert float(raw.abs().max()) < 2 ** 24                     # every element is an exactly represented integer
+    col = raw.double().sum(0).cpu()
+    want = xq.double().sum(0) @ wq.double().t()
+    assert torch.equal(col, want)
+    torch.testing.assert_close(to_cpu(raw[rows.to(DEV)]), (xq[rows].double() @ wq.double().t()).float(), atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("m,k,n", FULL_SHAPES)
+def test_quant_gemm_fp8_full_size(m, k, n):
+    """fp8-e4m3 (extension, PARITY UNPINNED: no reference implementation) at the benchmarked shapes: sampled whole rows
+    against the float64 formula, and the column-sum identity to fp32-accumulation tolerance."""
+    f8 = torch.float8_e4m3fn
+    g = torch.Generator().manual_seed(k + n + 1)
+    x = torch.randn(m, k, generator=g).to(f8)
+    w = torch.randn(n, k, generator=g).to(f8)
+    s_in, s_w = torch.rand(m, generator=g) + 0.5, (torch.rand(n, generator=g) + 0.5).to(torch.bfloat16)
+    rows = _sample_rows(m, g)
+    op = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.bfloat16, trans_weight=True,
+                                  quant_dtype=f8, weight_dtype=f8, device=DEV)
+    op.weight.copy_(w)
+    op.weight_scale.copy_(s_w)
+    out = op(x.to(DEV), s_in.to(DEV))
+    exact = quant_gemm_formula(x[rows], w.t(), s_in[rows], s_w, torch.bfloat16)
+    torch.testing.assert_close(to_cpu(out[rows.to(DEV)]).float(), exact.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -7)
+    op32 = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.float32, trans_weight=True,
+                                    quant_dtype=f8, weight_dtype=f8, device=DEV)
+    op32.weight.copy_(w)
+    op32.weight_scale.fill_(1.0)
+    raw = op32(x.to(DEV), torch.ones(m, device=DEV))
+    col = raw.double().sum(0).cpu()
+    want = x.double().sum(0) @ w.double().t()
+    torch.testing.assert_close(col, want, atol=1e-3 * (m * k) ** 0.5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("quant_dtype", [torch.int8, torch.float8_e4m3fn])
+def test_quant_gemm_split_k_route_is_deterministic_and_exact(quant_dtype, monkeypatch):
+    """M >= 256 with few output tiles: each K slice writes its own fp32 / int32 slab and a finalize kernel sums the slabs in
+    a fixed order.  Forced here with 1 (no split), 2 and 8 slices: int8 is bit-identical across all of them and to the
+    integer formula; fp8 is bit-stable run to run for a given split and within tolerance of the float64 formula."""
+    m, k, n = 512, 4096, 520
+    g = torch.Generator().manual_seed(21)
+    if quant_dtype == torch.int8:
+        x, xs = _quantize(torch.randn(m, k, generator=g))
+        w, ws = _quantize(torch.randn(n, k, generator=g))
+    else:
+        x, w = torch.randn(m, k, generator=g).to(quant_dtype), torch.randn(n, k, generator=g).to(quant_dtype)
+        xs, ws = torch.rand(m, generator=g) + 0.5, torch.rand(n, generator=g) + 0.5
+    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=torch.bfloat16, trans_weight=True, quant_dtype=quant_dtype,
+                                  weight_dtype=quant_dtype, device=DEV)
+    op.weight.copy_(w)
+    op.weight_scale.copy_(ws.to(torch.bfloat16))
+    exact = quant_gemm_formula(x, w.t(), xs, ws.to(torch.bfloat16), torch.bfloat16)
+    outs = {}
+    for sk in ("1", "2", "8"):
+        monkeypatch.setenv("MOJO_HIP_QGEMM_SPLITK", sk)
+        a = op(x.to(DEV), xs.to(DEV))
+        b = op(x.to(DEV), xs.to(DEV))
+        assert torch.equal(a, b), f"split {sk}: not deterministic"
+        outs[sk] = to_cpu(a)
+        if quant_dtype == torch.int8:
+            torch.testing.assert_close(outs[sk], exact, atol=0, rtol=0)
+        else:
+            torch.testing.assert_close(outs[sk].float(), exact.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -7)
+    if quant_dtype == torch.int8:
+        assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["8"])
