@@ -95,10 +95,33 @@ def decode_algorithmic_bytes(lens, max_blocks):
     return kv + qo + idx
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, cut by the cgroup CPU quota when one is set.  torch sizes
+    its pool from the cores it SEES; on a box that grants 16 of 128 an all-cores OpenMP team spins on itself."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(budget_s=12.0):
     """Oracle (port of the reference's torch golden) on the host cores: 4 sequences of the same shape."""
     import mojo_opset_amd as mo
     import oracle  # noqa: F401
+
+    torch.set_num_threads(usable_cores())
 
     sample_b = 4
     (q, k, v, lens, table), = build_decode_inputs("cpu", batch=sample_b, sets=1)

@@ -59,6 +59,13 @@ def hip(name):
     return getattr(mo, name).get_backend_impl("hip", strict=True)
 
 
+def _want(case_name):
+    """MOJO_BENCH_ONLY=<substring>: run only the cases whose name contains it (one case per profiled process, so the rows of
+    a kernel trace belong to one case)."""
+    only = os.environ.get("MOJO_BENCH_ONLY")
+    return not only or only in case_name
+
+
 def _mfma(t, flops, peak=MFMA_BF16_PEAK_TFLOPS):
     tf = flops / t / 1e12
     return {"us": t * 1e6, "tflops": tf, "frac_of_mfma_peak": tf / peak}
@@ -101,6 +108,8 @@ def bench_group_gemm(device):
         "mixtral_up_16384_skewed_KN": (16384, 4096, 28672, 8, False, "skewed"),
         "mixtral_up_4096x4096x28672_G8_KN": (4096, 4096, 28672, 8, False, "balanced"),
     }.items():
+        if not _want(name):
+            continue
         out[name] = group_gemm_case(device, m, k, n, g, trans, split)
         torch.cuda.empty_cache()
     return out
@@ -111,6 +120,8 @@ def bench_quant_gemm(device):
     for qname, qd, peak in (("int8", torch.int8, MFMA_I8_PEAK_TOPS), ("fp8_e4m3", torch.float8_e4m3fn, MFMA_FP8_PEAK_TFLOPS)):
         for m, k, n in ((4096, 7168, 36864), (4096, 18432, 7168), (128, 7168, 4096), (32, 7168, 4096), (1, 7168, 4096),
                         (32, 18432, 7168)):
+            if not _want(f"{qname}_{m}x{k}x{n}_NK"):
+                continue
             op = hip("MojoQuantGemm")(k, n, trans_weight=True, quant_dtype=qd, weight_dtype=qd, device=device)
             if qd == torch.int8:
                 op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=device))
@@ -155,6 +166,8 @@ def bench_decode_variants(device):
     for name, lens in {"uniform_ctx1024": [1024] * bsz, "uniform_ctx16384": [16384] * bsz,
                        "ragged_ctx2048_4096": torch.randint(2048, 4097, (bsz,), generator=g).tolist(),
                        "ragged_ctx8192_16384": torch.randint(8192, 16385, (bsz,), generator=g).tolist()}.items():
+        if not _want(name):
+            continue
         sets = []
         for _ in range(2 if max(lens) <= 4096 else 1):                      # 2 x >= 256 MB defeats the MALL at the short contexts
             k, v, table = _paged(device, lens, hkv, d, page)
@@ -185,6 +198,8 @@ def bench_prefill(device):
     for name, (q_lens, cached) in {"4x2048_nocache": ([2048] * 4, [0] * 4), "4x2048_cached2048": ([2048] * 4, [2048] * 4),
                                    "16_ragged_512_1024_nocache": (ragged, [0] * 16),
                                    "1x16384_nocache": ([16384], [0])}.items():
+        if not _want(name):
+            continue
         kv = [a + b for a, b in zip(q_lens, cached)]
         k, v, table = _paged(device, kv, hkv, d, page)
         q = torch.randn(sum(q_lens), hq, d, device=device, dtype=torch.bfloat16)
@@ -226,6 +241,8 @@ def bench_mla_prefill(device):
         op.kv_b_proj.copy_(torch.randn_like(op.kv_b_proj) * 0.02)
     out = {}
     for name, (q_lens, cached) in {"4x512_nocache": ([512] * 4, [0] * 4), "4x512_cached2048": ([512] * 4, [2048] * 4)}.items():
+        if not _want(name):
+            continue
         kv = [a + b for a, b in zip(q_lens, cached)]
         need = [(n + page - 1) // page for n in kv]
         total = sum(need) + 4
@@ -237,8 +254,19 @@ def bench_mla_prefill(device):
         q = torch.randn(sum(q_lens), h, nope + rope, device=device, dtype=torch.bfloat16)
         t = _time(lambda: op(q, ckv, kpe, cu_q, table, cu_total_seq_lens=cu_kv), 5, 1)
         vis = sum(a * b - a * (a - 1) / 2.0 for a, b in zip(q_lens, kv))          # visible (query, key) pairs
-        flops = 2.0 * h * vis * (2 * r + rope) + 2.0 * sum(q_lens) * h * r * (nope + vd)
-        out[name] = _mfma(t, flops)
+        # FLOPs of the formulation that runs (the golden's own: decompress every key once, then D_qk = 192 / D_v = 128
+        # attention) and, for continuity with round 1, of the weight-absorbed formulation of the same result
+        flops = 2.0 * sum(kv) * r * h * (nope + vd) + 2.0 * h * vis * (nope + rope + vd)
+        flops_absorbed = 2.0 * h * vis * (2 * r + rope) + 2.0 * sum(q_lens) * h * r * (nope + vd)
+        res = _mfma(t, flops)
+        res["absorbed_form_equivalent_tflops"] = flops_absorbed / t / 1e12
+        os.environ["MOJO_HIP_MLA_PREFILL"] = "absorbed"
+        try:
+            t_abs = _time(lambda: op(q, ckv, kpe, cu_q, table, cu_total_seq_lens=cu_kv), 3, 1)
+        finally:
+            os.environ.pop("MOJO_HIP_MLA_PREFILL", None)
+        res["absorbed_route_us"] = t_abs * 1e6
+        out[name] = res
     return out
 
 

@@ -129,6 +129,62 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     return out
 
 
+def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tables, softmax_scale, cu_total_seq_lens):
+    """Prefill in the golden's own formulation (experimental/operators/attention.py:405-447): un-page the latent,
+    decompress K_nope / V for every key with ONE GEMM (rounded to the storage type, like `c_kv @ kv_b_proj.T`), then flash
+    attention per head with D_qk = nope + rope, D_v = v (csrc/mla_prefill.hip).  3.4x fewer FLOPs than running the
+    absorbed decode kernel per query token at DeepSeek-V3 dimensions, and the golden's rounding points.  Returns None when
+    this route does not apply (dimensions without an instantiation, or a key capacity whose decompressed image would not
+    fit the budget) — the caller then takes the absorbed route."""
+    lib = L.load()
+    tq, heads, qk = query.shape
+    nope, rope, vdim, r = op.qk_nope_head_dim, op.qk_rope_head_dim, op.v_head_dim, op.kv_lora_rank
+    if not lib.mojo_hip_mla_prefill_supported(nope, rope, vdim, L.dtype_code(query.dtype)):
+        return None
+    if os.environ.get("MOJO_HIP_MLA_PREFILL", "decompress") == "absorbed":
+        return None
+    dev, dt = query.device, query.dtype
+    batch, width = block_tables.shape
+    page = ckv_cache.shape[2]
+    # host-side bound of the number of keys (lengths stay on the device: no sync)
+    cap = tq if cu_total_seq_lens is None else min(batch * width * page, ckv_cache.shape[0] * page)
+    per_seq_cap = min(tq, width * page) if cu_total_seq_lens is None else width * page
+    kv_cols = heads * (nope + vdim)
+    budget = int(os.environ.get("MOJO_HIP_MLA_PREFILL_BYTES", str(8 << 30)))
+    if cap <= 0 or cap * kv_cols * query.element_size() > budget:
+        return None
+    proj = op.kv_b_proj.detach()
+    proj = proj if proj.is_contiguous() else proj.contiguous()
+    if query.stride(2) != 1 or query.stride(1) != qk or query.stride(0) != heads * qk:
+        query = query.contiguous()
+    tables = block_tables if block_tables.stride(1) == 1 else block_tables.contiguous()
+    cu_q = cu_q_lens.contiguous()
+    cu_kv = None if cu_total_seq_lens is None else cu_total_seq_lens.contiguous()
+    stream = L.stream_of(query)
+    ckv_flat = torch.empty(cap, r, dtype=dt, device=dev)
+    kpe_flat = torch.empty(cap, rope, dtype=dt, device=dev)
+    L.check(lib.mojo_hip_mla_unpage(L.ptr(ckv_cache), L.ptr(kpe_cache), L.ptr(ckv_flat), L.ptr(kpe_flat), L.ptr(cu_q),
+                                    L.ptr(cu_kv), L.ptr(tables), tables.stride(0), width, batch, r, rope, page,
+                                    query.element_size(), ckv_cache.stride(0), ckv_cache.stride(2), kpe_cache.stride(0),
+                                    kpe_cache.stride(2), per_seq_cap, stream), "hip mla un-page")
+    # kv[t, h*(nope+v) + j] = sum_k ckv[t, k] * kv_b_proj[h*(nope+v) + j, k]: one group whose row count is the device-side
+    # total number of keys (the last entry of the cumulative lengths), so rows past it are never computed
+    kv = torch.empty(cap, kv_cols, dtype=dt, device=dev)
+    counts = cu_q if cu_kv is None else cu_kv
+    count_ptr = L.c_void_p(counts.data_ptr() + 4 * batch)
+    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(1), dtype=torch.uint8, device=dev)
+    L.check(lib.mojo_hip_group_gemm(L.ptr(ckv_flat), L.ptr(proj), L.ptr(kv), count_ptr, 0, cap, r, kv_cols, 1, 1,
+                                    L.dtype_code(dt), L.ptr(ws), ws.numel(), stream), "hip mla decompression")
+    out = torch.empty(tq, heads, vdim, dtype=dt, device=dev)
+    sink = getattr(op, "attn_sink", None)
+    sink = None if sink is None else sink.detach().to(torch.float32).contiguous()
+    scale = 1.0 / math.sqrt(nope + rope) if softmax_scale is None else float(softmax_scale)
+    L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), L.ptr(cu_q),
+                                          L.ptr(cu_kv), tq, batch, heads, nope, rope, vdim, min(tq, per_seq_cap), scale,
+                                          L.dtype_code(dt), stream), "hip mla prefill attention")
+    return out
+
+
 class HIPPagedDecodeMLA(_AbsorbedWeightCache, MojoPagedDecodeMLA):
     supported_platforms_list = _ROCM
 
@@ -147,5 +203,12 @@ class HIPPagedPrefillMLA(_AbsorbedWeightCache, MojoPagedPrefillMLA):
         assert_paged_prefill_contract(cu_q_lens, block_tables, cu_total_seq_lens)
         if not self.is_causal:
             raise NotImplementedError("HIPPagedPrefillMLA supports causal attention only")
+        if query.shape[0] > 0 and query.is_cuda and self.kv_b_proj.dtype == query.dtype == compressed_kv_cache.dtype == k_pe_cache.dtype \
+                and compressed_kv_cache.stride(3) == 1 and k_pe_cache.stride(3) == 1 and query.shape[0] >= 16:
+            L.require_cuda(query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables, cu_total_seq_lens, self.kv_b_proj)
+            out = _prefill_decompressed(self, query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables, softmax_scale,
+                                        cu_total_seq_lens)
+            if out is not None:
+                return out
         return _mla_forward(self, query, compressed_kv_cache, k_pe_cache, block_tables, softmax_scale,
                             cu_q_lens=cu_q_lens, cu_total_seq_lens=cu_total_seq_lens)

@@ -181,6 +181,15 @@ static int fill_ptrs(PeerPtrs& pp, void* const* data, void* const* flags, int ws
   return MOJO_OK;
 }
 
+static int peer_max_blocks() {
+  static const int v = [] {
+    const char* e = getenv("MOJO_HIP_PEER_BLOCKS");
+    const int n = e ? atoi(e) : 64;
+    return n >= 1 ? n : 64;
+  }();
+  return v;
+}
+
 static long long timeout_ticks() {
   static const long long t = [] {
     const char* e = getenv("MOJO_HIP_PEER_TIMEOUT_MS");
@@ -296,8 +305,12 @@ template <typename T>
 static int launch_reduce(const PeerPtrs& pp, int ws, int rank, int chunk, uint32_t epoch, int64_t src_off, int64_t rows,
                          int64_t n, void* dst, int64_t ld_dst, int write_back, hipStream_t s) {
   const int64_t vecs = rows * (n / (16 / static_cast<int64_t>(sizeof(T))));
+  // Few workgroups: they share the chip with the next chunk's GEMM, whose workgroups need a whole CU each (all of its
+  // registers and 128 KiB of LDS) — a waiting pull workgroup on every CU would keep that GEMM off the chip until the peers
+  // have signalled (and, with two ranks time-sharing ONE GPU as in the tests, for ever: the peer's GEMM is what it waits for).
+  // 64 workgroups keep > 1 MiB of 16-byte reads in flight, far more than seven xGMI links need.
   int64_t blocks = ceil_div(vecs, 256 * 2);
-  if (blocks > 256) blocks = 256;                     // few workgroups: they share the chip with the next chunk's GEMM
+  if (blocks > peer_max_blocks()) blocks = peer_max_blocks();
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(peer_reduce_kernel<T>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, pp, ws, rank, chunk, epoch,
                      static_cast<long long>(src_off), static_cast<long long>(rows), static_cast<int>(n), static_cast<T*>(dst),
@@ -346,7 +359,7 @@ extern "C" int mojo_hip_peer_gather(void* const* peer_data, void* const* peer_fl
   const int ws = static_cast<int>(world), rk = static_cast<int>(rank), ck = static_cast<int>(chunk);
   const int64_t share_vecs = ceil_div(rows, world) * (n / ve);
   int64_t bx = ceil_div(share_vecs, 256 * 2);
-  if (bx > 32) bx = 32;
+  if (bx > peer_max_blocks() / (ws - 1)) bx = peer_max_blocks() / (ws - 1);     // same budget as the pull-and-add launch
   if (bx < 1) bx = 1;
   const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(ws - 1));
   const long long tt = timeout_ticks();

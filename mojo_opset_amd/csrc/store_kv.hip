@@ -15,7 +15,10 @@ struct StoreArgs {
   int64_t tokens, heads, row_bytes, num_blocks, page;
   int64_t src_tok, src_head;          // bytes
   int64_t c_blk, c_head, c_tok;       // bytes
-  int tensors = 2;                    // 1: only ks -> kc (the MLA latent caches are stored one tensor per launch)
+  // second tensor's own geometry (the layout kernel only; equal to the first tensor's for K/V, different for the MLA
+  // store, where the compressed latent and the positional key have different widths and both go out in ONE launch)
+  int64_t row_bytes_v, src_tok_v, src_head_v, c_blk_v, c_head_v, c_tok_v;
+  int tensors = 2;                    // 1: only ks -> kc
   int stop_at_hole = 0;               // MLA store: a negative page id ends the sequence's store (and page 0 < 0 skips it)
 };
 
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(256) void store_layout_kernel(StoreArgs a, const in
                                                            const int32_t* __restrict__ cu_q,
                                                            const int32_t* __restrict__ ctx_lens, int64_t batch) {
   const int pieces = static_cast<int>(a.row_bytes / VB);
+  const int pieces_v = static_cast<int>(a.row_bytes_v / VB);
   const int64_t per_tensor = a.heads * pieces;
-  const int64_t per_token = a.tensors * per_tensor;
+  const int64_t per_token = per_tensor + (a.tensors == 2 ? a.heads * pieces_v : 0);
   const int tok_per_block = blockDim.x / 64;                 // one wave per token
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int64_t t = static_cast<int64_t>(blockIdx.x) * tok_per_block + wave; t < a.tokens;
@@ -114,11 +118,13 @@ __global__ __launch_bounds__(256) void store_layout_kernel(StoreArgs a, const in
     const int64_t slot = pos - lp * a.page;
     for (int64_t w = lane; w < per_token; w += 64) {
       const int which = w >= per_tensor;
-      int64_t r = which ? w - per_tensor : w;
-      const int p = static_cast<int>(r % pieces);
-      const int h = static_cast<int>(r / pieces);
-      const char* src = (which ? a.vs : a.ks) + t * a.src_tok + h * a.src_head + p * VB;
-      char* dst = (which ? a.vc : a.kc) + blk * a.c_blk + h * a.c_head + slot * a.c_tok + p * VB;
+      const int64_t r = which ? w - per_tensor : w;
+      const int pc = which ? pieces_v : pieces;
+      const int p = static_cast<int>(r % pc);
+      const int h = static_cast<int>(r / pc);
+      const char* src = which ? a.vs + t * a.src_tok_v + h * a.src_head_v + p * VB : a.ks + t * a.src_tok + h * a.src_head + p * VB;
+      char* dst = which ? a.vc + blk * a.c_blk_v + h * a.c_head_v + slot * a.c_tok_v + p * VB
+                        : a.kc + blk * a.c_blk + h * a.c_head + slot * a.c_tok + p * VB;
       copy_piece<VB>(src, dst);
     }
   }
@@ -128,7 +134,8 @@ static int pick_vb(const StoreArgs& a) {
   auto ok = [&](int vb) {
     return a.row_bytes % vb == 0 && a.src_tok % vb == 0 && a.src_head % vb == 0 && a.c_blk % vb == 0 &&
            a.c_head % vb == 0 && a.c_tok % vb == 0 && aligned_to(a.ks, vb) && aligned_to(a.kc, vb) &&
-           (a.tensors == 1 || (aligned_to(a.vs, vb) && aligned_to(a.vc, vb)));
+           (a.tensors == 1 || (aligned_to(a.vs, vb) && aligned_to(a.vc, vb) && a.row_bytes_v % vb == 0 && a.src_tok_v % vb == 0 &&
+                               a.src_head_v % vb == 0 && a.c_blk_v % vb == 0 && a.c_head_v % vb == 0 && a.c_tok_v % vb == 0));
   };
   for (int vb : {16, 8, 4, 2})
     if (ok(vb)) return vb;
@@ -148,6 +155,8 @@ static int fill_args(StoreArgs& a, const void* ks, const void* vs, void* kc, voi
   a.tokens = tokens; a.heads = heads; a.row_bytes = dim * eb; a.num_blocks = num_blocks; a.page = page;
   a.src_tok = s_tok * eb; a.src_head = s_head * eb;
   a.c_blk = c_blk * eb; a.c_head = c_head * eb; a.c_tok = c_tok * eb;
+  a.row_bytes_v = a.row_bytes; a.src_tok_v = a.src_tok; a.src_head_v = a.src_head;
+  a.c_blk_v = a.c_blk; a.c_head_v = a.c_head; a.c_tok_v = a.c_tok;
   return MOJO_OK;
 }
 
@@ -226,18 +235,29 @@ extern "C" int mojo_hip_store_paged_kv_layout(const void* key_states, const void
 }
 
 // ---- MojoStorePagedMLAKVCache (experimental/operators/kv_cache.py:13-106): the compressed-KV latent and the positional
-//      key have different widths, so they go out as two single-tensor launches of the layout kernel, with the MLA
-//      store's own hole semantics (a negative page id ends that sequence's store).
-static int store_one_mla(const void* states, void* cache, const int32_t* block_table, int64_t block_table_stride,
-                         int64_t max_blocks_per_seq, const int32_t* cu_q_lens, const int32_t* context_kv_lens,
-                         int64_t batch, int64_t num_tokens, int64_t width, int64_t num_blocks, int64_t block_size,
-                         int64_t elt_bytes, int64_t src_token_stride, int64_t cache_block_stride,
-                         int64_t cache_token_stride, hipStream_t s) {
+//      key have different widths; they are the "first" and "second" tensor of ONE launch of the layout kernel (each with its
+//      own row width and strides), with the MLA store's own hole semantics (a negative page id ends that sequence's store).
+extern "C" int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_pe_states,
+                                           void* compressed_kv_cache, void* k_pe_cache, const int32_t* block_table,
+                                           int64_t block_table_stride, int64_t max_blocks_per_seq,
+                                           const int32_t* cu_q_lens, const int32_t* context_kv_lens, int64_t batch,
+                                           int64_t num_tokens, int64_t kv_lora_rank, int64_t rope_dim,
+                                           int64_t num_blocks, int64_t block_size, int64_t elt_bytes,
+                                           int64_t ckv_src_token_stride, int64_t kpe_src_token_stride,
+                                           int64_t ckv_block_stride, int64_t ckv_token_stride,
+                                           int64_t kpe_block_stride, int64_t kpe_token_stride, mojo_stream_t stream) {
+  if (num_tokens == 0 || batch == 0 || max_blocks_per_seq == 0) return MOJO_OK;
+  MOJO_REQUIRE(compressed_kv_states && k_pe_states && compressed_kv_cache && k_pe_cache && block_table && context_kv_lens,
+               MOJO_EINVAL, "store_paged_mla_kv: null pointer");
+  MOJO_REQUIRE(rope_dim > 0, MOJO_EINVAL, "store_paged_mla_kv: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
   StoreArgs a;
-  int rc = fill_args(a, states, nullptr, cache, nullptr, num_tokens, 1, width, num_blocks, block_size, elt_bytes,
-                     src_token_stride, 0, cache_block_stride, 0, cache_token_stride);
+  int rc = fill_args(a, compressed_kv_states, k_pe_states, compressed_kv_cache, k_pe_cache, num_tokens, 1, kv_lora_rank,
+                     num_blocks, block_size, elt_bytes, ckv_src_token_stride, 0, ckv_block_stride, 0, ckv_token_stride);
   if (rc) return rc;
-  a.tensors = 1;
+  a.row_bytes_v = rope_dim * elt_bytes; a.src_tok_v = kpe_src_token_stride * elt_bytes; a.src_head_v = 0;
+  a.c_blk_v = kpe_block_stride * elt_bytes; a.c_head_v = 0; a.c_tok_v = kpe_token_stride * elt_bytes;
+  a.tensors = 2;
   a.stop_at_hole = 1;
   const int vb = pick_vb(a);
   MOJO_REQUIRE(vb != 0, MOJO_EUNSUPPORTED, "store_paged_mla_kv: rows are not even 2-byte aligned");
@@ -256,26 +276,4 @@ static int store_one_mla(const void* states, void* cache, const int32_t* block_t
 #undef LAUNCH
   MOJO_CHECK_LAUNCH("store_paged_mla_kv");
   return MOJO_OK;
-}
-
-extern "C" int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_pe_states,
-                                           void* compressed_kv_cache, void* k_pe_cache, const int32_t* block_table,
-                                           int64_t block_table_stride, int64_t max_blocks_per_seq,
-                                           const int32_t* cu_q_lens, const int32_t* context_kv_lens, int64_t batch,
-                                           int64_t num_tokens, int64_t kv_lora_rank, int64_t rope_dim,
-                                           int64_t num_blocks, int64_t block_size, int64_t elt_bytes,
-                                           int64_t ckv_src_token_stride, int64_t kpe_src_token_stride,
-                                           int64_t ckv_block_stride, int64_t ckv_token_stride,
-                                           int64_t kpe_block_stride, int64_t kpe_token_stride, mojo_stream_t stream) {
-  if (num_tokens == 0 || batch == 0 || max_blocks_per_seq == 0) return MOJO_OK;
-  MOJO_REQUIRE(compressed_kv_states && k_pe_states && compressed_kv_cache && k_pe_cache && block_table && context_kv_lens,
-               MOJO_EINVAL, "store_paged_mla_kv: null pointer");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  int rc = store_one_mla(compressed_kv_states, compressed_kv_cache, block_table, block_table_stride, max_blocks_per_seq,
-                         cu_q_lens, context_kv_lens, batch, num_tokens, kv_lora_rank, num_blocks, block_size, elt_bytes,
-                         ckv_src_token_stride, ckv_block_stride, ckv_token_stride, s);
-  if (rc) return rc;
-  return store_one_mla(k_pe_states, k_pe_cache, block_table, block_table_stride, max_blocks_per_seq, cu_q_lens,
-                       context_kv_lens, batch, num_tokens, rope_dim, num_blocks, block_size, elt_bytes,
-                       kpe_src_token_stride, kpe_block_stride, kpe_token_stride, s);
 }

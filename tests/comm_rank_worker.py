@@ -10,8 +10,9 @@ repository's own pull-and-add kernel over HIP-IPC peer buffers instead.
 
 Checks (reference: tests/accuracy/operators/test_compute_with_comm.py):
   * the reference's per-rank vectors (tests/golden/compute_with_comm.pt) at the reference's bounds (5e-3 / 1e-4);
-  * the oracle classes running over the same gloo group on CPU copies of the same per-rank inputs, at the
-    reference's shapes and seeds (:97-103, :141-146, :180-185, :215-247).
+  * the oracle classes running over the same gloo group on CPU copies of the same per-rank inputs, at the reference's
+    seeds and a quarter of each of its dimensions (:97-103, :141-146, :180-185, :215-247), and the golden's definition in
+    fp32 torch on the device at the reference's full shapes (a full-size fp16 product takes the box's CPU share ~40 s).
 Writes one JSON line per check to stdout; exits non-zero on the first failure.
 """
 import json
@@ -35,8 +36,12 @@ def _ulps(got, want):
 
 
 def _report(rank, **kw):
-    if rank == 0:
-        print(json.dumps(kw), flush=True)
+    print(json.dumps(kw), flush=True)
+    try:                                       # progress files: a long multi-process run must not look hung from outside
+        with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"comm_ranks_progress_rank{rank}.log"), "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
 
 
 def _compare(rank, name, got, want, tol):
@@ -82,38 +87,87 @@ def check_vectors(rank, ws, group):
         _compare(rank, f"vector:{case['op']}:{case['name']}", got, want, 5e-3 if x.dtype != torch.float32 else 1e-4)
 
 
+_CACHE = {}
+
+
+def _cached(key, make):
+    if key not in _CACHE:
+        _CACHE[key] = make()
+    return _CACHE[key]
+
+
+def _device_closed_form(ws, rank, m, k, n, dtype, op):
+    """What the golden defines, evaluated without communication on this rank's GPU in fp32 torch (the allowed fp32
+    reference of a floating-point kernel): every rank's inputs follow from its seed (42 + r), its product is rounded to the
+    storage type, the rounded products are added in the storage type (2 ranks: one addition, order-free)."""
+    kl = k // ws
+    total = None
+    for r in range(ws):
+        torch.manual_seed(42 + r)
+        x = torch.randn(m, kl, dtype=dtype).to(DEV)
+        w = torch.randn(kl, n, dtype=dtype).to(DEV)
+        y = (x.float() @ w.float()).to(dtype)
+        total = y if total is None else (total + y)
+    if op == "MojoGemmReduceScatter":
+        total = total.chunk(ws, dim=0)[rank]
+    return total.cpu()
+
+
 def check_reference_shapes(rank, ws, group):
-    """The reference's own cases, same seeds; the oracle (CPU, over the same gloo group) is the other side."""
+    """The reference's own cases and seeds (tests/accuracy/operators/test_compute_with_comm.py:97-103, :141-146, :180-185,
+    :215-247).  The pinned oracle (CPU golden classes over the same gloo group) is the other side at a QUARTER of every
+    dimension — the box grants 16 CPU cores and has no fast fp16 GEMM: one full-size fp16 oracle product takes ~40 s there —
+    and at the reference's full shapes the other side is the golden's definition evaluated in fp32 torch on the device."""
     import torch.nn.functional as F
 
     from hip_utils import hip_cls, torch_cls
 
-    # GemmAllReduce / GemmReduceScatter: test_compute_with_comm.py:141-146 / :180-185, per-rank seed 42 + rank
-    for m, k, n, dtype in ((4096, 4096, 4096, torch.float16), (2048, 8192, 4096, torch.float16),
-                           (8192, 4096, 2048, torch.float16), (4096, 4096, 4096, torch.bfloat16)):
-        kl = k // ws
-        torch.manual_seed(42 + rank)
-        x = torch.randn(m, kl, dtype=dtype)
-        w = torch.randn(kl, n, dtype=dtype)
-        for name, kw in (("MojoGemmAllReduce", {}), ("MojoGemmReduceScatter", {"scatter_dim": 0})):
-            want = torch_cls(name)(weight=w, bias=None, trans_weight=True, process_group=group, **kw)(x)
-            got = hip_cls(name)(weight=w.to(DEV), bias=None, trans_weight=True, process_group=group, **kw)(x.to(DEV))
-            torch.cuda.synchronize()
-            _compare(rank, f"oracle:{name}:{m}x{k}x{n}:{str(dtype)[6:]}", got, want, 5e-3)
+    full = ((4096, 4096, 4096, torch.float16), (2048, 8192, 4096, torch.float16), (8192, 4096, 2048, torch.float16),
+            (4096, 4096, 4096, torch.bfloat16))
+    for scale in (4, 1):
+        for m0, k0, n0, dtype in full:
+            m, k, n = m0 // scale, k0 // scale, n0 // scale
+            kl = k // ws
+            torch.manual_seed(42 + rank)
+            x = torch.randn(m, kl, dtype=dtype)
+            w = torch.randn(kl, n, dtype=dtype)
+            tag = f"{m}x{k}x{n}:{str(dtype)[6:]}"
+            for name, kw in (("MojoGemmAllReduce", {}), ("MojoGemmReduceScatter", {"scatter_dim": 0})):
+                if scale == 1:
+                    want = _cached((name, tag), lambda: _device_closed_form(ws, rank, m, k, n, dtype, name))
+                    side = "fp32ref"
+                else:
+                    want = _cached((name, tag), lambda: torch.as_tensor(
+                        torch_cls(name)(weight=w, bias=None, trans_weight=True, process_group=group, **kw)(x)).clone())
+                    side = "oracle"
+                got = hip_cls(name)(weight=w.to(DEV), bias=None, trans_weight=True, process_group=group, **kw)(x.to(DEV))
+                torch.cuda.synchronize()
+                _compare(rank, f"{side}:{name}:{tag}", got, want, 5e-3)
     # AllGatherGemm: :97-103, one seed for all ranks, [N, K] weights, bias in the fp16 cases
-    for m, k, n, dtype, use_bias in ((4096, 4096, 4096, torch.float16, True), (2048, 4096, 8192, torch.float16, True),
-                                     (8192, 2048, 4096, torch.float16, True), (4096, 4096, 4096, torch.bfloat16, False)):
-        torch.manual_seed(42)
-        x_full = torch.randn(m, k, dtype=dtype)
-        w = torch.randn(n, k, dtype=dtype)
-        b = torch.randn(n, dtype=dtype) if use_bias else None
-        ml = m // ws
-        x = x_full[rank * ml:(rank + 1) * ml].contiguous()
-        want = torch_cls("MojoAllGatherGemm")(weight=w, bias=b, trans_weight=False, gather_dim=0, process_group=group)(x)
-        got = hip_cls("MojoAllGatherGemm")(weight=w.to(DEV), bias=None if b is None else b.to(DEV), trans_weight=False,
-                                           gather_dim=0, process_group=group)(x.to(DEV))
-        torch.cuda.synchronize()
-        _compare(rank, f"oracle:MojoAllGatherGemm:{m}x{k}x{n}:{str(dtype)[6:]}", got, want, 5e-3)
+    for scale in (4, 1):
+        for m0, k0, n0, dtype, use_bias in ((4096, 4096, 4096, torch.float16, True), (2048, 4096, 8192, torch.float16, True),
+                                            (8192, 2048, 4096, torch.float16, True), (4096, 4096, 4096, torch.bfloat16, False)):
+            m, k, n = m0 // scale, k0 // scale, n0 // scale
+            torch.manual_seed(42)
+            x_full = torch.randn(m, k, dtype=dtype)
+            w = torch.randn(n, k, dtype=dtype)
+            b = torch.randn(n, dtype=dtype) if use_bias else None
+            ml = m // ws
+            x = x_full[rank * ml:(rank + 1) * ml].contiguous()
+            tag = f"{m}x{k}x{n}:{str(dtype)[6:]}"
+            if scale == 1:
+                def closed():
+                    y = (x_full.to(DEV).float() @ w.to(DEV).float().t()).to(dtype)       # F.linear: product rounded, then the bias
+                    return (y if b is None else (y + b.to(DEV))).cpu()
+                want, side = _cached(("ag", tag), closed), "fp32ref"
+            else:
+                want = _cached(("ag", tag), lambda: torch.as_tensor(torch_cls("MojoAllGatherGemm")(
+                    weight=w, bias=b, trans_weight=False, gather_dim=0, process_group=group)(x)).clone())
+                side = "oracle"
+            got = hip_cls("MojoAllGatherGemm")(weight=w.to(DEV), bias=None if b is None else b.to(DEV), trans_weight=False,
+                                               gather_dim=0, process_group=group)(x.to(DEV))
+            torch.cuda.synchronize()
+            _compare(rank, f"{side}:MojoAllGatherGemm:{tag}", got, want, 5e-3)
     # GemmAll2All: :215-247, fp32, the closed form the reference test builds without communication
     torch.manual_seed(42)
     m, k, n = 32, 64, 128
@@ -129,7 +183,14 @@ def check_reference_shapes(rank, ws, group):
 
 
 def main():
+    import faulthandler
+
     rank, ws = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    # The oracle side is CPU work (a 4096 x 2048 x 4096 matmul per case and rank).  torch sizes its thread pool from the
+    # cores it SEES, the box grants a fraction of them: two ranks x all-visible-cores OpenMP teams spinning on a 16-core
+    # share turned seconds into minutes.  A fixed small team per rank keeps the oracle in seconds.
+    torch.set_num_threads(int(os.environ.get("MOJO_TEST_RANK_THREADS", "6")))
+    faulthandler.dump_traceback_later(int(os.environ.get("MOJO_TEST_DUMP_AFTER_S", "120")), exit=False)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     group = dist.group.WORLD

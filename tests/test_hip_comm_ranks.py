@@ -26,12 +26,13 @@ def _free_port():
     return p
 
 
-def run_ranks(modes, ws=2, timeout=900):
+def run_ranks(modes, ws=2, timeout=420):
     port = _free_port()
     procs = []
     for rank in range(ws):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), MOJO_TEST_COMM_MODES=modes, HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), MOJO_TEST_COMM_MODES=modes, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   OMP_NUM_THREADS="6", MKL_NUM_THREADS="6")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "comm_rank_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -42,21 +43,29 @@ def run_ranks(modes, ws=2, timeout=900):
             for q in procs:
                 q.kill()
             outs.append(p.communicate())
-    for rank, (p, (so, se)) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {rank} exited {p.returncode}\n--- stdout\n{so[-3000:]}\n--- stderr\n{se[-6000:]}"
+    if any(p.returncode != 0 for p in procs):
+        report = "\n".join(f"==== rank {rank} exited {p.returncode}\n--- stdout (tail)\n{so[-2500:]}\n--- stderr (tail)\n{se[-3500:]}"
+                           for rank, (p, (so, se)) in enumerate(zip(procs, outs)))
+        raise AssertionError(report)
     return [json.loads(ln) for ln in outs[0][0].splitlines() if ln.startswith("{")]
 
 
-def test_hip_compute_comm_two_ranks_rccl_pipeline_layout():
-    recs = run_ranks("chunks1,chunks4")
-    checks = [r for r in recs if "check" in r]
-    names = {r["check"].split(":")[1] for r in checks}
-    assert {"MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoAllGatherGemm", "MojoGemmAll2All"} <= names, names
-    assert len(checks) == 2 * (5 + 8 + 4 + 1), len(checks)
+def test_hip_compute_comm_two_ranks():
+    """One pair of ranks runs all four exchange modes back to back (the oracle products are computed once and shared):
+    chunks1 / chunks4 = the collective-library pipeline (1 and 4 row chunks), direct1 / direct4 = the HIP-IPC peer exchange."""
+    recs = run_ranks("chunks1,chunks4,direct1,direct4")
     print("\n".join(json.dumps(r) for r in recs))
-
-
-def test_hip_compute_comm_two_ranks_direct_peer_exchange():
-    recs = run_ranks("direct1,direct4")
-    assert any(r.get("check", "").startswith("oracle:MojoGemmAllReduce") for r in recs)
-    print("\n".join(json.dumps(r) for r in recs))
+    per_mode, mode = {}, None
+    for r in recs:
+        if "mode" in r:
+            mode = r["mode"]
+            per_mode[mode] = []
+        elif "check" in r:
+            per_mode[mode].append(r["check"])
+    assert set(per_mode) == {"chunks1", "chunks4", "direct1", "direct4"}
+    for mode, checks in per_mode.items():
+        names = {c.split(":")[1] for c in checks}
+        assert {"MojoGemmAllReduce", "MojoGemmReduceScatter", "MojoAllGatherGemm", "MojoGemmAll2All"} <= names, (mode, names)
+        assert len(checks) == 5 + 2 * (8 + 4) + 1, (mode, len(checks))
+        assert any(c.startswith("oracle:") for c in checks) and any(c.startswith("fp32ref:") for c in checks)
+    assert any("direct_exchange" in r for r in recs)
