@@ -103,10 +103,17 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem_generic[];
   lds_m* smem = (lds_m*)smem_generic;
 
-  // query block the slow coordinate, descending (longest first over the whole launch); (head, sequence) the fast one
+  // Block -> (sequence, head, query block).  The query blocks of one (sequence, head) read the SAME keys (block j the first
+  // offset + 128 (j + 1) of them), and with 128 heads nothing else does: they must meet in one L2.  Consecutive block ids go
+  // to consecutive XCDs (each with its own 4 MiB L2), ids 8 apart share an XCD in dispatch order; so a unit = (sequence, head)
+  // is pinned to XCD (unit % 8) and its query blocks take consecutive slots there, longest first — they are resident together
+  // and the later ones find the tiles of the first in L2.  (Query block as the slow coordinate, as in the GQA kernel, put 64
+  // other units' streams — ~80 MB through a 4 MiB L2 — between two readers of the same keys: every block read HBM.)
   const int inner = a.heads * a.batch;
-  if (static_cast<int>(blockIdx.x) >= a.n_qb * inner) {   // trailing workgroups: rows no sequence owns read as zeros
-    const int64_t z = static_cast<int64_t>(blockIdx.x) - a.n_qb * inner;
+  const int units_per_xcd = (inner + 7) / 8;
+  const int n_attn = 8 * units_per_xcd * a.n_qb;
+  if (static_cast<int>(blockIdx.x) >= n_attn) {          // trailing workgroups: rows no sequence owns read as zeros
+    const int64_t z = static_cast<int64_t>(blockIdx.x) - n_attn;
     const int64_t t0 = max(static_cast<int64_t>(a.cu_q[a.batch]), z * MPF_ZERO_TOKENS);
     const int64_t t1 = min(a.total_tokens, (z + 1) * MPF_ZERO_TOKENS);
     const int64_t row_elems = static_cast<int64_t>(a.heads) * VD;
@@ -118,9 +125,11 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
       *reinterpret_cast<V8*>(static_cast<T*>(a.out) + i) = zv;
     return;
   }
-  const int qb = a.n_qb - 1 - static_cast<int>(blockIdx.x / inner);
-  const int rem = static_cast<int>(blockIdx.x % inner);
-  const int head = rem % a.heads, b = rem / a.heads;
+  const int xcd = static_cast<int>(blockIdx.x) & 7, slot = static_cast<int>(blockIdx.x) >> 3;
+  const int unit = (slot / a.n_qb) * 8 + xcd;
+  if (unit >= inner) return;
+  const int qb = a.n_qb - 1 - slot % a.n_qb;
+  const int head = unit % a.heads, b = unit / a.heads;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_start = a.cu_kv ? a.cu_kv[b] : q_start;
@@ -417,7 +426,7 @@ static int launch_mla_pf(const MlaPfArgs& a, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MPF_LDS);
   const int64_t n_zero = ceil_div(a.total_tokens, static_cast<int64_t>(MPF_ZERO_TOKENS));
-  const int64_t blocks = static_cast<int64_t>(a.n_qb) * a.heads * a.batch + n_zero;
+  const int64_t blocks = static_cast<int64_t>(a.n_qb) * 8 * ceil_div(static_cast<int64_t>(a.heads) * a.batch, 8) + n_zero;
   MOJO_REQUIRE(blocks < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "mla_prefill: grid limit");
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(256), MPF_LDS, s, a);
   MOJO_CHECK_LAUNCH("mla_prefill");

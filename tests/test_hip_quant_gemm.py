@@ -139,33 +139,45 @@ def _sample_rows(m, g):
     return torch.cat([torch.arange(0, 16), torch.arange(m - 16, m), torch.randint(16, m - 16, (96,), generator=g)]).unique()
 
 
+def _exact_rows(x_rows, w_nk, s_in_rows, s_w, odt):
+    """The oracle's formula (`oracle.quant_gemm_formula`: float64 accumulation — exact for int8 — then the golden's fp32
+    scaling and one rounding), with the float64 product evaluated by torch ON THE DEVICE: 128 x K x N in float64 takes the
+    box's 16-core CPU share minutes, and a float64 sum of products below 2^53 is the same number wherever it is added up."""
+    acc = (x_rows.to(DEV).double() @ w_nk.to(DEV).double().t()).cpu()
+    return (acc.float() * s_in_rows.float().reshape(-1, 1).cpu() * s_w.float().reshape(1, -1).cpu()).to(odt)
+
+
 @pytest.mark.parametrize("m,k,n", FULL_SHAPES)
 def test_quant_gemm_int8_full_size_exact(m, k, n):
-    """int8 at the benchmarked shapes.  The exact integer formula is evaluated on the host for a sample of whole rows
-    (first / last 16 and 96 random ones: 128 x K x N in float64) and must match at atol = rtol = 0 in all three output
-    dtypes' worth of rounding (bf16 checked, fp32 with unit scales for the checksum); every other element is covered by a
-    checksum of checksums: with unit scales and fp32 output each element is the exact integer sum, so the column sums of
-    the whole [M, N] result must equal (sum_m x[m, :]) @ W exactly."""
+    """int8 at the benchmarked shapes.  The exact integer formula on a sample of whole rows (first / last 16 and 96 random
+    ones) must match at atol = rtol = 0; every other element is covered by a checksum of checksums: with unit scales and
+    fp32 output each element is the exact integer sum, so the column sums of the whole [M, N] result must equal
+    (sum_m x[m, :]) @ W exactly."""
     g = torch.Generator().manual_seed(k + n)
-    xq, xs = _quantize(torch.randn(m, k, generator=g))
-    wq, ws = _quantize(torch.randn(n, k, generator=g))
-    rows = _sample_rows(m, g)
+    gd = torch.Generator(device=DEV).manual_seed(k + n)
+    xq, xs = _quantize(torch.randn(m, k, generator=gd, device=DEV))
+    wq, ws = _quantize(torch.randn(n, k, generator=gd, device=DEV))
+    rows = _sample_rows(m, g).to(DEV)
     op = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.bfloat16, trans_weight=True, device=DEV)
     op.weight.copy_(wq)
     op.weight_scale.copy_(ws.to(torch.bfloat16))
-    out = op(xq.to(DEV), xs.to(DEV))
-    expect = quant_gemm_formula(xq[rows], wq.t(), xs[rows], ws.to(torch.bfloat16), torch.bfloat16)
-    torch.testing.assert_close(to_cpu(out[rows.to(DEV)]), expect, atol=0, rtol=0)
+    out = op(xq, xs)
+    expect = _exact_rows(xq[rows], wq, xs[rows], ws.to(torch.bfloat16), torch.bfloat16)
+    # the helper must be the oracle's formula: cross-check on a few rows against the CPU implementation itself
+    few = rows[:4]
+    assert torch.equal(_exact_rows(xq[few], wq, xs[few], ws.to(torch.bfloat16), torch.bfloat16),
+                       quant_gemm_formula(xq[few].cpu(), wq.cpu().t(), xs[few].cpu(), ws.to(torch.bfloat16).cpu(), torch.bfloat16))
+    torch.testing.assert_close(to_cpu(out[rows]), expect, atol=0, rtol=0)
     del out
     op32 = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.float32, trans_weight=True, device=DEV)
     op32.weight.copy_(wq)
     op32.weight_scale.fill_(1.0)
-    raw = op32(xq.to(DEV), torch.ones(m, device=DEV))
+    raw = op32(xq, torch.ones(m, device=DEV))
     assert float(raw.abs().max()) < 2 ** 24                     # every element is an exactly represented integer
-    col = raw.double().sum(0).cpu()
+    col = raw.double().sum(0)
     want = xq.double().sum(0) @ wq.double().t()
     assert torch.equal(col, want)
-    torch.testing.assert_close(to_cpu(raw[rows.to(DEV)]), (xq[rows].double() @ wq.double().t()).float(), atol=0, rtol=0)
+    assert torch.equal(raw[rows], (xq[rows].double() @ wq.double().t()).float())
 
 
 @pytest.mark.parametrize("m,k,n", FULL_SHAPES)
@@ -174,23 +186,25 @@ def test_quant_gemm_fp8_full_size(m, k, n):
     against the float64 formula, and the column-sum identity to fp32-accumulation tolerance."""
     f8 = torch.float8_e4m3fn
     g = torch.Generator().manual_seed(k + n + 1)
-    x = torch.randn(m, k, generator=g).to(f8)
-    w = torch.randn(n, k, generator=g).to(f8)
-    s_in, s_w = torch.rand(m, generator=g) + 0.5, (torch.rand(n, generator=g) + 0.5).to(torch.bfloat16)
-    rows = _sample_rows(m, g)
+    gd = torch.Generator(device=DEV).manual_seed(k + n + 1)
+    x = torch.randn(m, k, generator=gd, device=DEV).to(f8)
+    w = torch.randn(n, k, generator=gd, device=DEV).to(f8)
+    s_in = torch.rand(m, generator=gd, device=DEV) + 0.5
+    s_w = (torch.rand(n, generator=gd, device=DEV) + 0.5).to(torch.bfloat16)
+    rows = _sample_rows(m, g).to(DEV)
     op = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.bfloat16, trans_weight=True,
                                   quant_dtype=f8, weight_dtype=f8, device=DEV)
     op.weight.copy_(w)
     op.weight_scale.copy_(s_w)
-    out = op(x.to(DEV), s_in.to(DEV))
-    exact = quant_gemm_formula(x[rows], w.t(), s_in[rows], s_w, torch.bfloat16)
-    torch.testing.assert_close(to_cpu(out[rows.to(DEV)]).float(), exact.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -7)
+    out = op(x, s_in)
+    exact = _exact_rows(x[rows], w, s_in[rows], s_w, torch.bfloat16)
+    torch.testing.assert_close(to_cpu(out[rows]).float(), exact.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -7)
     op32 = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=torch.float32, trans_weight=True,
                                     quant_dtype=f8, weight_dtype=f8, device=DEV)
     op32.weight.copy_(w)
     op32.weight_scale.fill_(1.0)
-    raw = op32(x.to(DEV), torch.ones(m, device=DEV))
-    col = raw.double().sum(0).cpu()
+    raw = op32(x, torch.ones(m, device=DEV))
+    col = raw.double().sum(0)
     want = x.double().sum(0) @ w.double().t()
     torch.testing.assert_close(col, want, atol=1e-3 * (m * k) ** 0.5, rtol=1e-5)
 
