@@ -64,6 +64,50 @@ def _group_info(group):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+class _Done:
+    """Work handle of a collective that already completed (the host-staged gloo route below)."""
+
+    def wait(self):
+        return True
+
+
+def _host_staged(group, t: torch.Tensor) -> bool:
+    """gloo moves device tensors through the host anyway, and its asynchronous device-tensor collectives proved unreliable
+    when several are in flight (an `all_gather_into_tensor` of a 33 MB device tensor hung both ranks of the two-rank GPU
+    test once in three runs).  On a gloo group the exchange therefore runs on explicit host copies, synchronously.  Only
+    the single-GPU multi-rank TESTS use gloo with device tensors; on a node the group is RCCL and this is never taken."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, group):
+    if _host_staged(group, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def _reduce_scatter_tensor(out, buf, group):
+    if _host_staged(group, buf):
+        ws, rank = _group_info(group)
+        h = buf.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)          # gloo has no reduce_scatter for every dtype
+        rows = h.shape[0] // ws
+        out.copy_(h[rank * rows:(rank + 1) * rows])
+        return _Done()
+    return dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def _all_gather_into_tensor(buf, x, group):
+    if _host_staged(group, x):
+        h = torch.empty(buf.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(h, x.cpu().contiguous(), group=group)
+        buf.copy_(h)
+        return _Done()
+    return dist.all_gather_into_tensor(buf, x.contiguous(), group=group, async_op=True)
+
+
 def _flatten(x: torch.Tensor) -> torch.Tensor:
     x2 = x.reshape(-1, x.shape[-1])
     return x2 if x2.stride(-1) == 1 else x2.contiguous()
@@ -82,7 +126,7 @@ def gemm_all_reduce(engine: GemmEngine, x, weight, bias, trans_weight, group) ->
     works = []
     for lo, hi in plan_row_chunks(m):
         engine(x2[lo:hi], weight, bias, trans_weight, out=out[lo:hi])
-        works.append(dist.all_reduce(out[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        works.append(_all_reduce(out[lo:hi], group))
     for w in works:
         w.wait()
     return out.reshape(*x.shape[:-1], n)
@@ -114,7 +158,7 @@ def gemm_reduce_scatter(engine: GemmEngine, x, weight, bias, trans_weight, group
         rc = hi - lo
         buf = torch.empty(ws * rc, n, dtype=x.dtype, device=x.device)   # [dest rank][rc rows]
         engine(x2, weight, bias, trans_weight, out=buf, rows=ws * rc, a_map=(rc, ml, lo))
-        works.append(dist.reduce_scatter_tensor(out[lo:hi], buf, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        works.append(_reduce_scatter_tensor(out[lo:hi], buf, group))
         keep.append(buf)
     for w in works:
         w.wait()
@@ -141,7 +185,7 @@ def all_gather_gemm(engine: GemmEngine, x, weight, bias, trans_weight, group, ga
     stages = []
     for lo, hi in chunks:                          # enqueue every gather first: they run back to back on the comm stream
         buf = torch.empty(ws * (hi - lo), k, dtype=x.dtype, device=x.device)
-        stages.append((buf, dist.all_gather_into_tensor(buf, x2[lo:hi].contiguous(), group=group, async_op=True)))
+        stages.append((buf, _all_gather_into_tensor(buf, x2[lo:hi], group)))
     for (lo, hi), (buf, work) in zip(chunks, stages):
         work.wait()                                # the GEMM of chunk c overlaps the gathers of chunks c+1..
         engine(buf, weight, bias, trans_weight, out=out, rows=buf.shape[0], c_map=(hi - lo, ml, lo))
