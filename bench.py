@@ -95,6 +95,14 @@ def decode_algorithmic_bytes(lens, max_blocks):
     return kv + qo + idx
 
 
+def _profiled(name, key):
+    """A value from a committed rocprofv3 summary under profiles/ (None when absent)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get(key)
+    except Exception:
+        return None
+
+
 def usable_cores():
     """Cores this process may actually use: the affinity mask, cut by the cgroup CPU quota when one is set.  torch sizes
     its pool from the cores it SEES; on a box that grants 16 of 128 an all-cores OpenMP team spins on itself."""
@@ -217,11 +225,16 @@ def main():
     alg_bytes = decode_algorithmic_bytes(lens_cpu, sets[0][4].shape[1])
     kernel_s = dev_ms / 1e3 / ns.steps
     achieved = alg_bytes / kernel_s / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 owns the counters and
+    # must wrap the program): they come from the committed summary of scripts/profile_r2.sh + scripts/summarize_r2.py
+    # (separate --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command line; date and box are in the file)
+    traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "decode_gqa_traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tp))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/decode_gqa_traffic.json ({tj.get('collected', 'round 1')})"
         except Exception:
             traffic = None
 
@@ -242,7 +255,7 @@ def main():
                                "AABB, random block tables (BASELINE configs[1])",
                    "per_gpu_batch": B, "parallelism": f"replicas x{world} (no collective on this path)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
                      "kernel": ("mojo::decode_split_kernel<bf16,4,nt,fused> (one launch per op call: the chunk partials are merged in LDS)"
                                 if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" else
@@ -276,7 +289,8 @@ def main():
                 "bound": "mfma", "achieved": head["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": head["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
                 "flops_per_launch": 2.0 * 16384 * 4096 * 28672, "device_us_per_launch": head["us"],
-                "sustained_clock_mhz": head.get("sustained_clock_mhz"),
+                "sustained_clock_mhz": _profiled("r2_group_gemm_counters.json", "sustained_clock_mhz"),
+                "mfma_busy_frac_profiled": _profiled("r2_group_gemm_counters.json", "mfma_busy_frac"),
                 "workload": "MojoGroupGemm bf16, Mixtral up-projection: 16384 rows over 8 experts (balanced), K=4096, N=28672, "
                             "weights [G,K,N], random data (BASELINE configs[2])",
                 "kernel": "mojo::g256::gemm256_kernel<bf16>"}

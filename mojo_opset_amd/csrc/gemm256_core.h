@@ -699,8 +699,13 @@ inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hi
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
   if constexpr (Epi::kRowStaged) {
     // persistent form (one workgroup per CU, next tile requested before this tile's epilogue): row-staged 16-bit output,
-    // no bias / GLU / split-K, and enough tiles that every CU gets at least two.  MOJO_HIP_GEMM_PERSIST=0 disables.
-    static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_PERSIST"); return e && e[0] == '0'; }();
+    // no bias / GLU / split-K, and enough tiles that every CU gets at least two.  OPT-IN (MOJO_HIP_GEMM_PERSIST=1): A/B on
+    // one MI355X in one session (round 2, random bf16, TFLOP/s plain -> persistent): Mixtral up [K,N] 1279 -> 1278-1285,
+    // [N,K] 1313-1318 -> 1315-1328, down 1226-1234 -> 1219-1222, skewed 1199-1200 -> 1196-1203, M = 4096 1010-1016 ->
+    // 1001-1008, reference case 1050-1068 -> 1070-1094, K = 512 (MLA decompression) 741-755 -> 748-804: inside the run-to-run
+    // spread except at short K.  The hardware's own workgroup hand-over already hides most of what the loop was meant to
+    // hide, and hipcc builds the loop body with 19-20 SGPR spills; results are identical (all GEMM tests pass with it on).
+    static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_PERSIST"); return !(e && e[0] == '1'); }();
     const int cus = device_cu_count();
     if (allow_persistent && !off && a.stage_rows && !a.glu && a.splitk == 1 && !epi.has_bias() && !a.ablate && blocks >= 2 * cus) {
       constexpr int LDS_P = LDS_BYTES + PERSIST_STAGE_BYTES;
