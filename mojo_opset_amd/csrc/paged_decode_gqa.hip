@@ -56,7 +56,7 @@ struct DecodeArgs {
   void* out;
   float* ws_acc;     // [B*Hkv][chunks][G][D] fp32, un-normalised
   float* ws_ml;      // [B*Hkv][chunks][G][2]  (running max in log2 units, running sum)
-  int hq, hkv, dim, page, page_shift, max_pages;
+  int hq, hkv, dim, page, page_shift, max_pages, batch;
   int64_t table_stride, c_blk, c_head, c_tok;
   int chunk_tokens, n_chunks;     // launch-wide bound: no sequence is cut into more than n_chunks pieces of <= chunk_tokens
   float scale_log2;
@@ -79,22 +79,73 @@ __device__ __forceinline__ int decode_seq_chunk(const DecodeArgs& a, int seq_len
   return min(c, a.chunk_tokens);
 }
 
-// FUSED: one workgroup = all chunks of one (sequence, kv-head), one wave per chunk (n_chunks <= 8); the partial states
-// meet in LDS and the workgroup writes the final output itself — no partials in HBM, no merge launch.
-template <typename T, int G, bool NT, bool FUSED>
-__global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeArgs a) {
+// MODE 1 (fused): one workgroup = all chunks of one (sequence, kv-head), one wave per chunk (n_chunks <= 8); the partial
+// states meet in LDS and the workgroup writes the final output itself — no partials in HBM, no merge launch.
+// MODE 2 (fused, paired): an 8-wave workgroup owns TWO sequences of one kv-head — the one of rank p and the one of rank
+// B-1-p when the batch is ordered by length — and deals its waves between them in proportion to their lengths.  Every wave
+// of the launch is resident at once, so a launch lasts as long as its busiest wave: with four waves per sequence that is
+// max_len / 4 tokens; a long row paired with a short one leaves every wave ~(len_long + len_short) / 8, the batch mean / 4.
+// A uniform batch gets 4 + 4 waves per pair, i.e. exactly the MODE 1 work per wave.
+constexpr int DEC_SPLIT = 0, DEC_FUSED = 1, DEC_PAIRED = 2;
+
+template <typename T, int G, bool NT, int MODE>
+__global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_kernel(DecodeArgs a) {
+  constexpr bool FUSED = MODE != DEC_SPLIT;
+  constexpr bool PAIRED = MODE == DEC_PAIRED;
   typedef typename pack8<T>::vec V8;
   typedef typename pack8<T>::pair V2;
   const int lane = threadIdx.x & 63;
   const int r = lane / DEC_LPT;
   const int j = lane % DEC_LPT;
   // (readfirstlane: the wave index must be a scalar, or every page-table lookup below turns into a vector load)
-  const int chunk = FUSED ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) : static_cast<int>(blockIdx.x);
-  const int b = blockIdx.y / a.hkv;
+  const int wave_id = FUSED ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) : 0;
+  int chunk = FUSED ? wave_id : static_cast<int>(blockIdx.x);
+  int b = blockIdx.y / a.hkv;
   const int kvh = blockIdx.y % a.hkv;
 
-  const int seq_len = a.max_pages > 0 ? decode_seq_len(a, b) : 0;      // (no table columns: nothing to attend over)
-  const int chunk_tokens = decode_seq_chunk(a, seq_len);
+  int seq_len, chunk_tokens;
+  // paired mode: the two sequences of this workgroup, their (clamped) lengths and the waves dealt to the first
+  int pb[2] = {0, -1}, plen[2] = {0, 0}, pchunk[2] = {DEC_TILE, DEC_TILE}, n_first = 8;
+  if constexpr (PAIRED) {
+    const int cap = a.n_chunks * a.chunk_tokens;
+    int len = -1;                                      // lanes past the batch rank behind every sequence
+    if (lane < a.batch) len = a.max_pages > 0 ? max(min(a.seq_lens[lane], cap), 0) : 0;
+    int rank = lane;                                   // position of sequence `lane` when ordered by length, longest first
+    if (__ballot(lane < a.batch && len != __builtin_amdgcn_readfirstlane(len)) != 0) {   // (a uniform batch keeps its order)
+      rank = 0;
+      for (int o = 0; o < a.batch; ++o) {
+        const int lo = __builtin_amdgcn_readlane(len, o);
+        rank += (lo > len || (lo == len && o < lane)) ? 1 : 0;
+      }
+    }
+    const int p = b;                                   // blockIdx.y / hkv is the pair index here
+    const unsigned long long first = __ballot(lane < a.batch && rank == p);
+    const unsigned long long second = __ballot(lane < a.batch && rank == a.batch - 1 - p && a.batch - 1 - p > p);
+    pb[0] = __builtin_ctzll(first);
+    plen[0] = __builtin_amdgcn_readlane(len, pb[0]);
+    if (second) {
+      pb[1] = __builtin_ctzll(second);
+      plen[1] = __builtin_amdgcn_readlane(len, pb[1]);
+    }
+    const int sum = plen[0] + plen[1];
+    n_first = plen[1] <= 0 ? 8 : min(max((8 * plen[0] + sum / 2) / sum, 1), 7);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n_u = u ? 8 - n_first : n_first;
+      int c = n_u > 0 ? (plen[u] + n_u - 1) / n_u : DEC_TILE;
+      c = max(c, 128);
+      pchunk[u] = ((c + DEC_TILE - 1) / DEC_TILE) * DEC_TILE;
+    }
+    const int u = wave_id < n_first ? 0 : 1;
+    b = pb[u];
+    chunk = u ? wave_id - n_first : wave_id;
+    seq_len = b >= 0 ? plen[u] : 0;
+    chunk_tokens = pchunk[u];
+    if (b < 0) b = pb[0];                              // a wave without a sequence: valid addresses, no work
+  } else {
+    seq_len = a.max_pages > 0 ? decode_seq_len(a, b) : 0;      // (no table columns: nothing to attend over)
+    chunk_tokens = decode_seq_chunk(a, seq_len);
+  }
   const int tok_begin = chunk * chunk_tokens;
   const bool has_work = seq_len > 0 && tok_begin < seq_len;
   if (!FUSED && !has_work) return;
@@ -285,27 +336,39 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
     if (r == 0 && dim_ok) {
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        float* dst = s_part + (chunk * G + g) * stride;
+        float* dst = s_part + (wave_id * G + g) * stride;     // (wave_id == chunk in the unpaired form)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dst[j * 8 + e] = acc[g][e];
         if (j == 0) { dst[a.dim] = m[g]; dst[a.dim + 1] = l[g]; }
       }
     }
     __syncthreads();
-    // every thread of the workgroup takes (head g, 4 output elements) items
-    const int n_chunks_seq = seq_len <= 0 ? 0 : min((seq_len + chunk_tokens - 1) / chunk_tokens, static_cast<int>(blockDim.x >> 6));
-    if (n_chunks_seq == 0 && a.leave_empty) return;      // (uniform over the workgroup, after its only barrier)
+    // every thread of the workgroup takes (sequence of the pair, head g, 4 output elements) items
     const int per_head = a.dim / 4;
     typedef typename vec_of<T, 4>::type V4;
-    for (int item = threadIdx.x; item < G * per_head; item += blockDim.x) {
-      const int g = item / per_head, d0 = (item - g * per_head) * 4;
+    constexpr int UNITS = PAIRED ? 2 : 1;
+    for (int item = threadIdx.x; item < UNITS * G * per_head; item += blockDim.x) {
+      const int u = item / (G * per_head);
+      const int rest = item - u * (G * per_head);
+      const int g = rest / per_head, d0 = (rest - g * per_head) * 4;
+      int ub, ulen, uchunk, slot0, uwaves;
+      if constexpr (PAIRED) {
+        ub = pb[u]; ulen = plen[u]; uchunk = pchunk[u];
+        slot0 = u ? n_first : 0;
+        uwaves = u ? 8 - n_first : n_first;
+        if (ub < 0) continue;                            // odd batch: the middle sequence has no partner
+      } else {
+        ub = b; ulen = seq_len; uchunk = chunk_tokens; slot0 = 0; uwaves = static_cast<int>(blockDim.x >> 6);
+      }
+      const int n_chunks_seq = ulen <= 0 ? 0 : min((ulen + uchunk - 1) / uchunk, uwaves);
+      if (n_chunks_seq == 0 && a.leave_empty) continue;
       const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
       float mx = -INFINITY;
-      for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, s_part[(c * G + g) * stride + a.dim]);
+      for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, s_part[((slot0 + c) * G + g) * stride + a.dim]);
       f32x4 num = {0.f, 0.f, 0.f, 0.f};
       float den = 0.f;
       for (int c = 0; c < n_chunks_seq; ++c) {
-        const float* src = s_part + (c * G + g) * stride;
+        const float* src = s_part + ((slot0 + c) * G + g) * stride;
         const float w = exp2f(src[a.dim] - mx);
         den = fmaf(w, src[a.dim + 1], den);
         num += f32x4{src[d0], src[d0 + 1], src[d0 + 2], src[d0 + 3]} * w;
@@ -314,7 +377,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 64) void decode_split_kernel(DecodeAr
       V4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(num[e] * inv);
-      *reinterpret_cast<V4*>(static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + d0) = o;
+      *reinterpret_cast<V4*>(static_cast<T*>(a.out) + (static_cast<int64_t>(ub) * a.hq + h) * a.dim + d0) = o;
     }
     return;
   }
@@ -413,15 +476,30 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
 template <typename T, bool NT>
 static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
   static const bool no_fuse = [] { const char* e = getenv("MOJO_HIP_DECODE_FUSE"); return e && e[0] == '0'; }();
+  static const bool no_pair = [] { const char* e = getenv("MOJO_HIP_DECODE_PAIR"); return e && e[0] == '0'; }();
+  if (a.n_chunks == 4 && batch >= 2 && batch <= 64 && a.dim % 4 == 0 && !no_fuse && !no_pair) {
+    // four waves per sequence fill the chip once: pair the sequences by length rank and deal each pair's 8 waves by length
+    dim3 grid(1, static_cast<unsigned>(((batch + 1) / 2) * a.hkv));
+    const size_t lds = static_cast<size_t>(8) * G * (a.dim + 2) * sizeof(float);
+    switch (G) {
+      case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, DEC_PAIRED>), grid, dim3(512), lds, s, a); break;
+      case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, DEC_PAIRED>), grid, dim3(512), lds, s, a); break;
+      case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, DEC_PAIRED>), grid, dim3(512), lds, s, a); break;
+      case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, DEC_PAIRED>), grid, dim3(512), lds, s, a); break;
+      default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
+    }
+    MOJO_CHECK_LAUNCH("paged_decode_gqa(paired)");
+    return MOJO_OK;
+  }
   if (a.n_chunks <= 8 && a.dim % 4 == 0 && !no_fuse) {   // all chunks of a (sequence, kv-head) in one workgroup: merged in LDS
     dim3 grid(1, static_cast<unsigned>(batch * a.hkv));
     const dim3 block(static_cast<unsigned>(64 * a.n_chunks));
     const size_t lds = static_cast<size_t>(a.n_chunks) * G * (a.dim + 2) * sizeof(float);
     switch (G) {
-      case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, true>), grid, block, lds, s, a); break;
-      case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, true>), grid, block, lds, s, a); break;
-      case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, true>), grid, block, lds, s, a); break;
-      case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, true>), grid, block, lds, s, a); break;
+      case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, DEC_FUSED>), grid, block, lds, s, a); break;
+      case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, DEC_FUSED>), grid, block, lds, s, a); break;
+      case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, DEC_FUSED>), grid, block, lds, s, a); break;
+      case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, DEC_FUSED>), grid, block, lds, s, a); break;
       default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
     }
     MOJO_CHECK_LAUNCH("paged_decode_gqa(fused)");
@@ -429,10 +507,10 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
   }
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv));
   switch (G) {
-    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, false>), grid, dim3(64), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, false>), grid, dim3(64), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, false>), grid, dim3(64), 0, s, a); break;
-    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, false>), grid, dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, DEC_SPLIT>), grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, DEC_SPLIT>), grid, dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((decode_split_kernel<T, 4, NT, DEC_SPLIT>), grid, dim3(64), 0, s, a); break;
+    case 8: hipLaunchKernelGGL((decode_split_kernel<T, 8, NT, DEC_SPLIT>), grid, dim3(64), 0, s, a); break;
     default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
   }
   MOJO_CHECK_LAUNCH("paged_decode_gqa(split)");
@@ -493,7 +571,7 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
   DecodeArgs a;
   a.q = query; a.kc = key_cache; a.vc = value_cache; a.seq_lens = total_seq_lens; a.tables = block_tables; a.out = out;
   a.hq = static_cast<int>(q_heads); a.hkv = static_cast<int>(kv_heads); a.dim = static_cast<int>(head_dim);
-  a.page = static_cast<int>(block_size); a.max_pages = static_cast<int>(max_blocks_per_seq);
+  a.page = static_cast<int>(block_size); a.max_pages = static_cast<int>(max_blocks_per_seq); a.batch = static_cast<int>(batch);
   a.page_shift = (block_size & (block_size - 1)) == 0 ? __builtin_ctzll(block_size) : -1;
   a.table_stride = block_table_stride; a.c_blk = cache_block_stride; a.c_head = cache_head_stride;
   a.c_tok = cache_token_stride;

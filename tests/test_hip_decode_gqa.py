@@ -216,3 +216,29 @@ def test_decode_padded_rows_under_graph_replay(layout):
         torch.testing.assert_close(eager[:cur_b].float(), out[:cur_b].float(), atol=0, rtol=0)
         forced = op(sq, sk, sv, sl, st, max_total_seq_len=max_len, leave_empty_rows=False)
         assert torch.count_nonzero(forced[cur_b:]) == 0
+
+
+@pytest.mark.parametrize("batch", [64, 63, 53])
+@pytest.mark.parametrize("layout", ["AABB", "ABAB"])
+def test_decode_paired_workgroups_on_ragged_batches(batch, layout, monkeypatch):
+    """Llama-3-8B head shape with 52..64 sequences: four waves per (sequence, kv-head) fill the chip once, and the kernel
+    then pairs the sequences by length rank (longest with shortest, ...) in 8-wave workgroups that deal their waves by
+    length.  Ragged lengths incl. empty rows, an odd batch (the middle sequence has no partner), ties; against the oracle,
+    and against the unpaired kernel (MOJO_HIP_DECODE_PAIR=0) on the same inputs."""
+    g = torch.Generator().manual_seed(batch)
+    lens = torch.randint(1, 700, (batch,), generator=g).tolist()
+    lens[3], lens[10], lens[11], lens[12] = 0, 699, 699, 1           # an empty row, a tie, a one-token row
+    q, k, v, lens_t, table = make_decode_inputs(batch, 32, 8, 128, 0, 16, lens=lens, seed=batch + 1)
+    dev = [t.to(DEV) for t in (q, k, v, lens_t, table)]
+    op = hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    ref = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    want = ref(q, k, v, lens_t, table)
+    got = op(*dev, max_total_seq_len=700)
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    assert torch.count_nonzero(got[3]) == 0
+    monkeypatch.setenv("MOJO_HIP_DECODE_PAIR", "0")
+    plain = op(*dev, max_total_seq_len=700)
+    torch.testing.assert_close(got.float(), plain.float(), atol=4e-3, rtol=4e-3)     # different chunk boundaries, same sums
+    monkeypatch.delenv("MOJO_HIP_DECODE_PAIR")
+    # launch-to-launch determinism
+    assert torch.equal(op(*dev, max_total_seq_len=700), got)
