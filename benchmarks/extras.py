@@ -419,15 +419,30 @@ def bench_compute_comm(device, world, rank):
         for m in (1024, 4096, 8192):
             xs = torch.randn(m // world, k2, device=device, dtype=dt)
             op = hip("MojoAllGatherGemm")(w2, None, True, gather_dim=0)
-            t = timed(lambda: op(xs))
-            rec = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k2 * n_total / t / 1e12}
+            t_local = None
             if world > 1:
                 xfull = torch.randn(m, k2, device=device, dtype=dt)
                 t_local = timed(lambda: _ENGINE(xfull, w2, None, True))
-                rec.update({"local_gemm_us": t_local * 1e6, "exposed_exchange_us": max(t - t_local, 0.0) * 1e6,
-                            "gathered_MB_per_rank": (world - 1) * (m // world) * k2 * 2 / 1e6})
                 del xfull
-            out[f"allgather_gemm_M{m}_K{k2}_N{n_total}_tp{world}"] = rec
+            for variant in (("rccl", "direct") if world > 1 else ("rccl",)):
+                key = f"allgather_gemm_M{m}_K{k2}_N{n_total}_tp{world}" + ("" if world == 1 else f"_{variant}")
+                try:
+                    t = with_direct("1" if variant == "direct" else "0", lambda: timed(lambda: op(xs)))
+                    if variant == "direct":
+                        from mojo_opset_amd.comm import peer
+                        for ex in peer._CACHE.values():
+                            ex.check()
+                except Exception as e:
+                    out[key] = {"error": repr(e)}
+                    continue
+                rec = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k2 * n_total / t / 1e12}
+                if world > 1:
+                    gathered = (world - 1) * (m // world) * k2 * 2
+                    per_link = gathered if variant == "rccl" else gathered / (world - 1)     # ring: all of it over one link
+                    rec.update({"local_gemm_us": t_local * 1e6, "exposed_exchange_us": max(t - t_local, 0.0) * 1e6,
+                                "gathered_MB_per_rank": gathered / 1e6, "link_MB": per_link / 1e6,
+                                "link_GBps_over_exposed_time": per_link / max(t - t_local, 1e-6) / 1e9, "link_peak_GBps": link_peak})
+                out[key] = rec
             del xs
         del w2
         torch.cuda.empty_cache()

@@ -368,6 +368,12 @@ int mojo_hip_peer_reduce(void* const* peer_data, void* const* peer_flags, int64_
 int mojo_hip_peer_gather(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
                          int64_t chunk, uint32_t epoch, int64_t chunk_offset_bytes, int64_t rows, int64_t n,
                          void* dst, int64_t ld_dst, int dtype, mojo_stream_t stream);
+/*      pull (the all-gather of MojoAllGatherGemm, compute_with_comm.py:119-184): slot p of dst (dst + p * dst_stride_bytes)
+ *      <- `bytes` at src_offset_bytes of rank p's data area, for every rank (include_self) or every other rank, each after
+ *      rank p's flag (kind, flag_chunk) reached `epoch` (the own block needs no wait).                                   */
+int mojo_hip_peer_pull(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank, int kind,
+                       int64_t flag_chunk, uint32_t epoch, int64_t src_offset_bytes, int64_t bytes, void* dst,
+                       int64_t dst_stride_bytes, int include_self, mojo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mojo_hip_peer_signal": (c_int, [_P, _P, _I, _I, c_int, _I, ctypes.c_uint32, _P]),
     "mojo_hip_peer_reduce": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint32, _I, _I, _I, _P, _I, c_int, c_int, _P]),
     "mojo_hip_peer_gather": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint32, _I, _I, _I, _P, _I, c_int, _P]),
+    "mojo_hip_peer_pull": (c_int, [_P, _P, _I, _I, c_int, _I, ctypes.c_uint32, _I, _I, _P, _I, c_int, _P]),
     "mojo_hip_quant_gemm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "mojo_hip_quant_gemm": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, c_int, c_int, c_int, _P, _I, _P]),
 }

@@ -70,7 +70,19 @@ class HIPAllGatherGemm(MojoAllGatherGemm):
     supported_platforms_list = _ROCM
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
-        return all_gather_gemm(_ENGINE, input, self.weight, self.bias, self.trans_weight, _group_of(self), self.gather_dim)
+        group = _group_of(self)
+        if peer.direct_enabled(group, input) and self.gather_dim % input.dim() == 0 and input.dim() >= 2:
+            import torch.distributed as dist
+
+            x2 = input.reshape(-1, input.shape[-1])
+            x2 = x2 if x2.stride(-1) == 1 and x2.stride(0) == x2.shape[1] else x2.contiguous()
+            n = _ENGINE.out_features(self.weight, self.trans_weight)
+            if x2.shape[0] > 0 and (x2.shape[1] * x2.element_size()) % 16 == 0 and x2.dtype in (torch.bfloat16, torch.float16, torch.float32):
+                out = peer.all_gather_gemm_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
+                shape = list(input.shape[:-1]) + [n]
+                shape[0] *= dist.get_world_size(group)
+                return out.reshape(shape)
+        return all_gather_gemm(_ENGINE, input, self.weight, self.bias, self.trans_weight, group, self.gather_dim)
 
 
 class HIPGemmAll2All(MojoGemmAll2All):

@@ -111,6 +111,10 @@ class PeerExchange:
         L.check(L.load().mojo_hip_peer_gather(self._data, self._flags, self.ws, self.rank, chunk, epoch, chunk_off, rows, n,
                                               L.ptr(dst), dst.stride(0), L.dtype_code(dst.dtype), stream), "peer gather")
 
+    def pull(self, kind, flag_chunk, epoch, src_off, nbytes, dst: torch.Tensor, dst_stride_bytes, include_self, stream) -> None:
+        L.check(L.load().mojo_hip_peer_pull(self._data, self._flags, self.ws, self.rank, kind, flag_chunk, epoch, src_off,
+                                            nbytes, L.ptr(dst), dst_stride_bytes, 1 if include_self else 0, stream), "peer pull")
+
     def check(self, clear: bool = True) -> None:
         """Raise if a wait of an earlier call timed out (its outputs were poisoned with NaN).  Synchronises."""
         err = ctypes.c_int32(0)
@@ -235,4 +239,37 @@ def gemm_reduce_scatter_direct(engine, x2: torch.Tensor, weight, bias, trans_wei
         ex.side.wait_stream(main)
         ex.reduce(c, epoch, off + rank * rc * n * es, rc, n, out[lo:hi], False, _side_ptr(ex))
     main.wait_stream(ex.side)
+    return out
+
+
+def all_gather_gemm_direct(engine, x2: torch.Tensor, weight, bias, trans_weight: bool, group) -> torch.Tensor:
+    """allgather(x2, rows) @ W (+ bias) with the gather pulled straight from the peers' buffers: this rank's shard is copied
+    into its peer buffer and flagged once; per row chunk c a side-stream launch pulls rows [lo, hi) of EVERY rank's shard
+    (ws - 1 links in parallel) into a contiguous [ws * rc, K] block, and the GEMM on that block writes its rows to their final
+    place through the C-row map — the pull of chunk c + 1 overlaps the GEMM of chunk c."""
+    from .pipelines import plan_row_chunks
+
+    n = engine.out_features(weight, trans_weight)
+    ml, k = x2.shape
+    es = x2.element_size()
+    ex = get_exchange(group, ml * k * es)
+    ws = ex.ws
+    epoch, base = ex.begin_call()
+    main = torch.cuda.current_stream(x2.device)
+    ex.local_view(base, ml, k, x2.dtype).copy_(x2)
+    ex.signal(0, 0, epoch, L.stream_of(x2))
+    out = torch.empty(ws * ml, n, dtype=x2.dtype, device=x2.device)
+    chunks = plan_row_chunks(ml)
+    ex.side.wait_stream(main)
+    stages = []
+    for lo, hi in chunks:
+        rc = hi - lo
+        buf = torch.empty(ws * rc, k, dtype=x2.dtype, device=x2.device)
+        ex.pull(0, 0, epoch, base + lo * k * es, rc * k * es, buf, rc * k * es, True, _side_ptr(ex))
+        ev = torch.cuda.Event()
+        ev.record(ex.side)
+        stages.append((buf, ev))
+    for (lo, hi), (buf, ev) in zip(chunks, stages):
+        main.wait_event(ev)
+        engine(buf, weight, bias, trans_weight, out=out, rows=buf.shape[0], c_map=(hi - lo, ml, lo))
     return out

@@ -172,6 +172,30 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerPtrs pp, int ws, i
   }
 }
 
+// ---- pull: copy one contiguous block from every rank's data area into consecutive slots of a local buffer -------------
+// (the all-gather of MojoAllGatherGemm: slot p of dst <- `bytes` at src_off of rank p's data area, after rank p's flag
+// (kind, flag_chunk) reached `epoch`; blockIdx.y walks the ranks starting at the own one, which needs no wait)
+__global__ __launch_bounds__(256) void peer_pull_kernel(PeerPtrs pp, int ws, int rank, int kind, int flag_chunk, uint32_t epoch,
+                                                        long long src_off, long long bytes, char* dst, long long dst_stride,
+                                                        int first, long long timeout_ticks) {
+  __shared__ int s_ok;
+  const int p = (rank + first + blockIdx.y) % ws;
+  uint32_t* my_flags = pp.flags[rank];
+  if (threadIdx.x == 0)
+    s_ok = (p == rank || wait_flag(flag_word(my_flags, kind, p, flag_chunk), epoch, my_flags + PEER_ERR_WORD, timeout_ticks)) ? 1 : 0;
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const bool ok = s_ok != 0;
+  const char* src = pp.data[p] + src_off;
+  char* out = dst + p * dst_stride;
+  const long long vecs = bytes / 16;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < vecs; i += static_cast<long long>(gridDim.x) * 256) {
+    u32x4 v = {0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};       // bf16 / fp16 / fp32 NaN patterns on a failed wait
+    if (ok) v = *reinterpret_cast<const u32x4*>(src + i * 16);
+    *reinterpret_cast<u32x4*>(out + i * 16) = v;
+  }
+}
+
 static int fill_ptrs(PeerPtrs& pp, void* const* data, void* const* flags, int ws) {
   for (int i = 0; i < PEER_MAX; ++i) {
     pp.data[i] = i < ws ? static_cast<char*>(data[i]) : nullptr;
@@ -373,5 +397,31 @@ extern "C" int mojo_hip_peer_gather(void* const* peer_data, void* const* peer_fl
   }
 #undef LAUNCH
   MOJO_CHECK_LAUNCH("peer_gather");
+  return MOJO_OK;
+}
+
+extern "C" int mojo_hip_peer_pull(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank, int kind,
+                                  int64_t flag_chunk, uint32_t epoch, int64_t src_offset_bytes, int64_t bytes, void* dst,
+                                  int64_t dst_stride_bytes, int include_self, mojo_stream_t stream) {
+  MOJO_REQUIRE(world >= 1 && world <= PEER_MAX && rank >= 0 && rank < world && flag_chunk >= 0 && flag_chunk < PEER_MAX_CHUNKS &&
+                   kind >= 0 && kind < PEER_FLAG_KINDS,
+               MOJO_EINVAL, "peer_pull: bad arguments");
+  const int first = include_self ? 0 : 1;
+  const int n_src = static_cast<int>(world) - first;
+  if (bytes == 0 || n_src <= 0) return MOJO_OK;
+  MOJO_REQUIRE(dst && bytes > 0 && src_offset_bytes >= 0 && dst_stride_bytes >= bytes, MOJO_EINVAL, "peer_pull: bad shape");
+  MOJO_REQUIRE(bytes % 16 == 0 && src_offset_bytes % 16 == 0 && dst_stride_bytes % 16 == 0 && aligned_to(dst, 16), MOJO_EUNSUPPORTED,
+               "peer_pull: blocks must be whole 16-byte vectors");
+  PeerPtrs pp;
+  MOJO_REQUIRE(fill_ptrs(pp, peer_data, peer_flags, static_cast<int>(world)) == MOJO_OK, MOJO_EINVAL, "peer_pull: null peer pointer");
+  int64_t bx = ceil_div(bytes / 16, 256 * 2);
+  const int64_t cap = peer_max_blocks() / n_src > 0 ? peer_max_blocks() / n_src : 1;
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(peer_pull_kernel, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(n_src)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pp, static_cast<int>(world), static_cast<int>(rank), kind,
+                     static_cast<int>(flag_chunk), epoch, static_cast<long long>(src_offset_bytes), static_cast<long long>(bytes),
+                     static_cast<char*>(dst), static_cast<long long>(dst_stride_bytes), first, timeout_ticks());
+  MOJO_CHECK_LAUNCH("peer_pull");
   return MOJO_OK;
 }

@@ -5,8 +5,8 @@ The test box has ONE MI355X, and RCCL refuses two ranks on one device, so the ra
 group is gloo (device tensors are staged by gloo) — the same arrangement the reference uses when it runs these ops
 on a host without its vendor collective library (`tests/dist_common.py:38-81`).  What runs is the product path:
 `HIP<Op>.forward` -> `mojo_opset_amd.comm` pipelines -> `mojo_hip_gemm_rowmap` through the C ABI, chunked, with the
-exchange step on the process group; with ``MOJO_HIP_COMM_DIRECT=1`` the all-reduce / reduce-scatter exchange is this
-repository's own pull-and-add kernel over HIP-IPC peer buffers instead.
+exchange step on the process group; with ``MOJO_HIP_COMM_DIRECT=1`` the all-reduce / reduce-scatter / all-gather exchange
+is this repository's own pull kernels over HIP-IPC peer buffers instead.
 
 Checks (reference: tests/accuracy/operators/test_compute_with_comm.py):
   * the reference's per-rank vectors (tests/golden/compute_with_comm.pt) at the reference's bounds (5e-3 / 1e-4);
