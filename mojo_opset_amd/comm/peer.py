@@ -160,8 +160,8 @@ def release_all() -> None:
 
 
 def direct_enabled(group, x: torch.Tensor) -> bool:
-    """MOJO_HIP_COMM_DIRECT: "1" = use the peer exchange, "0"/unset = the collective library's ring (default until the
-    direct path has been measured on an 8-GPU node)."""
+    """MOJO_HIP_COMM_DIRECT: "1" = use the peer exchange (GemmAllReduce, GemmReduceScatter, AllGatherGemm), "0"/unset = the
+    collective library's ring (default until the direct path has been measured on an 8-GPU node)."""
     if group is None or not x.is_cuda:
         return False
     return os.environ.get("MOJO_HIP_COMM_DIRECT", "0") == "1" and dist.get_world_size(group) > 1
