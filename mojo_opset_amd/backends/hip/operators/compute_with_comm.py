@@ -60,7 +60,7 @@ class HIPGemmAllReduce(MojoGemmAllReduce):
             x2 = input.reshape(-1, input.shape[-1])
             x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
             n = _ENGINE.out_features(self.weight, self.trans_weight)
-            if peer.direct_supported(x2, n, x2.shape[0], 0):
+            if peer.direct_supported(x2, n, x2.shape[0]):
                 out = peer.gemm_all_reduce_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
                 return out.reshape(*input.shape[:-1], n)
         return gemm_all_reduce(_ENGINE, input, self.weight, self.bias, self.trans_weight, group)
@@ -105,7 +105,7 @@ class HIPGemmReduceScatter(MojoGemmReduceScatter):
             x2 = input.reshape(-1, input.shape[-1])
             x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
             n = _ENGINE.out_features(self.weight, self.trans_weight)
-            if input.shape[0] % ws == 0 and peer.direct_supported(x2, n, x2.shape[0] // ws, ws):
+            if input.shape[0] % ws == 0 and peer.direct_supported(x2, n, x2.shape[0] // ws):
                 out = peer.gemm_reduce_scatter_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
                 shape = list(input.shape[:-1]) + [n]
                 shape[0] //= ws

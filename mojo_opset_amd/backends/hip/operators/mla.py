@@ -129,13 +129,17 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
     return out
 
 
-def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tables, softmax_scale, cu_total_seq_lens):
+def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tables, softmax_scale, cu_total_seq_lens,
+                          max_total_seq_len=None):
     """Prefill in the golden's own formulation (experimental/operators/attention.py:405-447): un-page the latent,
     decompress K_nope / V for every key with ONE GEMM (rounded to the storage type, like `c_kv @ kv_b_proj.T`), then flash
     attention per head with D_qk = nope + rope, D_v = v (csrc/mla_prefill.hip).  3.4x fewer FLOPs than running the
-    absorbed decode kernel per query token at DeepSeek-V3 dimensions, and the golden's rounding points.  Returns None when
-    this route does not apply (dimensions without an instantiation, or a key capacity whose decompressed image would not
-    fit the budget) — the caller then takes the absorbed route."""
+    absorbed decode kernel per query token at DeepSeek-V3 dimensions, and the golden's rounding points.
+
+    The decompressed image needs `keys * H * (nope + v)` elements.  Lengths stay on the device, so the host sizes it from
+    what it knows: the table width (`max_total_seq_len` tightens it), and walks the batch in slices of sequences whose
+    image fits `MOJO_HIP_MLA_PREFILL_BYTES`.  Returns None when this route does not apply (dimensions without an
+    instantiation, or ONE sequence's capacity alone exceeds the budget) — the caller then takes the absorbed route."""
     lib = L.load()
     tq, heads, qk = query.shape
     nope, rope, vdim, r = op.qk_nope_head_dim, op.qk_rope_head_dim, op.v_head_dim, op.kv_lora_rank
@@ -146,13 +150,20 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     dev, dt = query.device, query.dtype
     batch, width = block_tables.shape
     page = ckv_cache.shape[2]
-    # host-side bound of the number of keys (lengths stay on the device: no sync)
-    cap = tq if cu_total_seq_lens is None else min(batch * width * page, ckv_cache.shape[0] * page)
-    per_seq_cap = min(tq, width * page) if cu_total_seq_lens is None else width * page
+    es = query.element_size()
     kv_cols = heads * (nope + vdim)
     budget = int(os.environ.get("MOJO_HIP_MLA_PREFILL_BYTES", str(8 << 30)))
-    if cap <= 0 or cap * kv_cols * query.element_size() > budget:
+    # host-side bound of one sequence's keys (lengths stay on the device: no sync)
+    per_seq = width * page
+    if max_total_seq_len is not None:
+        per_seq = min(per_seq, int(max_total_seq_len))
+    if cu_total_seq_lens is None:
+        per_seq = min(per_seq, tq)
+    if batch == 0 or per_seq <= 0 or per_seq * kv_cols * es > budget:
         return None
+    seqs_per_slice = max(1, min(batch, budget // (per_seq * kv_cols * es)))
+    if cu_total_seq_lens is None and tq * kv_cols * es <= budget:
+        seqs_per_slice = batch                              # kv = q lengths: the whole batch has exactly tq keys
     proj = op.kv_b_proj.detach()
     proj = proj if proj.is_contiguous() else proj.contiguous()
     if query.stride(2) != 1 or query.stride(1) != qk or query.stride(0) != heads * qk:
@@ -161,27 +172,35 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     cu_q = cu_q_lens.contiguous()
     cu_kv = None if cu_total_seq_lens is None else cu_total_seq_lens.contiguous()
     stream = L.stream_of(query)
-    ckv_flat = torch.empty(cap, r, dtype=dt, device=dev)
-    kpe_flat = torch.empty(cap, rope, dtype=dt, device=dev)
-    L.check(lib.mojo_hip_mla_unpage(L.ptr(ckv_cache), L.ptr(kpe_cache), L.ptr(ckv_flat), L.ptr(kpe_flat), L.ptr(cu_q),
-                                    L.ptr(cu_kv), L.ptr(tables), tables.stride(0), width, batch, r, rope, page,
-                                    query.element_size(), ckv_cache.stride(0), ckv_cache.stride(2), kpe_cache.stride(0),
-                                    kpe_cache.stride(2), per_seq_cap, stream), "hip mla un-page")
-    # kv[t, h*(nope+v) + j] = sum_k ckv[t, k] * kv_b_proj[h*(nope+v) + j, k]: one group whose row count is the device-side
-    # total number of keys (the last entry of the cumulative lengths), so rows past it are never computed
-    kv = torch.empty(cap, kv_cols, dtype=dt, device=dev)
-    counts = cu_q if cu_kv is None else cu_kv
-    count_ptr = L.c_void_p(counts.data_ptr() + 4 * batch)
-    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(1), dtype=torch.uint8, device=dev)
-    L.check(lib.mojo_hip_group_gemm(L.ptr(ckv_flat), L.ptr(proj), L.ptr(kv), count_ptr, 0, cap, r, kv_cols, 1, 1,
-                                    L.dtype_code(dt), L.ptr(ws), ws.numel(), stream), "hip mla decompression")
     out = torch.empty(tq, heads, vdim, dtype=dt, device=dev)
     sink = getattr(op, "attn_sink", None)
     sink = None if sink is None else sink.detach().to(torch.float32).contiguous()
     scale = 1.0 / math.sqrt(nope + rope) if softmax_scale is None else float(softmax_scale)
-    L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), L.ptr(cu_q),
-                                          L.ptr(cu_kv), tq, batch, heads, nope, rope, vdim, min(tq, per_seq_cap), scale,
-                                          L.dtype_code(dt), stream), "hip mla prefill attention")
+    cap = min(seqs_per_slice * per_seq, ckv_cache.shape[0] * page)
+    if cu_total_seq_lens is None:
+        cap = min(cap, tq)
+    ckv_flat = torch.empty(cap, r, dtype=dt, device=dev)
+    kpe_flat = torch.empty(cap, rope, dtype=dt, device=dev)
+    kv = torch.empty(cap, kv_cols, dtype=dt, device=dev)
+    count = torch.empty(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(1), dtype=torch.uint8, device=dev)
+    for b0 in range(0, batch, seqs_per_slice):
+        nb = min(seqs_per_slice, batch - b0)
+        cq = L.c_void_p(cu_q.data_ptr() + 4 * b0)
+        ck = None if cu_kv is None else L.c_void_p(cu_kv.data_ptr() + 4 * b0)
+        tb = L.c_void_p(tables.data_ptr() + 4 * b0 * tables.stride(0))
+        L.check(lib.mojo_hip_mla_unpage(L.ptr(ckv_cache), L.ptr(kpe_cache), L.ptr(ckv_flat), L.ptr(kpe_flat), cq, ck, tb,
+                                        tables.stride(0), width, nb, r, rope, page, es, ckv_cache.stride(0),
+                                        ckv_cache.stride(2), kpe_cache.stride(0), kpe_cache.stride(2), per_seq, L.ptr(count),
+                                        stream), "hip mla un-page")
+        # kv[t, h*(nope+v) + j] = sum_k ckv[t, k] * kv_b_proj[h*(nope+v) + j, k]: one group whose row count is the slice's
+        # device-side number of keys, so rows past it are never computed
+        L.check(lib.mojo_hip_group_gemm(L.ptr(ckv_flat), L.ptr(proj), L.ptr(kv), L.ptr(count), 0, cap, r, kv_cols, 1, 1,
+                                        L.dtype_code(dt), L.ptr(ws), ws.numel(), stream), "hip mla decompression")
+        last = b0 + nb >= batch
+        L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), cq, ck, tq,
+                                              nb, heads, nope, rope, vdim, min(tq, per_seq), scale, 1 if last else 0,
+                                              L.dtype_code(dt), stream), "hip mla prefill attention")
     return out
 
 
@@ -199,7 +218,10 @@ class HIPPagedPrefillMLA(_AbsorbedWeightCache, MojoPagedPrefillMLA):
     supported_platforms_list = _ROCM
 
     def forward(self, query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables,
-                softmax_scale: Optional[float] = None, cu_total_seq_lens: Optional[torch.Tensor] = None):
+                softmax_scale: Optional[float] = None, cu_total_seq_lens: Optional[torch.Tensor] = None, *,
+                max_total_seq_len: Optional[int] = None):
+        """``max_total_seq_len`` (extension, kw-only host int like the paged GQA ops take): an upper bound of any sequence's
+        total length; without it the block table's width bounds the size of the decompressed K/V image."""
         assert_paged_prefill_contract(cu_q_lens, block_tables, cu_total_seq_lens)
         if not self.is_causal:
             raise NotImplementedError("HIPPagedPrefillMLA supports causal attention only")
@@ -207,7 +229,7 @@ class HIPPagedPrefillMLA(_AbsorbedWeightCache, MojoPagedPrefillMLA):
                 and compressed_kv_cache.stride(3) == 1 and k_pe_cache.stride(3) == 1 and query.shape[0] >= 16:
             L.require_cuda(query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables, cu_total_seq_lens, self.kv_b_proj)
             out = _prefill_decompressed(self, query, compressed_kv_cache, k_pe_cache, cu_q_lens, block_tables, softmax_scale,
-                                        cu_total_seq_lens)
+                                        cu_total_seq_lens, max_total_seq_len)
             if out is not None:
                 return out
         return _mla_forward(self, query, compressed_kv_cache, k_pe_cache, block_tables, softmax_scale,

@@ -21,7 +21,7 @@ import torch.distributed as dist
 from ..backends.hip import lib as L
 
 _LOCK = threading.RLock()
-_CACHE: Dict[Tuple[int, int], "PeerExchange"] = {}
+_CACHE: Dict[Tuple[object, int], "PeerExchange"] = {}
 
 
 class _DeviceBytes:
@@ -137,7 +137,8 @@ class PeerExchange:
 def get_exchange(group, need_bytes: int) -> PeerExchange:
     """The group's exchange with at least ``need_bytes`` per parity half; (re)built collectively when it must grow, so every
     rank has to ask with the same sizes in the same order (they do: the ops are SPMD)."""
-    key = id(group)
+    # (the group's name identifies it for its lifetime; `id()` of a collected group object could be reused)
+    key = getattr(group, "group_name", None) or id(group)
     with _LOCK:
         for (k, cap), ex in list(_CACHE.items()):
             if k == key and cap >= need_bytes:
@@ -174,8 +175,8 @@ def _side_ptr(ex: PeerExchange):
     return ctypes.c_void_p(ex.side.cuda_stream)
 
 
-def direct_supported(x: torch.Tensor, n: int, rows: int, ws: int) -> bool:
-    """Whole 16-byte vectors per row, 16-bit or fp32 data, and no more chunks than the flag area holds."""
+def direct_supported(x: torch.Tensor, n: int, rows: int) -> bool:
+    """Whole 16-byte vectors per output row, 16-bit or fp32 data, at least one row."""
     es = x.element_size()
     return x.dtype in (torch.bfloat16, torch.float16, torch.float32) and (n * es) % 16 == 0 and rows > 0
 

@@ -35,14 +35,17 @@ struct UnpageArgs {
   const char* ckv; const char* kpe;
   char* ckv_out; char* kpe_out;
   const int32_t* cu_q; const int32_t* cu_kv; const int32_t* tables;
+  int32_t* count_out;                                          // [1]: total keys of these sequences (the GEMM's row count)
   int64_t table_stride, ckv_blk, ckv_tok, kpe_blk, kpe_tok;     // bytes
   int ckv_row_bytes, kpe_row_bytes, page, max_pages, batch;
 };
 
 __global__ __launch_bounds__(256) void mla_unpage_kernel(UnpageArgs a) {
   const int b = blockIdx.y;
+  // (flat rows are relative to the first sequence handed in: a caller may pass a slice of the batch)
   const int32_t* cu = a.cu_kv ? a.cu_kv : a.cu_q;
-  const int start = cu[b], len = cu[b + 1] - start;
+  const int start = cu[b] - cu[0], len = cu[b + 1] - cu[b];
+  if (a.count_out && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = cu[a.batch] - cu[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
   for (int t = blockIdx.x * 4 + wave; t < len; t += gridDim.x * 4) {
@@ -69,8 +72,9 @@ struct MlaPfArgs {
   const int32_t* cu_q;
   const int32_t* cu_kv;      // may be null: kv_len = q_len
   int heads, batch, n_qb;
-  int64_t total_tokens;
+  int64_t total_tokens;      // rows of `out`; rows behind cu_q[batch] are zeroed when zero_tail is set
   float scale_log2;
+  int zero_tail;
 };
 
 template <typename T> struct mpf_mfma;
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   const int head = unit % a.heads, b = unit / a.heads;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
-  const int kv_start = a.cu_kv ? a.cu_kv[b] : q_start;
-  const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - kv_start : q_len;
+  const int kv_start = a.cu_kv ? a.cu_kv[b] - a.cu_kv[0] : q_start - a.cu_q[0];      // row in the (slice-relative) flat buffers
+  const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
   if (qb * MPF_QPB >= q_len) return;
 
   const int lane = threadIdx.x & 63;
@@ -425,7 +429,7 @@ static int launch_mla_pf(const MlaPfArgs& a, hipStream_t s) {
   auto* fn = mla_prefill_kernel<T, DKN, DKR, DVV>;
   static std::atomic<uint64_t> attr_set{0};
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MPF_LDS);
-  const int64_t n_zero = ceil_div(a.total_tokens, static_cast<int64_t>(MPF_ZERO_TOKENS));
+  const int64_t n_zero = a.zero_tail ? ceil_div(a.total_tokens, static_cast<int64_t>(MPF_ZERO_TOKENS)) : 0;
   const int64_t blocks = static_cast<int64_t>(a.n_qb) * 8 * ceil_div(static_cast<int64_t>(a.heads) * a.batch, 8) + n_zero;
   MOJO_REQUIRE(blocks < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "mla_prefill: grid limit");
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(256), MPF_LDS, s, a);
@@ -449,7 +453,8 @@ extern "C" int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* 
                                    int64_t block_table_stride, int64_t max_blocks_per_seq, int64_t batch,
                                    int64_t kv_lora_rank, int64_t rope_dim, int64_t block_size, int64_t elt_bytes,
                                    int64_t ckv_block_stride, int64_t ckv_token_stride, int64_t kpe_block_stride,
-                                   int64_t kpe_token_stride, int64_t max_tokens_per_seq, mojo_stream_t stream) {
+                                   int64_t kpe_token_stride, int64_t max_tokens_per_seq, int32_t* total_keys_out,
+                                   mojo_stream_t stream) {
   if (batch == 0 || max_tokens_per_seq <= 0) return MOJO_OK;
   MOJO_REQUIRE(compressed_kv_cache && k_pe_cache && ckv_out && kpe_out && cu_q_lens && block_tables, MOJO_EINVAL,
                "mla_unpage: null pointer");
@@ -463,6 +468,7 @@ extern "C" int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* 
   a.ckv = static_cast<const char*>(compressed_kv_cache); a.kpe = static_cast<const char*>(k_pe_cache);
   a.ckv_out = static_cast<char*>(ckv_out); a.kpe_out = static_cast<char*>(kpe_out);
   a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens; a.tables = block_tables; a.table_stride = block_table_stride;
+  a.count_out = total_keys_out;
   a.ckv_blk = ckv_block_stride * elt_bytes; a.ckv_tok = ckv_token_stride * elt_bytes;
   a.kpe_blk = kpe_block_stride * elt_bytes; a.kpe_tok = kpe_token_stride * elt_bytes;
   a.ckv_row_bytes = static_cast<int>(kv_lora_rank * elt_bytes); a.kpe_row_bytes = static_cast<int>(rope_dim * elt_bytes);
@@ -479,7 +485,7 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
                                          const float* attn_sink, void* out, const int32_t* cu_q_lens,
                                          const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
                                          int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
-                                         float softmax_scale, int dtype, mojo_stream_t stream) {
+                                         float softmax_scale, int zero_padding_rows, int dtype, mojo_stream_t stream) {
   if (total_tokens == 0) return MOJO_OK;
   MOJO_REQUIRE(query && kv_decompressed && k_pe_flat && out && cu_q_lens, MOJO_EINVAL, "mla_prefill_attn: null pointer");
   MOJO_REQUIRE(mojo_hip_mla_prefill_supported(nope, rope, v_dim, dtype), MOJO_EUNSUPPORTED,
@@ -500,6 +506,7 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   a.n_qb = static_cast<int>(ceil_div(mq, MPF_QPB));
   a.total_tokens = total_tokens;
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.zero_tail = zero_padding_rows ? 1 : 0;
 #define MPF_LAUNCH(T)                                                                  \
   (nope == 128 ? launch_mla_pf<T, 4, 2, 4>(a, s) : nope == 64 ? launch_mla_pf<T, 2, 1, 2>(a, s) : launch_mla_pf<T, 3, 1, 4>(a, s))
   return dtype == MOJO_BF16 ? MPF_LAUNCH(bf16_t) : MPF_LAUNCH(f16_t);

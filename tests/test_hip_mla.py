@@ -397,6 +397,19 @@ def test_mla_prefill_decompressed_route(cfg, sink):
     if all(c == 0 for c in cached):                      # kv = q lengths: the `cu_total_seq_lens=None` calling form
         got2 = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV)))
         assert torch.equal(got, got2)
+    # the batch walked in slices of sequences (a byte budget for the decompressed image that only fits two of them), and
+    # the same with the per-sequence bound passed by the caller instead of taken from the table width: same numbers
+    import os
+    kv_cols_bytes = h * (nope + vd) * 2
+    os.environ["MOJO_HIP_MLA_PREFILL_BYTES"] = str(2 * table.shape[1] * page * kv_cols_bytes)
+    try:
+        sliced = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
+    finally:
+        os.environ.pop("MOJO_HIP_MLA_PREFILL_BYTES", None)
+    assert torch.equal(sliced, got)
+    hinted = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV),
+                       max_total_seq_len=max(kv_lens)))
+    assert torch.equal(hinted, got)
     # padding rows behind the last sequence read as zeros (the golden's `torch.zeros` output, :393)
     pad = torch.randn(5, h, nope + rope, generator=g).to(torch.bfloat16)
     got3 = to_cpu(op(torch.cat([q, pad]).to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV),
