@@ -257,7 +257,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
-                     "kernel": ("mojo::decode_split_kernel<bf16,4,nt,fused> (one launch per op call: the chunk partials are merged in LDS)"
+                     "kernel": ("mojo::decode_split_kernel<bf16,4,nt,paired> (one launch per op call: 8-wave workgroups own a length-ranked pair "
+                                "of sequences, their chunk partials are merged in LDS)"
+                                if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" and os.environ.get("MOJO_HIP_DECODE_PAIR", "1") != "0" else
+                                "mojo::decode_split_kernel<bf16,4,nt,fused> (MOJO_HIP_DECODE_PAIR=0)"
                                 if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" else
                                 "mojo::decode_split_kernel<bf16,4,nt> + mojo::decode_merge_kernel (MOJO_HIP_DECODE_FUSE=0)")},
     }

@@ -182,6 +182,43 @@ def check_reference_shapes(rank, ws, group):
     _compare(rank, "closed_form:MojoGemmAll2All:32x64x128:float32", got, want, 1e-4)
 
 
+def check_timeout_path(rank, ws, group):
+    """Liveness of the peer exchange: a rank whose peer never shows up must not spin for ever.  Both ranks make one
+    normal call (that builds the exchange); then only rank 0 calls again.  Its waits expire (MOJO_HIP_PEER_TIMEOUT_MS), the
+    kernels drain, the output is NaN-poisoned and `PeerExchange.check()` raises."""
+    import time
+
+    from hip_utils import hip_cls
+    from mojo_opset_amd.comm import peer
+
+    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+    torch.manual_seed(rank)
+    x = torch.randn(512, 256, dtype=torch.bfloat16).to(DEV)
+    w = torch.randn(256, 512, dtype=torch.bfloat16).to(DEV)
+    op = hip_cls("MojoGemmAllReduce")(weight=w, bias=None, trans_weight=True, process_group=group)
+    first = op(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(first.float()).all()
+    for ex in peer._CACHE.values():
+        ex.check()
+    dist.barrier()
+    if rank == 0:
+        t0 = time.time()
+        lonely = op(x)
+        torch.cuda.synchronize()
+        waited = time.time() - t0
+        assert torch.isnan(lonely.float()).any(), "a timed-out exchange must poison its output"
+        raised = False
+        try:
+            for ex in peer._CACHE.values():
+                ex.check()
+        except RuntimeError:
+            raised = True
+        assert raised, "PeerExchange.check() must report the expired wait"
+        _report(rank, check="timeout:MojoGemmAllReduce", waited_s=round(waited, 2), poisoned=True, reported=True)
+    dist.barrier()
+
+
 def main():
     import faulthandler
 
@@ -199,6 +236,10 @@ def main():
         modes = [m for m in os.environ.get("MOJO_TEST_COMM_MODES", "chunks1,chunks4").split(",") if m]
         for mode in modes:
             os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+            if mode == "timeout":
+                _report(rank, mode=mode)
+                check_timeout_path(rank, ws, group)
+                continue
             if mode.startswith("chunks"):
                 os.environ["MOJO_HIP_COMM_CHUNKS"] = mode[6:]
             elif mode.startswith("direct"):

@@ -69,3 +69,12 @@ def test_hip_compute_comm_two_ranks():
         assert len(checks) == 5 + 2 * (8 + 4) + 1, (mode, len(checks))
         assert any(c.startswith("oracle:") for c in checks) and any(c.startswith("fp32ref:") for c in checks)
     assert any("direct_exchange" in r for r in recs)
+
+
+def test_hip_peer_exchange_wait_is_bounded(monkeypatch):
+    """A rank whose peer never enters the call: the bounded wait expires, the grid drains, the output is NaN and the error
+    word is reported (csrc/peer_comm.hip `wait_flag`)."""
+    monkeypatch.setenv("MOJO_HIP_PEER_TIMEOUT_MS", "700")
+    recs = run_ranks("timeout", timeout=120)
+    hit = [r for r in recs if r.get("check") == "timeout:MojoGemmAllReduce"]
+    assert hit and hit[0]["poisoned"] and hit[0]["reported"] and hit[0]["waited_s"] < 30, recs
