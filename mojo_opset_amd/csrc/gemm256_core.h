@@ -154,6 +154,23 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
   }
 };
 
+#ifdef GEMM_STAMPS
+// In-kernel cycle anatomy of the K loop (build with MOJO_HIP_EXTRA_CXXFLAGS=-DGEMM_STAMPS; scripts/probes/gemm_stamps.py):
+// lane i of `tacc` accumulates the cycles between stamp i-1 and stamp i; 5 stamps per phase x 4 phases.  Timing tool only.
+static __device__ unsigned g_gemm_stamps[8192 * 8 * 32];
+#define G_STAMP(i)                                                                \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    const unsigned long long t_ = __builtin_readcyclecounter();                   \
+    const unsigned d_ = static_cast<unsigned>(t_ - t_prev);                       \
+    t_prev = t_;                                                                  \
+    tacc += (lane == (i)) ? d_ : 0u;                                              \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } while (0)
+#else
+#define G_STAMP(i)
+#endif
+
 // ---- the kernel ------------------------------------------------------------------------------------------
 // PERSIST: one workgroup per CU walks tiles bid, bid + gridDim.x, ...; the first six half-tiles of the NEXT tile are
 // requested before the epilogue of the current one (which then stages through its own 32 KiB instead of the tile
@@ -402,40 +419,64 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   };
   prologue();
 
-  frag32 fa[4], fw0[2], fw1[2];
+  frag32 fa0[4], fa1[4], fw0[2], fw1[2];          // A0 / A1 fragments live in their own registers: A0 of the NEXT K-tile is read in P4
   TrRegs tr;
 
   auto seg_end = [&]() {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   };
+#ifdef GEMM_STAMPS
+  unsigned tacc = 0;
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
+  auto seg_end_s = [&](int p) {
+    G_STAMP(5 * p + 2);                                  // MFMA segment
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    G_STAMP(5 * p + 3);                                  // counted wait
+    __builtin_amdgcn_s_barrier();
+    G_STAMP(5 * p + 4);                                  // second barrier
+  };
   auto ktile = [&](int t, int buf) {
-    // P1
+    // P1   (A0 of this K-tile was read in P4 of the previous one, or ahead of the loop)
     stage(3, t + 1, buf ^ 1);
     if constexpr (W_NMAJOR) issue_w_tr(tr, 0, buf); else read_w(fw0, 0, buf);
-    read_a(fa, 0, buf);
+#ifdef GEMM_A0_IN_P1                                     // A/B switch: round 1's placement (12 reads in P1, none in P4)
+    read_a(fa0, 0, buf);
+#endif
+    G_STAMP(0);                                          // stage + read issue
     __builtin_amdgcn_s_barrier();
+    G_STAMP(1);                                          // first barrier
     if constexpr (W_NMAJOR) retire_w_tr(tr, fw0);
-    quadrant(fa, fw0, 0, 0);
-    seg_end();
+    quadrant(fa0, fw0, 0, 0);
+    seg_end_s(0);
     // P2
     stage(1, t + 1, buf ^ 1);
     if constexpr (W_NMAJOR) issue_w_tr(tr, 1, buf); else read_w(fw1, 1, buf);
+    G_STAMP(5);
     __builtin_amdgcn_s_barrier();
+    G_STAMP(6);
     if constexpr (W_NMAJOR) retire_w_tr(tr, fw1);
-    quadrant(fa, fw1, 0, 1);
-    seg_end();
+    quadrant(fa0, fw1, 0, 1);
+    seg_end_s(1);
     // P3
     stage(0, t + 2, buf);
-    read_a(fa, 1, buf);
+    read_a(fa1, 1, buf);
+    G_STAMP(10);
     __builtin_amdgcn_s_barrier();
-    quadrant(fa, fw1, 1, 1);
-    seg_end();
-    // P4
+    G_STAMP(11);
+    quadrant(fa1, fw1, 1, 1);
+    seg_end_s(2);
+    // P4   reads A0 of K-tile t+1 (retired by the wait at the end of P2; restaged two phases after this read at the earliest)
     stage(2, t + 2, buf);
+#ifndef GEMM_A0_IN_P1
+    read_a(fa0, 0, buf ^ 1);
+#endif
+    G_STAMP(15);
     __builtin_amdgcn_s_barrier();
-    quadrant(fa, fw0, 1, 0);
-    seg_end();
+    G_STAMP(16);
+    quadrant(fa1, fw0, 1, 0);
+    seg_end_s(3);
   };
 
   // stores the previous tile's epilogue put behind this tile's prologue loads (vmcnt counts both, in issue order)
@@ -455,6 +496,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   first_tile = false;
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();            // the stagger
+#ifndef GEMM_A0_IN_P1
+  read_a(fa0, 0, 0);                                    // A0 of K-tile 0 (every later A0 is read one phase ahead, in P4)
+#endif
 
   int t = 0;
   for (; t + 1 < nkt; t += 2) {
@@ -466,6 +510,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   // (the nops: an MFMA issued from asm is not padded by hipcc in front of the first vector read of its result)
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
+#ifdef GEMM_STAMPS
+  if (bid < 8192) {
+    if (lane < 20) g_gemm_stamps[(bid * 8 + wave) * 32 + lane] = tacc;
+    if (lane == 31) g_gemm_stamps[(bid * 8 + wave) * 32 + 31] = static_cast<unsigned>(nkt);
+    if (lane == 30) g_gemm_stamps[(bid * 8 + wave) * 32 + 30] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime());
+  }
+#endif
   if constexpr (PERSIST) {
     // ---- persistent form: request the next tile, then write this one out through the wave's own staging area ----------
     static_assert(Epi::kRowStaged, "the persistent form has the row-staged epilogue only");
@@ -692,12 +743,12 @@ inline int device_cu_count() {
   return v;
 }
 
-template <typename P, typename Epi>
-inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s, bool allow_persistent = false) {
+template <typename P, typename Epi, bool ALLOW_PERSISTENT = false>
+inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
   const int64_t n_tiles = a.glu ? (a.N / 2) / 128 : ceil_div(a.N, BN);
   const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles * a.splitk;   // upper bound; surplus blocks exit
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
-  if constexpr (Epi::kRowStaged) {
+  if constexpr (Epi::kRowStaged && ALLOW_PERSISTENT) {
     // persistent form (one workgroup per CU, next tile requested before this tile's epilogue): row-staged 16-bit output,
     // no bias / GLU / split-K, and enough tiles that every CU gets at least two.  OPT-IN (MOJO_HIP_GEMM_PERSIST=1): A/B on
     // one MI355X in one session (round 2, random bf16, TFLOP/s plain -> persistent): Mixtral up [K,N] 1279 -> 1278-1285,
@@ -707,7 +758,7 @@ inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hi
     // hide, and hipcc builds the loop body with 19-20 SGPR spills; results are identical (all GEMM tests pass with it on).
     static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_PERSIST"); return !(e && e[0] == '1'); }();
     const int cus = device_cu_count();
-    if (allow_persistent && !off && a.stage_rows && !a.glu && a.splitk == 1 && !epi.has_bias() && !a.ablate && blocks >= 2 * cus) {
+    if (!off && a.stage_rows && !a.glu && a.splitk == 1 && !epi.has_bias() && !a.ablate && blocks >= 2 * cus) {
       constexpr int LDS_P = LDS_BYTES + PERSIST_STAGE_BYTES;
       if (a.w_n == 1) {
         auto* fn = gemm256_kernel<P, true, Epi, true>;

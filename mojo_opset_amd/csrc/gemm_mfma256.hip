@@ -44,10 +44,10 @@ int launch_gemm_mfma256(const GemmArgs& a_in, int dtype, int64_t m_total, hipStr
   MOJO_REQUIRE(!a.glu || gemm_mfma256_glu_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: fused SwiGLU needs I %% 128 == 0");
   if (dtype == MOJO_BF16) {
     g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias)};
-    return g256::gemm256_launch<g256::PolBF16>(a, epi, m_total, s, true);
+    return g256::gemm256_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, true>(a, epi, m_total, s);
   }
   g256::EpiloguePlain<f16_t> epi{static_cast<f16_t*>(a.C), a.ldc, static_cast<const f16_t*>(a.bias)};
-  return g256::gemm256_launch<g256::PolF16>(a, epi, m_total, s, true);
+  return g256::gemm256_launch<g256::PolF16, g256::EpiloguePlain<f16_t>, true>(a, epi, m_total, s);
 }
 
 // 16-bit operands, fp32 output (optionally accumulated onto C): used by the MoE router for its hi/lo split product
@@ -60,3 +60,10 @@ int launch_gemm_mfma256_f32out(const GemmArgs& a, int dtype, int accumulate, int
 }
 
 }  // namespace mojo
+
+#ifdef GEMM_STAMPS
+extern "C" int mojo_hip_debug_gemm_stamps(unsigned* host_out, int64_t count) {
+  if (hipDeviceSynchronize() != hipSuccess) return MOJO_ELAUNCH;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mojo::g256::g_gemm_stamps), static_cast<size_t>(count) * 4) == hipSuccess ? MOJO_OK : MOJO_ELAUNCH;
+}
+#endif
