@@ -87,6 +87,31 @@ class PeerExchange:
         self.epoch = 0
         self.side = torch.cuda.Stream(device=self.device)
         dist.barrier(group=group)               # every rank has opened every buffer (and cleared its own) before first use
+        self._verify_mapping()
+
+    def _verify_mapping(self) -> None:
+        """Every rank stamps the head of its data area and reads every peer's stamp back through the opened pointer with a
+        plain device copy: a mapping that does not reach the peer's memory fails here, as an exception on every rank,
+        and not as a poisoned result (or a fault) inside the first exchange kernel."""
+        words = 64
+        stamp = torch.arange(words, dtype=torch.int32, device=self.device) * 16 + self.rank
+        self._alias[: words * 4].view(torch.int32).copy_(stamp)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        bad = []
+        for r, base in enumerate(self._bases):
+            seen = torch.as_tensor(_DeviceBytes(base, words * 4), device=self.device).view(torch.int32).clone()
+            want = torch.arange(words, dtype=torch.int32, device=self.device) * 16 + r
+            if not torch.equal(seen, want):
+                bad.append(r)
+        torch.cuda.synchronize(self.device)
+        verdicts: List[Optional[list]] = [None] * self.ws
+        dist.all_gather_object(verdicts, bad, group=self.group)   # also: nobody clears a stamp a peer is still reading
+        self._alias[: words * 4].zero_()
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        if any(verdicts):
+            raise RuntimeError(f"peer buffers: opened mappings do not show the peers' memory (per rank: {verdicts})")
 
     # ---- per-call state -----------------------------------------------------------------------------------------
     def begin_call(self) -> Tuple[int, int]:
