@@ -75,6 +75,7 @@ struct MlaPfArgs {
   int64_t total_tokens;      // rows of `out`; rows behind cu_q[batch] are zeroed when zero_tail is set
   float scale_log2;
   int zero_tail;
+  int n_slots;               // dispatch slots per unit: n_qb, made odd (see the kernel)
 };
 
 template <typename T> struct mpf_mfma;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   // other units' streams — ~80 MB through a 4 MiB L2 — between two readers of the same keys: every block read HBM.)
   const int inner = a.heads * a.batch;
   const int units_per_xcd = (inner + 7) / 8;
-  const int n_attn = 8 * units_per_xcd * a.n_qb;
+  const int n_attn = 8 * units_per_xcd * a.n_slots;
   if (static_cast<int>(blockIdx.x) >= n_attn) {          // trailing workgroups: rows no sequence owns read as zeros
     const int64_t z = static_cast<int64_t>(blockIdx.x) - n_attn;
     const int64_t t0 = max(static_cast<int64_t>(a.cu_q[a.batch]), z * MPF_ZERO_TOKENS);
@@ -130,9 +131,15 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
     return;
   }
   const int xcd = static_cast<int>(blockIdx.x) & 7, slot = static_cast<int>(blockIdx.x) >> 3;
-  const int unit = (slot / a.n_qb) * 8 + xcd;
+  const int unit = (slot / a.n_slots) * 8 + xcd;
   if (unit >= inner) return;
-  const int qb = a.n_qb - 1 - slot % a.n_qb;
+  // Inside an XCD the blocks go to its four shader engines in strict rotation and in order, and a block waits for ITS
+  // engine (scripts/probes/dispatch_rate.hip: work that repeats every 4 blocks of an XCD lands on one engine, 3.7x the
+  // balanced time).  With every unit's blocks listed longest first and an even count per unit, an engine would get the same
+  // position of every unit — engine 0 all the longest blocks.  The count of slots per unit is therefore odd (one empty
+  // slot when n_qb is even), so consecutive units start on consecutive engines and the order inside a unit stays.
+  if (slot % a.n_slots >= a.n_qb) return;
+  const int qb = a.n_qb - 1 - slot % a.n_slots;
   const int head = unit % a.heads, b = unit / a.heads;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
@@ -430,7 +437,7 @@ static int launch_mla_pf(const MlaPfArgs& a, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MPF_LDS);
   const int64_t n_zero = a.zero_tail ? ceil_div(a.total_tokens, static_cast<int64_t>(MPF_ZERO_TOKENS)) : 0;
-  const int64_t blocks = static_cast<int64_t>(a.n_qb) * 8 * ceil_div(static_cast<int64_t>(a.heads) * a.batch, 8) + n_zero;
+  const int64_t blocks = static_cast<int64_t>(a.n_slots) * 8 * ceil_div(static_cast<int64_t>(a.heads) * a.batch, 8) + n_zero;
   MOJO_REQUIRE(blocks < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "mla_prefill: grid limit");
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(256), MPF_LDS, s, a);
   MOJO_CHECK_LAUNCH("mla_prefill");
@@ -504,6 +511,7 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   a.heads = static_cast<int>(heads); a.batch = static_cast<int>(batch);
   const int64_t mq = (max_q_len > 0 && max_q_len < total_tokens) ? max_q_len : total_tokens;
   a.n_qb = static_cast<int>(ceil_div(mq, MPF_QPB));
+  { const char* e = getenv("MOJO_HIP_MLA_PREFILL_ODD_SLOTS"); a.n_slots = (e && e[0] == '0') ? a.n_qb : (a.n_qb | 1); }
   a.total_tokens = total_tokens;
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.zero_tail = zero_padding_rows ? 1 : 0;

@@ -49,6 +49,7 @@ struct PrefillArgs {
   float scale_log2;
   int abab;
   int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
+  int skew;                  // rotate the sequence coordinate by this much per query-block level (0 or 1)
 };
 
 template <typename T> struct pf_mfma;
@@ -131,7 +132,12 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   }
   const int qb = a.n_qb - 1 - static_cast<int>(blockIdx.x / inner);
   const int rem = static_cast<int>(blockIdx.x % inner);
-  const int kvh = rem % a.hkv, b = rem / a.hkv;
+  // Blocks are dealt to XCDs, and inside an XCD to its shader engines, in strict rotation and in order: with the
+  // sequence as a fixed coordinate every block of a long sequence lands on ONE engine, and while its two slots per CU are
+  // full the blocks behind it wait although other engines are empty (measured on 16 ragged sequences: 272 workgroups
+  // resident for the first 25 us of a 150 us launch, 91 CUs idle).  The sequence coordinate is therefore rotated by
+  // one per query-block level, so a sequence's blocks walk over the engines.
+  const int kvh = rem % a.hkv, b = (rem / a.hkv + a.skew * static_cast<int>(blockIdx.x / inner)) % a.batch;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
@@ -159,7 +165,11 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
 #ifdef PF_WG_STAMPS
   const unsigned long long wg_t0 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) g_pf_stamps[blockIdx.x * 16 + 6] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime());   // 100 MHz, chip-wide
+  if (threadIdx.x == 0 && blockIdx.x < 8192 * 4) {
+    g_pf_stamps[blockIdx.x * 16 + 6] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime());   // 100 MHz, chip-wide
+    g_pf_stamps[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                 // HW_ID: where it runs
+    g_pf_stamps[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);                // XCC_ID
+  }
 #endif
 
   const int lane = threadIdx.x & 63;
@@ -646,6 +656,7 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
   MOJO_REQUIRE(n_qb * a.hkv * batch + n_zero < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
   a.batch = static_cast<int>(batch);
   a.n_qb = static_cast<int>(n_qb);
+  { const char* e = getenv("MOJO_HIP_PREFILL_SKEW"); a.skew = (e && e[0] == '0') ? 0 : 1; }
   dim3 grid(static_cast<unsigned>(n_qb * a.hkv * batch + n_zero));
   switch (G) {
     case 1: return dispatch_dk<T, 1>(a, grid, s);
