@@ -410,6 +410,13 @@ def test_mla_prefill_decompressed_route(cfg, sink):
     hinted = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV),
                        max_total_seq_len=max(kv_lens)))
     assert torch.equal(hinted, got)
+    # dispatch slots per (sequence, head) padded to an odd count (engine rotation) or not: every block visited once either way
+    os.environ["MOJO_HIP_MLA_PREFILL_ODD_SLOTS"] = "0"
+    try:
+        even = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
+    finally:
+        os.environ.pop("MOJO_HIP_MLA_PREFILL_ODD_SLOTS", None)
+    assert torch.equal(even, got)
     # padding rows behind the last sequence read as zeros (the golden's `torch.zeros` output, :393)
     pad = torch.randn(5, h, nope + rope, generator=g).to(torch.bfloat16)
     got3 = to_cpu(op(torch.cat([q, pad]).to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV),

@@ -148,3 +148,19 @@ def test_prefill_fast_staging_is_bit_identical_to_general_staging(page, layout_n
     monkeypatch.setenv("MOJO_HIP_PREFILL_FAST_STAGE", "1")
     got = op(*args, cu_total_seq_lens=cu_kv.to(DEV))
     assert torch.equal(got, want)
+
+
+def test_prefill_block_order_does_not_change_the_result(monkeypatch):
+    """The (sequence, query block) -> workgroup mapping is rotated per query-block level so that a long sequence's blocks
+    walk over the shader engines; every (sequence, block) must still be visited exactly once: same bits either way."""
+    q_lens, cached = [700, 33, 0, 512, 129, 1000, 64], [0, 90, 10, 0, 300, 17, 0]
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, 8, 2, 128, 16, seed=11, pad_tokens=5)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    args = [t.to(DEV) for t in (q, k, v, cu_q, table)]
+    monkeypatch.setenv("MOJO_HIP_PREFILL_SKEW", "0")
+    plain = op(*args, cu_total_seq_lens=cu_kv.to(DEV), max_q_len=max(q_lens), max_total_seq_len=max(kv_lens))
+    monkeypatch.setenv("MOJO_HIP_PREFILL_SKEW", "1")
+    rotated = op(*args, cu_total_seq_lens=cu_kv.to(DEV), max_q_len=max(q_lens), max_total_seq_len=max(kv_lens))
+    assert torch.equal(plain, rotated)
+    want = torch_cls("MojoPagedPrefillGQA")()(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv)
+    assert_close_tree(to_cpu(rotated), want, ATOL, RTOL)
