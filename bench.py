@@ -290,7 +290,12 @@ def main():
         if isinstance(head, dict) and "tflops" in head:
             line["roofline_group_gemm"] = {
                 "bound": "mfma", "achieved": head["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": head["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "frac": head["tflops"] / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": (lambda r, w: None if r is None or w is None else int(r + w))(
+                    _profiled("r2_group_gemm_traffic.json", "memory_side_read_bytes"),
+                    _profiled("r2_group_gemm_traffic.json", "memory_side_write_bytes")),
+                "traffic_source": "profiles/r2_group_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                "algorithmic_bytes_per_launch": 2 * (16384 * 4096 + 8 * 4096 * 28672 + 16384 * 28672),
                 "flops_per_launch": 2.0 * 16384 * 4096 * 28672, "device_us_per_launch": head["us"],
                 "sustained_clock_mhz": _profiled("r2_group_gemm_counters.json", "sustained_clock_mhz"),
                 "mfma_busy_frac_profiled": _profiled("r2_group_gemm_counters.json", "mfma_busy_frac"),
