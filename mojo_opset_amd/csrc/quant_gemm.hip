@@ -354,10 +354,17 @@ static bool quant_skinny_ok(int64_t m, const GemmArgs& a) {
 static int quant_skinny_splitk(int k, int n, int64_t m) {
   if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return v; }
   const int nkb = k / 256, tiles = (n / 64) * (m > 64 ? 2 : 1);
-  int sk = (256 + tiles - 1) / tiles;                    // one workgroup per CU, three weight blocks in flight each
-  if (sk > nkb / 4) sk = nkb / 4;                        // at least four K blocks per slice
-  if (sk > 64) sk = 64;
-  return sk < 1 ? 1 : sk;
+  // A CU's rate does not grow with a second workgroup on it (measured, N = 7168: 3 slices = 336 workgroups, 1.3 per CU,
+  // 33-35 us; 2 slices = 224 and 4 = 448 workgroups 29.5 us), so the time goes as (workgroups on the fullest CU) x
+  // (work per workgroup) = ceil(tiles * sk / 256) / sk.  Take the smallest sk (least slab traffic) with the least of that,
+  // among splits of at most two workgroups per CU and at least four K blocks per slice.
+  int best = 1;
+  double best_cost = static_cast<double>((tiles + 255) / 256);
+  for (int sk = 2; sk <= 64 && sk <= nkb / 4 && tiles * sk <= 512; ++sk) {
+    const double cost = static_cast<double>((tiles * sk + 255) / 256) / sk;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = sk; }
+  }
+  return best;
 }
 
 template <typename TO, bool FP8>
