@@ -56,6 +56,7 @@ template <> struct mla_mfma<f16_t> {
 };
 
 constexpr int MLA_KEYS = 64;
+constexpr int MLA512_DEFAULT_KERNEL = 0;       // 0 oct, 1 pair, 2 ping-pong (dispatch_mla)
 
 template <int R, int ROPE> struct mla_geom {
   static constexpr int CH = (R + ROPE) / 8;                               // 16-byte chunks per latent row
@@ -347,6 +348,7 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
 }  // namespace mojo
 #include "mla512_pair.h"
 #include "mla512_oct.h"
+#include "mla512_pp.h"
 namespace mojo {
 
 // merge the splits of one (token, head): grid = (Tq, H), R/4 threads
@@ -400,12 +402,23 @@ template <typename T>
 static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
   if (r == 512 && rope == 64 && a.page_shift >= 0) {
     const int head_blocks = (a.heads + 63) / 64;
-    // MOJO_HIP_MLA_KERNEL=pair selects the one-wave-per-SIMD layout (32 heads per wave); default: two waves per SIMD
-    static const bool use_pair = [] { const char* e = getenv("MOJO_HIP_MLA_KERNEL"); return e && e[0] == 'p'; }();
-    if (use_pair) {
+    // MOJO_HIP_MLA_KERNEL: "pp" the ping-pong kernel (32-key tiles, the two waves of a SIMD one segment apart), "oct" two
+    // waves per SIMD in lock-step on 64-key tiles, "pair" one wave per SIMD with 32 heads
+    const int which = [] {                               // read per call: the tests switch kernels inside one process
+      const char* e = getenv("MOJO_HIP_MLA_KERNEL");
+      if (!e) return MLA512_DEFAULT_KERNEL;
+      if (e[0] == 'p' && e[1] == 'a') return 1;
+      if (e[0] == 'p') return 2;
+      return 0;
+    }();
+    if (which == 1) {
       void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
       hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
+    } else if (which == 2) {
+      void (*fn)(MlaArgs) = mla512_pp_kernel<T>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PP_LDS);
+      hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(512), MLA512_PP_LDS, s, a);
     } else {
       void (*fn)(MlaArgs) = mla512_oct_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_OCT_LDS);

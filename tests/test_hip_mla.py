@@ -223,6 +223,38 @@ def test_mla_decode_full_size_properties():
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("cfg", [(2, 128, 700, False), (5, 128, 1500, True), (3, 64, 3000, False), (16, 128, 2048, True), (1, 16, 900, False),
+                                 (64, 128, 300, False), (4, 128, 33, True)],
+                         ids=["B2", "B5_SINK", "B3_H64", "B16_SINK", "B1_H16", "B64_SHORT", "B4_TINY"])
+@pytest.mark.parametrize("kernel", ["pp", "oct", "pair"])
+def test_mla_decode_r512_kernels_agree(cfg, kernel, monkeypatch):
+    """The three r = 512 latent kernels (MOJO_HIP_MLA_KERNEL: ping-pong on 32-key tiles, lock-step on 64-key tiles, one wave
+    per SIMD) against the exactly computed result and the golden, on ragged batches with empty sequences, empty key splits,
+    lengths that end inside a tile and fewer heads than a workgroup covers."""
+    b, h, s_max, sink = cfg
+    nope, rope, vd, r, page = 128, 64, 128, 512, 16
+    g = torch.Generator().manual_seed(b * 7 + h)
+    lens = [int(x) for x in torch.randint(1, s_max + 1, (b,), generator=g)]
+    lens[0] = s_max
+    if b > 2:
+        lens[1] = 0                                                  # an empty sequence: zeros
+        lens[2] = min(40, s_max)                                     # all but the first key split empty
+    ckv, kpe, table, w, sk = make_mla(lens, h, nope, rope, vd, r, page, sink, seed=h + b, wscale=0.05)
+    q = torch.randn(b, h, nope + rope, generator=g).to(torch.bfloat16)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, DEV)
+    monkeypatch.setenv("MOJO_HIP_MLA_KERNEL", kernel)
+    got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV)))
+    again = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV)))
+    assert torch.equal(got, again)                                   # no race between the staggered wave groups
+    if b <= 5:
+        ref = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, "cpu")
+        check_mla(got, ref(q, ckv, kpe, lens_t, table), exact_mla(q, ckv, kpe, table, w, sk, h, nope, rope, vd, r, lens))
+    else:
+        exact = exact_mla(q, ckv, kpe, table, w, sk, h, nope, rope, vd, r, lens)
+        torch.testing.assert_close(got.double(), exact.double(), atol=1e-2, rtol=1e-2)
+
+
 # ---- the reference's own generators, verbatim recipe (test_attention.py:1131-1155, :1193-1233): kv_b_proj = randn ------
 def _ref_decode_data(batch, h, nope, rope, r, max_len, page):
     q = torch.randn(batch, h, nope + rope, dtype=torch.bfloat16)
