@@ -234,6 +234,9 @@ __global__ __launch_bounds__(512, 1) void mla512_oct_kernel(MlaArgs a) {
           if (prefetch) stage_piece(sp, B);
         });
       }
+      // wait states between the last MFMA and the first vector read of the scores: on the last tile of a split (nothing to
+      // stage) with no key to mask that read follows the MFMA across two branches, where hipcc places none (mla512_pp.h)
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s[0]), "+v"(s[1]));
       MLA_STAMP(2);
       // ---- own-half maxima and probabilities -------------------------------------------------------------------------
       const int key0 = k_begin + kt * MLA_KEYS + 32 * half + 4 * grp;

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void mla512_pair_kernel(MlaArgs a) {
           if (prefetch) { stage_piece(sp, 2 * B); stage_piece(sp, 2 * B + 1); }
         });
       }
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));   // see mla512_oct.h
       // ---- row maxima of the own half, exchanged with the partner ----------------------------------------------------
       const int key0 = k_begin + kt * MLA_KEYS + 32 * half + 4 * grp;
       if (k_begin + (kt + 1) * MLA_KEYS > k_end) {
