@@ -1,9 +1,18 @@
-# full GPU pass: test suite, smoke, bench, profiling pass (outputs under gpurun_out/)
-mkdir -p gpurun_out; cd /root/repo; export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/pytest_full.log
-cat gpurun_out/pytest_full.log | tail -3
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash scripts/gpu_bench.sh
-rm -rf gpurun_out/prof_r1; bash scripts/profile_r1.sh > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1/mla_stats -- python benchmarks/mla_bench.py > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1/prefill_stats -- python benchmarks/prefill_bench.py > /dev/null 2>&1
+# One GPU-box pass of the round: the whole GPU suite, the default bench line and the dispatcher probe.
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash scripts/gpu_round.sh'
+# Progress goes to gpurun_out/ (a silent command is taken for hung after 7 minutes).
+cd /root/repo; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+mkdir -p gpurun_out; rm -f gpurun_out/comm_ranks_progress*.log gpurun_out/round_alive.log
+L=gpurun_out/round.log; : > $L
+( while true; do sleep 60; echo "[alive $(date +%T)] $(tail -c 120 $L | tr '\n' ' ')" >> gpurun_out/round_alive.log; done ) &
+ALIVE=$!
+echo "== suite" | tee -a $L
+MOJO_HIP_PEER_TIMEOUT_MS=8000 timeout -k 10 900 python -u -m pytest tests -q -m gpu --durations=10 >> $L 2>&1; echo "rc=$?" | tee -a $L
+echo "== bench" | tee -a $L
+timeout -k 10 400 python -u bench.py > gpurun_out/round_bench.json 2>> $L; echo "rc=$?" | tee -a $L
+echo "== two ranks, control flow over gloo (one GPU)" | tee -a $L
+MOJO_BENCH_DIST_BACKEND=gloo timeout -k 10 600 python -u bench.py --gpus 2 --steps 20 --warmup 3 > gpurun_out/round_bench_2ranks.json 2>> $L; echo "rc=$?" | tee -a $L
+echo "== dispatcher placement probe" | tee -a $L
+[ -x scripts/probes/build/dispatch_rate ] && timeout -k 10 120 scripts/probes/build/dispatch_rate > gpurun_out/r2_dispatch_placement.txt 2>&1; echo "rc=$?" | tee -a $L
+kill $ALIVE
+grep -E "^== |^rc=|passed|failed|^E  |s call" $L | cut -c1-300 | tail -30
