@@ -363,6 +363,8 @@ int mojo_hip_peer_export(void* ptr, void* handle_out);
 int mojo_hip_peer_open(const void* handle, void** ptr_out);
 int mojo_hip_peer_close(void* ptr);
 int mojo_hip_peer_error(void* local_flags, int clear, int32_t* error_out);
+/* set-up check: `bytes` of a peer's buffer (opened mapping) copied to host memory by the runtime; synchronises */
+int mojo_hip_peer_peek(const void* peer_ptr, void* host_out, int64_t bytes);
 int mojo_hip_peer_signal(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
                          int kind, int64_t chunk, uint32_t epoch, mojo_stream_t stream);
 int mojo_hip_peer_reduce(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,

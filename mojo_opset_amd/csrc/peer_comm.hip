@@ -296,6 +296,15 @@ extern "C" int mojo_hip_peer_close(void* ptr) {
   return MOJO_OK;
 }
 
+// Reads `bytes` of a peer's buffer (an opened mapping, or the own allocation) into host memory with a plain runtime copy:
+// the set-up check that an opened mapping really shows the peer's memory.  Synchronises.
+extern "C" int mojo_hip_peer_peek(const void* peer_ptr, void* host_out, int64_t bytes) {
+  MOJO_REQUIRE(peer_ptr && host_out && bytes >= 0, MOJO_EINVAL, "peer_peek: bad argument");
+  hipError_t e = hipMemcpy(host_out, peer_ptr, static_cast<size_t>(bytes), hipMemcpyDeviceToHost);
+  MOJO_REQUIRE(e == hipSuccess, MOJO_ELAUNCH, "peer_peek: %s", hipGetErrorString(e));
+  return MOJO_OK;
+}
+
 // Reads (and optionally clears) the sticky error word of this rank's control area.  Synchronises the device.
 extern "C" int mojo_hip_peer_error(void* local_flags, int clear, int32_t* error_out) {
   MOJO_REQUIRE(local_flags && error_out, MOJO_EINVAL, "peer_error: null pointer");
