@@ -357,6 +357,8 @@ __global__ __launch_bounds__(128) void mla_merge_kernel(MlaArgs a, int R) {
   const int tile = blockIdx.x, head = blockIdx.y;
   const int d0 = threadIdx.x * 4;
   if (d0 >= R) return;
+  // prefill: tokens no sequence owns were skipped by the attention launch (no partials written); their rows stay zero
+  if (a.cu_q && (tile < a.cu_q[0] || tile >= a.cu_q[a.batch])) return;
   float M = -INFINITY;
   for (int sp = 0; sp < a.n_splits; ++sp) M = fmaxf(M, a.part_ml[((static_cast<int64_t>(tile) * a.n_splits + sp) * a.heads + head) * 2]);
   float sk = 0.f;

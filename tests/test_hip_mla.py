@@ -188,6 +188,26 @@ def test_mla_prefill_reference_space(cfg, sink):
     check_mla(to_cpu(got_abs), want, exact, "absorbed")
 
 
+def test_mla_prefill_absorbed_route_padding_rows_stay_zero(monkeypatch):
+    """Few query tokens over long cached prefixes: the absorbed route cuts the keys into splits, and the merge launch must
+    skip the tokens no sequence owns (nothing wrote their partials) — the golden returns zeros there."""
+    h, nope, rope, vd, r, page = 128, 128, 64, 128, 512, 16
+    q_lens, cached = [3, 5], [2500, 1200]
+    kv_lens = [a + b for a, b in zip(q_lens, cached)]
+    g = torch.Generator().manual_seed(12)
+    ckv, kpe, table, w, _ = make_mla(kv_lens, h, nope, rope, vd, r, page, seed=21, wscale=0.05)
+    q = torch.randn(sum(q_lens) + 6, h, nope + rope, generator=g).to(torch.bfloat16)      # 6 padding tokens
+    op = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, False, w, None, DEV, is_causal=True)
+    ref = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, False, w, None, "cpu", is_causal=True)
+    monkeypatch.setenv("MOJO_HIP_MLA_PREFILL", "absorbed")
+    got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
+    want = ref(q, ckv, kpe, cu(q_lens), table, cu_total_seq_lens=cu(kv_lens))
+    n = sum(q_lens)
+    assert torch.count_nonzero(got[n:]) == 0 and torch.count_nonzero(want[n:]) == 0
+    exact = exact_mla(q[:n], ckv, kpe, table, w, None, h, nope, rope, vd, r, kv_lens, q_off=cu(q_lens).tolist())
+    check_mla(got[:n], want[:n], exact, "absorbed")
+
+
 def test_mla_uncast_module_raises_like_the_golden():
     ckv, kpe, table, w, _ = make_mla([20], 8, 64, 32, 64, 32, 16)
     op = hip_cls("MojoPagedDecodeMLA")(8, 64, 32, 64, 32).to(DEV)          # kv_b_proj stays fp32 (reference quirk)
