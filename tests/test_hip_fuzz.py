@@ -1,0 +1,144 @@
+"""Seeded random configurations of the paged attention operators against the oracle: shapes, page sizes, head groupings,
+ragged / zero lengths, holes (-1) in the block tables, layouts and dtypes drawn at random.  The fixed cases elsewhere pin
+the reference's own parameter sets; this sweep looks for a combination nobody wrote down."""
+import math
+import random
+
+import pytest
+import torch
+
+from hip_utils import DEV, assert_close_tree, hip_cls, to_cpu, torch_cls
+from test_hip_decode_gqa import make_decode_inputs
+from test_hip_mla import build, check_mla, cu, exact_mla, make_mla, prefill_route
+from test_hip_prefill_gqa import make_prefill_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_decode_gqa(seed):
+    rnd = random.Random(1000 + seed)
+    hkv = rnd.choice([1, 2, 4, 8])
+    g = rnd.choice([1, 2, 4, 8])
+    d = rnd.choice([64, 96, 128])
+    page = rnd.choice([16, 32, 64, 128])
+    batch = rnd.choice([1, 2, 3, 5, 8, 17, 64])
+    max_len = rnd.choice([40, 300, 1100, 2500])
+    lens = [rnd.choice([0, 1, rnd.randint(1, max_len), max_len]) for _ in range(batch)]
+    dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+    layout = rnd.choice(["ABAB", "AABB"])
+    q, k, v, lens_t, table = make_decode_inputs(batch, hkv * g, hkv, d, max_len, page, dtype=dtype, seed=seed, lens=lens)
+    if rnd.random() < 0.4 and table.shape[1] > 2:                       # a hole: the golden stops at the first negative id
+        b = rnd.randrange(batch)
+        table[b, rnd.randrange(1, table.shape[1])] = -1
+    op = hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    ref = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    scale = 1.0 / math.sqrt(d)
+    want = ref(q, k, v, lens_t, table, softmax_scale=scale)
+    got = op(*[t.to(DEV) for t in (q, k, v, lens_t, table)], softmax_scale=scale)
+    assert_close_tree(to_cpu(got), want, 2e-2, 2e-2)
+    hinted = op(*[t.to(DEV) for t in (q, k, v, lens_t, table)], softmax_scale=scale, max_total_seq_len=max(max(lens), 1))
+    assert_close_tree(to_cpu(hinted), want, 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_prefill_gqa(seed):
+    rnd = random.Random(2000 + seed)
+    hkv = rnd.choice([1, 2, 4, 8])
+    g = rnd.choice([1, 2, 4, 8])
+    d = rnd.choice([64, 96, 128])
+    page = rnd.choice([16, 32, 64, 128])
+    batch = rnd.choice([1, 2, 3, 4, 7])
+    q_lens = [rnd.choice([0, 1, rnd.randint(1, 300), rnd.randint(100, 700)]) for _ in range(batch)]
+    cached = [rnd.choice([0, 0, rnd.randint(1, 500)]) for _ in range(batch)]
+    pad = rnd.choice([0, 0, 3, 40])
+    dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+    layout = rnd.choice(["ABAB", "AABB"])
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hkv * g, hkv, d, page, dtype=dtype, seed=seed, pad_tokens=pad)
+    op = hip_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout=layout)
+    ref = torch_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout=layout)
+    kw = {} if cu_kv is None else {"cu_total_seq_lens": cu_kv}
+    want = ref(q, k, v, cu_q, table, **kw)
+    dkw = {k_: v_.to(DEV) for k_, v_ in kw.items()}
+    got = to_cpu(op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), **dkw))
+    assert_close_tree(got, want, 2e-2, 2e-2)
+    if pad:
+        assert torch.count_nonzero(got[sum(q_lens):]) == 0
+    if rnd.random() < 0.5:                                              # with the host hints: same bits
+        got2 = to_cpu(op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), max_q_len=max(q_lens + [0]),
+                         max_total_seq_len=max(kv_lens + [0]), **dkw))
+        assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_mla(seed):
+    rnd = random.Random(3000 + seed)
+    nope, rope, vd, r = rnd.choice([(128, 64, 128, 512), (64, 32, 64, 32), (96, 32, 128, 64)])
+    h = rnd.choice([8, 16, 40, 128] if r == 512 else [8, 16])
+    page = rnd.choice([16, 32, 64])
+    sink = rnd.random() < 0.5
+    batch = rnd.choice([1, 2, 3, 6])
+    wscale = 0.05 if r == 512 else 0.2
+    if rnd.random() < 0.5:                                              # decode
+        lens = [rnd.choice([0, 1, rnd.randint(1, 700), rnd.randint(200, 1500)]) for _ in range(batch)]
+        ckv, kpe, table, w, sk = make_mla(lens, h, nope, rope, vd, r, page, sink, seed=seed, wscale=wscale)
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(batch, h, nope + rope, generator=g).to(torch.bfloat16)
+        lens_t = torch.tensor(lens, dtype=torch.int32)
+        ref = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, "cpu")
+        op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, DEV)
+        got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV)))
+        check_mla(got, ref(q, ckv, kpe, lens_t, table), exact_mla(q, ckv, kpe, table, w, sk, h, nope, rope, vd, r, lens))
+    else:                                                               # prefill
+        kv_lens = [rnd.choice([0, rnd.randint(1, 200), rnd.randint(100, 600)]) for _ in range(batch)]
+        q_lens = [min(n, rnd.choice([1, 7, 40, 130])) for n in kv_lens]
+        ckv, kpe, table, w, sk = make_mla(kv_lens, h, nope, rope, vd, r, page, sink, seed=seed, wscale=wscale)
+        g = torch.Generator().manual_seed(seed)
+        q = torch.randn(sum(q_lens), h, nope + rope, generator=g).to(torch.bfloat16)
+        ref = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, sink, w, sk, "cpu", is_causal=True)
+        op = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, sink, w, sk, DEV, is_causal=True)
+        want = ref(q, ckv, kpe, cu(q_lens), table, cu_total_seq_lens=cu(kv_lens))
+        got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
+        exact = exact_mla(q, ckv, kpe, table, w, sk, h, nope, rope, vd, r, kv_lens, q_off=cu(q_lens).tolist())
+        check_mla(got, want, exact, prefill_route(h, nope, rope, vd, q.shape[0]))
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_group_gemm_exact(seed):
+    """Small-integer operands (every partial sum exact in fp32): random group splits with empty groups, K and N at the
+    kernels' alignment edges, both weight layouts, both 16-bit types — equality, element for element."""
+    rnd = random.Random(4000 + seed)
+    groups = rnd.choice([1, 2, 3, 8, 16])
+    k = rnd.choice([32, 64, 96, 128, 192, 320, 448, 512, 1024])
+    n = rnd.choice([8, 64, 72, 128, 264, 512, 1000])
+    counts = [rnd.choice([0, 1, 15, 16, 17, 64, 100, 255, 256, 257, 300, 700]) for _ in range(groups)]
+    if sum(counts) == 0:
+        counts[0] = 33
+    trans = rnd.random() < 0.5
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(-3, 4, (sum(counts), k), generator=g).to(dtype)
+    w = (torch.randint(-3, 4, (groups, n, k), generator=g) if trans else torch.randint(-3, 4, (groups, k, n), generator=g)).to(dtype)
+    gl = torch.tensor(counts, dtype=torch.int32)
+    want = torch_cls("MojoGroupGemm")(w.float(), trans)(x.float(), gl)
+    got = hip_cls("MojoGroupGemm")(w.to(DEV), trans)(x.to(DEV), gl.to(DEV))
+    assert torch.equal(to_cpu(got).float()[: sum(counts)], want.to(dtype).float())
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_quant_gemm_int8_exact(seed):
+    from test_hip_quant_gemm import _quantize, quant_gemm_formula
+    rnd = random.Random(5000 + seed)
+    m = rnd.choice([1, 2, 4, 5, 16, 31, 32, 33, 64, 100, 128, 129, 300, 513])
+    k = rnd.choice([48, 64, 128, 256, 272, 512, 1024, 1536, 4096])
+    n = rnd.choice([3, 10, 64, 128, 192, 256, 1000, 4096])
+    trans = rnd.random() < 0.5
+    odt = rnd.choice([torch.bfloat16, torch.float16, torch.float32])
+    torch.manual_seed(seed)
+    xq, xs = _quantize(torch.randn(m, k))
+    wq, ws = _quantize(torch.randn(n, k))
+    op = hip_cls("MojoQuantGemm")(in_features=k, out_features=n, output_dtype=odt, trans_weight=trans, device=DEV)
+    op.weight.copy_(wq if trans else wq.t())
+    op.weight_scale.copy_(ws.to(torch.bfloat16))
+    out = to_cpu(op(xq.to(DEV), xs.to(DEV)))
+    torch.testing.assert_close(out, quant_gemm_formula(xq, wq.t(), xs, ws.to(torch.bfloat16), odt), atol=0, rtol=0)
