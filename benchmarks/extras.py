@@ -375,6 +375,32 @@ def bench_compute_comm(device, world, rank):
             else:
                 os.environ["MOJO_HIP_COMM_DIRECT"] = old
 
+    # The direct exchange has run on 2 ranks of one GPU only.  Its flag waits are bounded; a short bound here keeps a broken
+    # fabric path from eating the extras' deadline, and once ANY rank has seen it fail every rank stops timing it (the ranks
+    # agree through a max-reduce, so they keep making the same collective calls).
+    os.environ.setdefault("MOJO_HIP_PEER_TIMEOUT_MS", "3000")
+    direct_state = {"off": False}
+
+    def direct_variant(fn):
+        """(seconds | None, error | None) of one direct-exchange case, identical verdict on every rank."""
+        import torch.distributed as dist
+        if direct_state["off"]:
+            return None, "skipped: the direct exchange failed in an earlier case"
+        err, t = None, None
+        try:
+            t = with_direct("1", fn)
+            from mojo_opset_amd.comm import peer
+            for ex in peer._CACHE.values():
+                ex.check()
+        except Exception as e:
+            err = repr(e)
+        bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()):
+            direct_state["off"] = True
+            return None, err or "failed on another rank"
+        return t, None
+
     for k_total, n in ((28672, 8192), (8192, 8192)):
         kl = k_total // world
         w = torch.randn(kl, n, device=device, dtype=dt) * 0.02
@@ -393,15 +419,13 @@ def bench_compute_comm(device, world, rank):
                 phases = 2 if name == "gemm_allreduce" else 1
                 for variant in (("rccl", "direct") if world > 1 else ("rccl",)):
                     key = f"{name}_M{m}_K{k_total}_N{n}_tp{world}" + ("" if world == 1 else f"_{variant}")
-                    try:
-                        t = with_direct("1" if variant == "direct" else "0", lambda: timed(lambda: op(x)))
-                        if variant == "direct":
-                            from mojo_opset_amd.comm import peer
-                            for ex in peer._CACHE.values():
-                                ex.check()
-                    except Exception as e:          # the direct exchange has never run on a multi-GPU node: report, keep going
-                        out[key] = {"error": repr(e)}
-                        continue
+                    if variant == "direct":
+                        t, err = direct_variant(lambda: timed(lambda: op(x)))
+                        if err:
+                            out[key] = {"error": err}
+                            continue
+                    else:
+                        t = with_direct("0", lambda: timed(lambda: op(x)))
                     rec = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k_total * n / t / 1e12, "local_gemm_us": t_local * 1e6,
                            "exposed_exchange_us": max(t - t_local, 0.0) * 1e6, "payload_MB_per_rank": payload / 1e6}
                     if world > 1:
@@ -431,15 +455,13 @@ def bench_compute_comm(device, world, rank):
                 del xfull
             for variant in (("rccl", "direct") if world > 1 else ("rccl",)):
                 key = f"allgather_gemm_M{m}_K{k2}_N{n_total}_tp{world}" + ("" if world == 1 else f"_{variant}")
-                try:
-                    t = with_direct("1" if variant == "direct" else "0", lambda: timed(lambda: op(xs)))
-                    if variant == "direct":
-                        from mojo_opset_amd.comm import peer
-                        for ex in peer._CACHE.values():
-                            ex.check()
-                except Exception as e:
-                    out[key] = {"error": repr(e)}
-                    continue
+                if variant == "direct":
+                    t, err = direct_variant(lambda: timed(lambda: op(xs)))
+                    if err:
+                        out[key] = {"error": err}
+                        continue
+                else:
+                    t = with_direct("0", lambda: timed(lambda: op(xs)))
                 rec = {"us": t * 1e6, "aggregate_tflops": 2.0 * m * k2 * n_total / t / 1e12}
                 if world > 1:
                     gathered = (world - 1) * (m // world) * k2 * 2
