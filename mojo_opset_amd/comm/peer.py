@@ -72,14 +72,25 @@ class PeerExchange:
             raise RuntimeError("peer buffers: ranks disagree on the buffer size (every rank must make the same calls)")
         self._bases: List[int] = []
         self._opened: List[ctypes.c_void_p] = []
+        failure = None
         for r, (h, _pid, _sz) in enumerate(everyone):
             if r == self.rank:
                 self._bases.append(self._local.value)
                 continue
             p = ctypes.c_void_p()
-            L.check(lib.mojo_hip_peer_open(ctypes.create_string_buffer(h, len(h)), ctypes.byref(p)), f"opening rank {r}'s peer buffer")
+            try:
+                L.check(lib.mojo_hip_peer_open(ctypes.create_string_buffer(h, len(h)), ctypes.byref(p)), f"opening rank {r}'s peer buffer")
+            except Exception as e:          # keep going: the ranks must reach the next collective together
+                failure = failure or repr(e)
+                self._bases.append(0)
+                continue
             self._opened.append(p)
             self._bases.append(p.value)
+        failures: List[Optional[str]] = [None] * self.ws
+        dist.all_gather_object(failures, failure, group=group)
+        if any(failures):
+            self.close()
+            raise RuntimeError(f"peer buffers: a rank could not open a peer's buffer (per rank: {failures})")
         self._flag_off = 2 * self.capacity + 4096
         self._data = _ptr_array(self._bases)
         self._flags = _ptr_array([b + self._flag_off for b in self._bases])
