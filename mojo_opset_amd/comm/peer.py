@@ -52,28 +52,35 @@ class PeerExchange:
         self.max_chunks = int(lib.mojo_hip_peer_max_chunks())
         total = 2 * self.capacity + 4096 + self.ctrl_bytes
         self._local = ctypes.c_void_p()
+        self._opened: List[ctypes.c_void_p] = []
         uncached = os.environ.get("MOJO_HIP_PEER_UNCACHED", "1") != "0"
         handle = (ctypes.c_char * int(lib.mojo_hip_peer_handle_bytes()))()
-        for attempt in ((1, 0) if uncached else (0,)):
-            L.check(lib.mojo_hip_peer_alloc(ctypes.byref(self._local), total, attempt), "peer buffer allocation")
-            rc = lib.mojo_hip_peer_export(self._local, handle)
-            if rc == 0:
-                self.uncached = bool(attempt)
-                break
-            lib.mojo_hip_peer_free(self._local)
-            self._local = ctypes.c_void_p()
-            if attempt == 0:
-                L.check(rc, "peer buffer export")
+        setup_error = None
+        try:
+            for attempt in ((1, 0) if uncached else (0,)):
+                L.check(lib.mojo_hip_peer_alloc(ctypes.byref(self._local), total, attempt), "peer buffer allocation")
+                rc = lib.mojo_hip_peer_export(self._local, handle)
+                if rc == 0:
+                    self.uncached = bool(attempt)
+                    break
+                lib.mojo_hip_peer_free(self._local)
+                self._local = ctypes.c_void_p()
+                if attempt == 0:
+                    L.check(rc, "peer buffer export")
+        except Exception as e:              # reported to every rank below: nobody may be left waiting in a collective
+            setup_error = repr(e)
         # exchange (handle, pid): a rank must not IPC-open its own allocation
-        mine = (bytes(handle), os.getpid(), total)
+        mine = (bytes(handle), os.getpid(), total, setup_error)
         everyone: List[Optional[tuple]] = [None] * self.ws
         dist.all_gather_object(everyone, mine, group=group)
+        if any(e[3] for e in everyone):
+            self.close()
+            raise RuntimeError(f"peer buffers: allocation / export failed (per rank: {[e[3] for e in everyone]})")
         if any(e[2] != total for e in everyone):
             raise RuntimeError("peer buffers: ranks disagree on the buffer size (every rank must make the same calls)")
         self._bases: List[int] = []
-        self._opened: List[ctypes.c_void_p] = []
         failure = None
-        for r, (h, _pid, _sz) in enumerate(everyone):
+        for r, (h, _pid, _sz, _err) in enumerate(everyone):
             if r == self.rank:
                 self._bases.append(self._local.value)
                 continue
