@@ -517,6 +517,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     if (lane == 30) g_gemm_stamps[(bid * 8 + wave) * 32 + 30] = static_cast<unsigned>(__builtin_amdgcn_s_memrealtime());
   }
 #endif
+  // Wait states between the K loop's last MFMA and the first instruction that reads an accumulator.  hipcc places them for the
+  // MFMAs it emits itself; the fp8 policy issues its MFMA from inline asm, which the hazard recogniser cannot see into, and a
+  // first read that follows a branch can go unprotected even for emitted ones (found in the MLA latent kernels).
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
   if constexpr (PERSIST) {
     // ---- persistent form: request the next tile, then write this one out through the wave's own staging area ----------
     static_assert(Epi::kRowStaged, "the persistent form has the row-staged epilogue only");
