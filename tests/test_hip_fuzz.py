@@ -13,11 +13,14 @@ from test_hip_mla import build, check_mla, cu, exact_mla, make_mla, prefill_rout
 from test_hip_prefill_gqa import make_prefill_inputs
 
 pytestmark = pytest.mark.gpu
+# MOJO_FUZZ_OFFSET=<n> shifts every seed: a soak run walks offsets 1, 2, ... (the suite itself runs offset 0)
+import os
+OFFSET = 1000 * int(os.environ.get("MOJO_FUZZ_OFFSET", "0"))
 
 
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_decode_gqa(seed):
-    rnd = random.Random(1000 + seed)
+    rnd = random.Random(1000 + seed + OFFSET)
     hkv = rnd.choice([1, 2, 4, 8])
     g = rnd.choice([1, 2, 4, 8])
     d = rnd.choice([64, 96, 128])
@@ -27,7 +30,7 @@ def test_fuzz_decode_gqa(seed):
     lens = [rnd.choice([0, 1, rnd.randint(1, max_len), max_len]) for _ in range(batch)]
     dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16])
     layout = rnd.choice(["ABAB", "AABB"])
-    q, k, v, lens_t, table = make_decode_inputs(batch, hkv * g, hkv, d, max_len, page, dtype=dtype, seed=seed, lens=lens)
+    q, k, v, lens_t, table = make_decode_inputs(batch, hkv * g, hkv, d, max_len, page, dtype=dtype, seed=seed + OFFSET, lens=lens)
     if rnd.random() < 0.4 and table.shape[1] > 2:                       # a hole: the golden stops at the first negative id
         b = rnd.randrange(batch)
         table[b, rnd.randrange(1, table.shape[1])] = -1
@@ -43,7 +46,7 @@ def test_fuzz_decode_gqa(seed):
 
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_prefill_gqa(seed):
-    rnd = random.Random(2000 + seed)
+    rnd = random.Random(2000 + seed + OFFSET)
     hkv = rnd.choice([1, 2, 4, 8])
     g = rnd.choice([1, 2, 4, 8])
     d = rnd.choice([64, 96, 128])
@@ -54,7 +57,7 @@ def test_fuzz_prefill_gqa(seed):
     pad = rnd.choice([0, 0, 3, 40])
     dtype = rnd.choice([torch.bfloat16, torch.bfloat16, torch.float16])
     layout = rnd.choice(["ABAB", "AABB"])
-    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hkv * g, hkv, d, page, dtype=dtype, seed=seed, pad_tokens=pad)
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hkv * g, hkv, d, page, dtype=dtype, seed=seed + OFFSET, pad_tokens=pad)
     op = hip_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout=layout)
     ref = torch_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout=layout)
     kw = {} if cu_kv is None else {"cu_total_seq_lens": cu_kv}
@@ -72,7 +75,7 @@ def test_fuzz_prefill_gqa(seed):
 
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_mla(seed):
-    rnd = random.Random(3000 + seed)
+    rnd = random.Random(3000 + seed + OFFSET)
     nope, rope, vd, r = rnd.choice([(128, 64, 128, 512), (64, 32, 64, 32), (96, 32, 128, 64)])
     h = rnd.choice([8, 16, 40, 128] if r == 512 else [8, 16])
     page = rnd.choice([16, 32, 64])
@@ -107,7 +110,7 @@ def test_fuzz_mla(seed):
 def test_fuzz_group_gemm_exact(seed):
     """Small-integer operands (every partial sum exact in fp32): random group splits with empty groups, K and N at the
     kernels' alignment edges, both weight layouts, both 16-bit types — equality, element for element."""
-    rnd = random.Random(4000 + seed)
+    rnd = random.Random(4000 + seed + OFFSET)
     groups = rnd.choice([1, 2, 3, 8, 16])
     k = rnd.choice([32, 64, 96, 128, 192, 320, 448, 512, 1024])
     n = rnd.choice([8, 64, 72, 128, 264, 512, 1000])
@@ -128,7 +131,7 @@ def test_fuzz_group_gemm_exact(seed):
 @pytest.mark.parametrize("seed", range(20))
 def test_fuzz_quant_gemm_int8_exact(seed):
     from test_hip_quant_gemm import _quantize, quant_gemm_formula
-    rnd = random.Random(5000 + seed)
+    rnd = random.Random(5000 + seed + OFFSET)
     m = rnd.choice([1, 2, 4, 5, 16, 31, 32, 33, 64, 100, 128, 129, 300, 513])
     k = rnd.choice([48, 64, 128, 256, 272, 512, 1024, 1536, 4096])
     n = rnd.choice([3, 10, 64, 128, 192, 256, 1000, 4096])
@@ -148,7 +151,7 @@ def test_fuzz_quant_gemm_int8_exact(seed):
 def test_fuzz_store_paged_kv_bit_exact(seed):
     from conftest import bit_equal
     from test_hip_streaming import _store_case
-    rnd = random.Random(6000 + seed)
+    rnd = random.Random(6000 + seed + OFFSET)
     batch = rnd.choice([1, 2, 5, 9])
     page = rnd.choice([8, 16, 64, 128, 1024])
     seqs = [(rnd.choice([-1, 0, 0, rnd.randint(1, 3 * page)]), rnd.choice([0, 1, rnd.randint(1, 2 * page + 5)])) for _ in range(batch)]
@@ -165,7 +168,7 @@ def test_fuzz_store_paged_kv_bit_exact(seed):
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_norm_and_swiglu(seed):
     from hip_utils import max_ulp_bf16ish
-    rnd = random.Random(7000 + seed)
+    rnd = random.Random(7000 + seed + OFFSET)
     rows = rnd.choice([1, 2, 7, 57, 64, 300, 2048])
     d = rnd.choice([8, 64, 256, 1000, 1024, 4096, 7338, 8192])
     dtype = rnd.choice([torch.bfloat16, torch.float16, torch.float32])
