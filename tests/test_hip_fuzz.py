@@ -193,3 +193,54 @@ def test_fuzz_norm_and_swiglu(seed):
         # rounding boundary (fp32 evaluation differing in the last bits) moves the product by one unit, two after its own
         # rounding — seen on fp16 with its 10-bit mantissa, never on bf16
         assert max_ulp_bf16ish(got, want) <= (1 if dtype == torch.bfloat16 else 2)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_moe_dispatch_combine(seed):
+    from test_hip_moe import _check_buckets
+    rnd = random.Random(8000 + seed + OFFSET)
+    experts = rnd.choice([2, 3, 8, 16, 60, 256])
+    k = rnd.choice([1, 2, 4, 8])
+    k = min(k, experts)
+    hidden = rnd.choice([8, 100, 512, 1024, 4096])
+    tokens = rnd.choice([1, 7, 64, 300, 2048])
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    g = torch.Generator().manual_seed(seed + OFFSET)
+    x = torch.rand(tokens, hidden, generator=g).to(dtype)
+    probs = torch.softmax(torch.randn(tokens, experts, generator=g), dim=-1)
+    gates, ids = torch.topk(probs, k, dim=-1)
+    gates = (gates / gates.sum(-1, keepdim=True)).contiguous()
+    ids = ids.to(torch.int32).contiguous()
+    op = hip_cls("MojoMoEDispatch")(num_experts=experts)
+    out = to_cpu(op(x.to(DEV), gates.to(DEV), ids.to(DEV)))
+    want = torch_cls("MojoMoEDispatch")(num_experts=experts)(x, gates, ids)
+    assert torch.equal(out[1], want[1])                                   # rows per expert
+    _check_buckets(*out, x, gates, ids)
+    # combine: bit-exact against the oracle on the oracle's own dispatch output
+    by_gates = rnd.random() < 0.5
+    buf = torch.zeros(tokens, hidden, dtype=dtype)
+    rows, per_expert, sgates, tok = want
+    cw = torch_cls("MojoMoECombine")(multiply_by_gates=by_gates)(buf.clone(), rows, sgates, tok)
+    cg = hip_cls("MojoMoECombine")(multiply_by_gates=by_gates)(buf.to(DEV), rows.to(DEV), sgates.to(DEV), tok.to(DEV))
+    assert torch.equal(to_cpu(cg), cw)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_dynamic_quant_bit_exact(seed):
+    from conftest import bit_equal
+    rnd = random.Random(9000 + seed + OFFSET)
+    rows = rnd.choice([1, 3, 64, 257, 4096])
+    d = rnd.choice([8, 128, 1000, 4096, 7168])
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    smooth = rnd.random() < 0.5
+    g = torch.Generator().manual_seed(seed + OFFSET)
+    x = (torch.randn(rows, d, generator=g) * rnd.choice([0.01, 1.0, 30.0])).to(dtype)
+    op = hip_cls("MojoDynamicQuant")(input_size=d if smooth else None)
+    ref = torch_cls("MojoDynamicQuant")(input_size=d if smooth else None)
+    if smooth:
+        w = torch.rand(d, generator=g) + 0.5
+        with torch.no_grad():
+            ref.inv_smooth_scale.copy_(w)
+            op.inv_smooth_scale.copy_(w)
+        op = op.to(DEV)
+    assert bit_equal(to_cpu(op(x.to(DEV))), ref(x))
