@@ -542,6 +542,77 @@ def bench_moe(device):
     return out
 
 
+def bench_decode_layer(device):
+    """One whole Llama-3-8B decoder layer at decode (B = 64, ctx = 4096, bf16) as ONE captured graph of the operators of this
+    package: residual-add RMSNorm -> QKV projection -> RoPE -> paged KV store -> paged decode attention -> output projection ->
+    residual-add RMSNorm -> gate|up projection -> SwiGLU -> down projection.  Reported next to the sum of its memory traffic:
+    what the per-operator numbers add up to once launch gaps and host work are out of the way."""
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm as _ENGINE
+    hq, hkv, d, page, bsz, ctx, hidden, inter = 32, 8, 128, 16, 64, 4096, 4096, 14336
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(20260716)
+    lens = [ctx] * bsz
+    k_cache, v_cache, table = _paged(device, [ctx + page] * bsz, hkv, d, page)
+    w_qkv = torch.randn((hq + 2 * hkv) * d, hidden, device=device, dtype=dt) * 0.02          # [N, K]
+    w_o = torch.randn(hidden, hq * d, device=device, dtype=dt) * 0.02
+    w_gu = torch.randn(2 * inter, hidden, device=device, dtype=dt) * 0.02
+    w_dn = torch.randn(hidden, inter, device=device, dtype=dt) * 0.02
+    x = torch.randn(bsz, hidden, device=device, dtype=dt)
+    resid = torch.randn(bsz, hidden, device=device, dtype=dt)
+    cos, sin = torch.randn(bsz, d, device=device), torch.randn(bsz, d, device=device)
+    ctx_t = torch.tensor(lens, dtype=torch.int32, device=device)
+    total_t = ctx_t + 1
+    norm1 = hip("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=device)
+    norm2 = hip("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=device)
+    rope, store, attn, act = hip("MojoApplyRoPE")(), hip("MojoStorePagedKVCache")(), hip("MojoPagedDecodeGQA")(is_causal=True, gqa_layout="AABB"), hip("MojoSwiGLU")()
+
+    def layer():
+        h, r1 = norm1(x, resid)
+        qkv = _ENGINE(h, w_qkv, None, False)
+        q = qkv[:, : hq * d].reshape(bsz, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].reshape(bsz, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].reshape(bsz, hkv, d).contiguous()
+        q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
+        store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, None, ctx_t)
+        o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1)
+        a = _ENGINE(o.reshape(bsz, hq * d), w_o, None, False)
+        h2, r2 = norm2(a, r1)
+        gu = _ENGINE(h2, w_gu, None, False)
+        m = act(gu[:, :inter].contiguous(), gu[:, inter:].contiguous())
+        return _ENGINE(m, w_dn, None, False), r2
+
+    t = _time_graph(layer, reps=4, replays=5)
+    # the same operators one at a time (each under graph replay on its own): their sum against the whole layer shows what
+    # chaining costs (cold weights: each GEMM's 0.1 - 0.2 GB of weights is evicted from the 256 MB MALL by the next one)
+    h, r1 = norm1(x, resid)
+    qkv = _ENGINE(h, w_qkv, None, False)
+    q = qkv[:, : hq * d].reshape(bsz, hq, d).contiguous()
+    k = qkv[:, hq * d: (hq + hkv) * d].reshape(bsz, hkv, d).contiguous()
+    v = qkv[:, (hq + hkv) * d:].reshape(bsz, hkv, d).contiguous()
+    o = attn(q, k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1).reshape(bsz, hq * d)
+    gu = _ENGINE(h, w_gu, None, False)
+    gate, up = gu[:, :inter].contiguous(), gu[:, inter:].contiguous()
+    m = act(gate, up)
+    parts = {
+        "norm_x2": 2 * _time_graph(lambda: norm1(x, resid)),
+        "qkv_gemm": _time_graph(lambda: _ENGINE(h, w_qkv, None, False)),
+        "rope": _time_graph(lambda: rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)),
+        "kv_store": _time_graph(lambda: store(k, v, k_cache, v_cache, table, None, ctx_t)),
+        "attention": _time_graph(lambda: attn(q, k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1), reps=4),
+        "o_gemm": _time_graph(lambda: _ENGINE(o, w_o, None, False)),
+        "gate_up_gemm": _time_graph(lambda: _ENGINE(h, w_gu, None, False), reps=4),
+        "swiglu": _time_graph(lambda: act(gate, up)),
+        "down_gemm": _time_graph(lambda: _ENGINE(m, w_dn, None, False), reps=4),
+    }
+    weights = (w_qkv.numel() + w_o.numel() + w_gu.numel() + w_dn.numel()) * 2
+    kv = sum(lens) * hkv * d * 2 * 2
+    res = _hbm(t, weights + kv)
+    res.update({"weights_MB": weights / 1e6, "kv_MB": kv / 1e6, "tokens_per_s_one_layer": bsz / t,
+                "per_op_us": {n: v * 1e6 for n, v in parts.items()}, "sum_of_ops_us": sum(parts.values()) * 1e6,
+                "note": "graph replay; bytes = the layer's weights + the K/V the attention reads (activations are noise at B = 64)"})
+    return {"llama3_8b_layer_B64_ctx4096": res}
+
+
 def bench_dense_decode(device):
     """Decode-sized dense bf16 GEMMs with K-major ([N,K], `F.linear`) weights — the GEMM half of the GEMM+collective ops at
     decode batch sizes; timed under HIP-graph replay (the Python shim's launch overhead would hide the kernel)."""
@@ -563,7 +634,7 @@ def run_extras(device, world, rank=0):
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
                      ("MojoPagedPrefillMLA_bf16", bench_mla_prefill),
                      ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),
-                     ("dense_gemm_decode_bf16", bench_dense_decode)):
+                     ("dense_gemm_decode_bf16", bench_dense_decode), ("decode_layer_bf16", bench_decode_layer)):
         try:
             out[name] = fn(device)
         except Exception as e:  # one failing extra must not hide the others
