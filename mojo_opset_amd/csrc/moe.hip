@@ -298,39 +298,75 @@ __global__ __launch_bounds__(256) void moe_hist_kernel(const int32_t* __restrict
   for (int e = threadIdx.x; e < experts; e += 256) block_hist[static_cast<int64_t>(blockIdx.x) * experts + e] = s_hist[e];
 }
 
-// one block: per expert, exclusive prefix over the blocks (in place), totals -> tokens_per_expert, exclusive scan -> start
-__global__ __launch_bounds__(256) void moe_scan_kernel(int32_t* __restrict__ block_hist, int blocks, int experts,
-                                                       int32_t* __restrict__ tokens_per_expert, int32_t* __restrict__ expert_start) {
-  __shared__ int s_part[256];
-  for (int e = threadIdx.x; e < experts; e += 256) {
-    int run = 0;
-    for (int b = 0; b < blocks; ++b) {
-      const int64_t at = static_cast<int64_t>(b) * experts + e;
-      const int c = block_hist[at];
-      block_hist[at] = run;
-      run += c;
-    }
-    tokens_per_expert[e] = run;
+// Exclusive prefix of `v` over the threads of the block (<= 1024 threads), wave shuffles + one LDS word per wave.
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+__device__ __forceinline__ int block_excl_scan(int v, int* s_wave, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = static_cast<int>(blockDim.x >> 6);
+  const int inc = wave_incl_scan(v, lane);
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    const int c = s_wave[w];
+    base += w < wave ? c : 0;
+    tot += c;
   }
   __syncthreads();
-  // exclusive scan of tokens_per_expert: thread t owns the contiguous chunk [t*chunk, (t+1)*chunk)
-  const int chunk = (experts + 255) / 256;
+  if (total) *total = tot;
+  return base + inc - v;
+}
+
+// one block of 1024 threads: per expert, exclusive prefix over the blocks (in place), totals -> tokens_per_expert, exclusive
+// scan -> start.  One WAVE per expert walks the blocks 64 at a time (shuffle scan + carry), two experts per step so that
+// two loads are in flight; the first version had one THREAD per expert walking the blocks through dependent loads, and
+// thread 0 scanning 256 partial sums through LDS one by one (12.5 us for Mixtral's 64 x 8 counters, now ~3 us).
+__global__ __launch_bounds__(1024) void moe_scan_kernel(int32_t* __restrict__ block_hist, int blocks, int experts,
+                                                        int32_t* __restrict__ tokens_per_expert, int32_t* __restrict__ expert_start) {
+  __shared__ int s_tot[DISP_MAX_E];
+  __shared__ int s_wave[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e0 = 2 * wave; e0 < experts; e0 += 32) {
+    const int e1 = e0 + 1 < experts ? e0 + 1 : e0;
+    int carry0 = 0, carry1 = 0;
+    for (int base = 0; base < blocks; base += 64) {
+      const int blk = base + lane;
+      const bool live = blk < blocks;
+      const int64_t at0 = static_cast<int64_t>(blk) * experts + e0, at1 = static_cast<int64_t>(blk) * experts + e1;
+      const int c0 = live ? block_hist[at0] : 0;
+      const int c1 = live ? block_hist[at1] : 0;
+      const int i0 = wave_incl_scan(c0, lane), i1 = wave_incl_scan(c1, lane);
+      if (live) {
+        block_hist[at0] = carry0 + i0 - c0;
+        if (e1 != e0) block_hist[at1] = carry1 + i1 - c1;
+      }
+      carry0 += __builtin_amdgcn_readlane(i0, 63);
+      carry1 += __builtin_amdgcn_readlane(i1, 63);
+    }
+    if (lane == 0) {
+      s_tot[e0] = carry0;
+      tokens_per_expert[e0] = carry0;
+      if (e1 != e0) { s_tot[e1] = carry1; tokens_per_expert[e1] = carry1; }
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the totals: thread t owns the contiguous chunk [t*chunk, (t+1)*chunk)
+  const int chunk = (experts + 1023) / 1024;
   int local = 0;
   for (int j = 0; j < chunk; ++j) {
     const int e = threadIdx.x * chunk + j;
-    if (e < experts) local += tokens_per_expert[e];
+    if (e < experts) local += s_tot[e];
   }
-  s_part[threadIdx.x] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int t = 0; t < 256; ++t) { const int c = s_part[t]; s_part[t] = run; run += c; }
-  }
-  __syncthreads();
-  int run = s_part[threadIdx.x];
+  int run = block_excl_scan(local, s_wave, nullptr);
   for (int j = 0; j < chunk; ++j) {
     const int e = threadIdx.x * chunk + j;
-    if (e < experts) { expert_start[e] = run; run += tokens_per_expert[e]; }
+    if (e < experts) { expert_start[e] = run; run += s_tot[e]; }
   }
 }
 
@@ -383,7 +419,18 @@ __global__ __launch_bounds__(256) void moe_gather_rows_kernel(const T* __restric
   const bool wide = hidden_size % VEC == 0 && (reinterpret_cast<uintptr_t>(hidden) % 16 == 0) &&
                     (reinterpret_cast<uintptr_t>(sorted_hidden) % 16 == 0);
   if (wide) {
-    for (int c = lane * VEC; c < hidden_size; c += 64 * VEC) store_vec<T, VEC>(dst + c, load_vec<T, VEC>(src + c));
+    // four 16-byte loads in flight per lane before the first store (a load -> store loop left one in flight)
+    typedef typename vec_of<T, VEC>::type V;
+    constexpr int STEP = 64 * VEC;
+    int c = lane * VEC;
+    for (; c + 3 * STEP < hidden_size; c += 4 * STEP) {
+      V v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = load_vec<T, VEC>(src + c + u * STEP);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) store_vec<T, VEC>(dst + c + u * STEP, v[u]);
+    }
+    for (; c < hidden_size; c += STEP) store_vec<T, VEC>(dst + c, load_vec<T, VEC>(src + c));
   } else {
     for (int c = lane; c < hidden_size; c += 64) dst[c] = src[c];
   }
@@ -410,21 +457,60 @@ __global__ __launch_bounds__(256) void moe_count_kernel(const int32_t* __restric
 // exclusive scan of cnt[0..tokens) into start[0..tokens], one block of 1024 threads
 __global__ __launch_bounds__(1024) void moe_token_scan_kernel(const int32_t* __restrict__ cnt, int64_t tokens,
                                                               int32_t* __restrict__ start) {
-  __shared__ int s_part[1024];
+  __shared__ int s_wave[16];
   const int64_t chunk = (tokens + 1023) / 1024;
   const int64_t lo = threadIdx.x * chunk, hi = min(lo + chunk, tokens);
   int local = 0;
   for (int64_t t = lo; t < hi; ++t) local += cnt[t];
-  s_part[threadIdx.x] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int t = 0; t < 1024; ++t) { const int c = s_part[t]; s_part[t] = run; run += c; }
-  }
-  __syncthreads();
-  int run = s_part[threadIdx.x];
+  int run = block_excl_scan(local, s_wave, nullptr);
   for (int64_t t = lo; t < hi; ++t) { start[t] = run; run += cnt[t]; }
   if (threadIdx.x == 1023) start[tokens] = run;            // the last thread's chunk ends the array (empty chunks carry the total)
+}
+
+// The whole row-list plan of the combine in ONE single-block launch when the per-token counters fit LDS: count (LDS
+// atomics) -> exclusive scan -> fill (LDS cursors).  Replaces zero + count + scan + zero + fill (five launches, ~35 us
+// for 8192 tokens — more than the 30 us the combine itself takes; ~6 us now).  The order inside a token's list is the
+// order of the atomics, i.e. undefined, exactly as before: the combine kernel sorts each list by row id.
+constexpr int PLAN_MAX_TOKENS = 15 * 1024;
+__global__ __launch_bounds__(1024) void moe_token_plan_kernel(const int32_t* __restrict__ tok, int64_t n, int tokens,
+                                                              int32_t* __restrict__ start, int32_t* __restrict__ list) {
+  extern __shared__ int s_cnt[];                            // [tokens]: counters, then cursors
+  __shared__ int s_wave[16];
+  for (int t = threadIdx.x; t < tokens; t += 1024) s_cnt[t] = 0;
+  __syncthreads();
+  // (token ids are fetched eight per thread at a time: a load -> atomic loop waits out one memory round trip per row)
+  for (int64_t j0 = threadIdx.x; j0 < n; j0 += 8 * 1024) {
+    int t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = j0 + u * 1024 < n ? tok[j0 + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t[u] >= 0 && t[u] < tokens) atomicAdd(&s_cnt[t[u]], 1);
+  }
+  __syncthreads();
+  const int chunk = (tokens + 1023) / 1024;
+  const int lo = min(static_cast<int>(threadIdx.x) * chunk, tokens), hi = min(lo + chunk, tokens);
+  int local = 0;
+  for (int t = lo; t < hi; ++t) local += s_cnt[t];
+  int run = block_excl_scan(local, s_wave, nullptr);
+  for (int t = lo; t < hi; ++t) {
+    const int c = s_cnt[t];
+    s_cnt[t] = run;
+    start[t] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) start[tokens] = run;
+  __syncthreads();
+  for (int64_t j0 = threadIdx.x; j0 < n; j0 += 8 * 1024) {
+    int t[8], at[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = j0 + u * 1024 < n ? tok[j0 + u * 1024] : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) at[u] = (t[u] >= 0 && t[u] < tokens) ? atomicAdd(&s_cnt[t[u]], 1) : -1;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (at[u] >= 0) list[at[u]] = static_cast<int32_t>(j0 + u * 1024);
+  }
 }
 
 __global__ __launch_bounds__(256) void moe_fill_kernel(const int32_t* __restrict__ tok, int64_t n, int64_t tokens,
@@ -463,24 +549,49 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const T* __restrict__ 
   const bool wide = hidden_size % VEC == 0 && (reinterpret_cast<uintptr_t>(rows) % 16 == 0) && (reinterpret_cast<uintptr_t>(out) % 16 == 0);
   T* dst = out + t * hidden_size;
   if (wide) {
-    for (int c = threadIdx.x * VEC; c < hidden_size; c += 256 * VEC) {
-      float acc[VEC];
+    // two column chunks x two rows per step: four 16-byte loads in flight per lane; the sums keep the list order
+    constexpr int STEP = 256 * VEC;
+    for (int c = threadIdx.x * VEC; c < hidden_size; c += 2 * STEP) {
+      const bool two = c + STEP < hidden_size;
+      const int c1 = two ? c + STEP : c;
+      float acc[2][VEC];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-      for (int a = 0; a < n; ++a) {
-        const int id = sortable ? s_list[a] : list[s0 + a];
-        const V r = load_vec<T, VEC>(rows + static_cast<int64_t>(id) * hidden_size + c);
-        const float g = gates ? gates[id] : 1.f;
+      for (int q = 0; q < VEC; ++q) acc[0][q] = acc[1][q] = 0.f;
+      auto add = [&](const V& r, float g, float (&dst_acc)[VEC]) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
           const float f = elt<T>::to_f(vget<T, VEC>(r, q));
-          acc[q] = __fadd_rn(acc[q], gates ? __fmul_rn(f, g) : f);
+          dst_acc[q] = __fadd_rn(dst_acc[q], gates ? __fmul_rn(f, g) : f);
         }
+      };
+      int a = 0;
+      for (; a + 1 < n; a += 2) {
+        const int id0 = sortable ? s_list[a] : list[s0 + a];
+        const int id1 = sortable ? s_list[a + 1] : list[s0 + a + 1];
+        const T* p0 = rows + static_cast<int64_t>(id0) * hidden_size;
+        const T* p1 = rows + static_cast<int64_t>(id1) * hidden_size;
+        const V r00 = load_vec<T, VEC>(p0 + c), r01 = load_vec<T, VEC>(p0 + c1);
+        const V r10 = load_vec<T, VEC>(p1 + c), r11 = load_vec<T, VEC>(p1 + c1);
+        const float g0 = gates ? gates[id0] : 1.f, g1 = gates ? gates[id1] : 1.f;
+        add(r00, g0, acc[0]); add(r01, g0, acc[1]);
+        add(r10, g1, acc[0]); add(r11, g1, acc[1]);
+      }
+      if (a < n) {
+        const int id0 = sortable ? s_list[a] : list[s0 + a];
+        const T* p0 = rows + static_cast<int64_t>(id0) * hidden_size;
+        const V r00 = load_vec<T, VEC>(p0 + c), r01 = load_vec<T, VEC>(p0 + c1);
+        const float g0 = gates ? gates[id0] : 1.f;
+        add(r00, g0, acc[0]); add(r01, g0, acc[1]);
       }
       V o;
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) vset<T, VEC>(o, q, elt<T>::from_f(acc[q]));
+      for (int q = 0; q < VEC; ++q) vset<T, VEC>(o, q, elt<T>::from_f(acc[0][q]));
       store_vec<T, VEC>(dst + c, o);
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) vset<T, VEC>(o, q, elt<T>::from_f(acc[1][q]));
+        store_vec<T, VEC>(dst + c1, o);
+      }
     }
   } else {
     for (int c = threadIdx.x; c < hidden_size; c += 256) {
@@ -662,7 +773,7 @@ extern "C" int mojo_hip_moe_dispatch(const void* hidden, const float* top_k_gate
   int32_t* expert_start = block_hist + static_cast<int64_t>(blocks) * e;
   hipLaunchKernelGGL(moe_hist_kernel, dim3(blocks), dim3(256), e * sizeof(int), s, top_k_indices, n, e, block_hist);
   MOJO_CHECK_LAUNCH("moe_dispatch(hist)");
-  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(256), 0, s, block_hist, blocks, e, tokens_per_expert, expert_start);
+  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), 0, s, block_hist, blocks, e, tokens_per_expert, expert_start);
   MOJO_CHECK_LAUNCH("moe_dispatch(scan)");
   const size_t lds = static_cast<size_t>(4) * e * sizeof(int);
   const int k = static_cast<int>(top_k), h = static_cast<int>(hidden_size);
@@ -699,21 +810,28 @@ extern "C" int mojo_hip_moe_combine(const void* expert_outputs, const float* sor
   int32_t* list = start + tokens + 1;                   // [rows]
   // (zeroed by a kernel, not hipMemsetAsync: a captured graph holding two memset nodes on this buffer between kernel
   // nodes aborted at replay on ROCm 7.0)
-  const unsigned zero_blocks = static_cast<unsigned>(ceil_div(tokens, 256) > 1024 ? 1024 : ceil_div(tokens, 256));
-  hipLaunchKernelGGL(moe_zero_kernel, dim3(zero_blocks), dim3(256), 0, s, cnt, tokens);
-  MOJO_CHECK_LAUNCH("moe_combine(zero)");
-  const int row_blocks = static_cast<int>(ceil_div(rows > 0 ? rows : 1, 256));
-  if (rows > 0) {
-    hipLaunchKernelGGL(moe_count_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, cnt);
-    MOJO_CHECK_LAUNCH("moe_combine(count)");
-  }
-  hipLaunchKernelGGL(moe_token_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, tokens, start);
-  MOJO_CHECK_LAUNCH("moe_combine(scan)");
-  if (rows > 0) {
+  const char* plan_env = getenv("MOJO_HIP_MOE_PLAN");          // "0": the five-launch plan (the route of > 15 360 tokens), read per call
+  if (tokens <= PLAN_MAX_TOKENS && !(plan_env && plan_env[0] == '0')) {
+    hipLaunchKernelGGL(moe_token_plan_kernel, dim3(1), dim3(1024), static_cast<size_t>(tokens) * sizeof(int), s, token_indices, rows,
+                       static_cast<int>(tokens), start, list);
+    MOJO_CHECK_LAUNCH("moe_combine(plan)");
+  } else {
+    const unsigned zero_blocks = static_cast<unsigned>(ceil_div(tokens, 256) > 1024 ? 1024 : ceil_div(tokens, 256));
     hipLaunchKernelGGL(moe_zero_kernel, dim3(zero_blocks), dim3(256), 0, s, cnt, tokens);
     MOJO_CHECK_LAUNCH("moe_combine(zero)");
-    hipLaunchKernelGGL(moe_fill_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, start, cnt, list);
-    MOJO_CHECK_LAUNCH("moe_combine(fill)");
+    const int row_blocks = static_cast<int>(ceil_div(rows > 0 ? rows : 1, 256));
+    if (rows > 0) {
+      hipLaunchKernelGGL(moe_count_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, cnt);
+      MOJO_CHECK_LAUNCH("moe_combine(count)");
+    }
+    hipLaunchKernelGGL(moe_token_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, tokens, start);
+    MOJO_CHECK_LAUNCH("moe_combine(scan)");
+    if (rows > 0) {
+      hipLaunchKernelGGL(moe_zero_kernel, dim3(zero_blocks), dim3(256), 0, s, cnt, tokens);
+      MOJO_CHECK_LAUNCH("moe_combine(zero)");
+      hipLaunchKernelGGL(moe_fill_kernel, dim3(row_blocks), dim3(256), 0, s, token_indices, rows, tokens, start, cnt, list);
+      MOJO_CHECK_LAUNCH("moe_combine(fill)");
+    }
   }
   const int h = static_cast<int>(hidden_size);
 #define COMBINE(TY)                                                                                                    \

@@ -132,6 +132,41 @@ def test_combine_reference_space_bit_exact(tokens, k, hidden, dtype, by_gates):
     assert torch.equal(to_cpu(got), want)
 
 
+@pytest.mark.parametrize("tokens,k,hidden", [(1, 1, 64), (1000, 3, 64), (15360, 2, 64), (15361, 2, 64), (20000, 1, 32)])
+@pytest.mark.parametrize("plan", ["1", "0"])
+def test_combine_row_list_plan_routes_agree_with_the_oracle(tokens, k, hidden, plan, monkeypatch):
+    """The row lists of the combine are built by one single-block kernel (counters in LDS, <= 15 360 tokens) or by the
+    five-launch plan (more tokens, or MOJO_HIP_MOE_PLAN=0): both bit-equal to the golden, skewed routing included."""
+    monkeypatch.setenv("MOJO_HIP_MOE_PLAN", plan)
+    torch.manual_seed(tokens + k)
+    n = tokens * k
+    rows = torch.randn(n, hidden, dtype=torch.bfloat16)
+    gates = torch.rand(n, 1)
+    tok = torch.randint(0, tokens, (n,), dtype=torch.int32)             # some tokens get many rows, some none
+    tok[: min(n // 3, 900)] = tok[0]                                    # one token owns many rows (<= 1024: the length the combine sorts in LDS)
+    tok = tok[torch.randperm(n)].contiguous()
+    buf = torch.zeros(tokens, hidden, dtype=torch.bfloat16)
+    want = torch_cls("MojoMoECombine")()(buf, rows, gates, tok)
+    got = hip_cls("MojoMoECombine")()(buf.to(DEV), rows.to(DEV), gates.to(DEV), tok.to(DEV))
+    assert torch.equal(to_cpu(got), want)
+
+
+@pytest.mark.parametrize("experts,k,tokens", [(1, 1, 5), (2, 2, 40000), (257, 4, 9000), (4096, 8, 3000), (64, 8, 20000)])
+def test_dispatch_scan_many_blocks_and_experts(experts, k, tokens):
+    """The counting sort's scan kernel (one wave per expert over the blocks' histograms, then the experts' totals): more
+    than 64 blocks per expert, an odd expert count, the maximum expert count."""
+    torch.manual_seed(experts)
+    x = torch.rand(tokens, 16, dtype=torch.bfloat16)
+    ids = torch.stack([torch.randperm(experts)[:k] for _ in range(64)]).repeat((tokens + 63) // 64, 1)[:tokens].to(torch.int32).contiguous()
+    ids = ids[torch.randperm(tokens)].contiguous()
+    gates = torch.rand(tokens, k)
+    op = hip_cls("MojoMoEDispatch")(num_experts=experts)
+    out = to_cpu(op(x.to(DEV), gates.to(DEV), ids.to(DEV)))
+    want = torch_cls("MojoMoEDispatch")(num_experts=experts)(x, gates, ids)
+    assert torch.equal(out[1], want[1])
+    _check_buckets(*out, x, gates, ids)
+
+
 def test_combine_tokens_without_rows_are_zero():
     rows = torch.randn(6, 64, dtype=torch.bfloat16)
     tok = torch.tensor([5, 5, 0, 5, 0, 9], dtype=torch.int32)
