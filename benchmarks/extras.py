@@ -16,11 +16,20 @@ MFMA_I8_PEAK_TOPS = 5000.0
 MFMA_FP8_PEAK_TFLOPS = 5000.0
 
 
-def _time(fn, iters=10, warmup=2):
+def _time(fn, iters=10, warmup=2, settle_s=0.03):
+    """Eager launches timed with HIP events, after ``warmup`` calls and ``settle_s`` of back-to-back device work (the
+    power-management transient after an idle moment, see _time_graph, lasts 10-30 ms)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
+    for _ in range(min(200, int(settle_s / one))):
+        fn()
     e0.record()
     for _ in range(iters):
         fn()
@@ -29,10 +38,16 @@ def _time(fn, iters=10, warmup=2):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def _time_graph(fn, reps=20, replays=5):
+def _time_graph(fn, reps=20, replays=5, settle_s=0.03, min_timed_s=0.01):
     """Device time of ``fn`` with launch overhead amortised: ``reps`` calls captured in one HIP graph, replayed.  For
     decode-sized ops the eager figure measures the Python shim (~20 us per call), not the kernels; a serving loop
-    replays graphs, so this is the figure that matters there."""
+    replays graphs, so this is the figure that matters there.
+
+    SUSTAINED rate: the graph is first replayed for ``settle_s`` of device time without a pause, then timed over at least
+    ``min_timed_s``.  After an idle moment (capture, allocation, a host sync) the chip runs a power-management transient:
+    the same decode kernel takes 52 us for the first ~40 back-to-back launches, 60-67 us between 2 and 8 ms, and is back at
+    52 us from ~10 ms on (ctx 1024; at ctx 4096: 209-217 us at first, 179 us after ~28 ms) — profiles/r2_decode_sustain.txt,
+    scripts/probes/decode_sustain.py.  Timing 100 launches right after the capture measured that transient."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -44,9 +59,16 @@ def _time_graph(fn, reps=20, replays=5):
     with torch.cuda.graph(graph):
         for _ in range(reps):
             fn()
-    graph.replay()
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1) * 1e-3, 1e-6)                       # seconds per replay (first, cold estimate)
+    settle = min(400, max(1, int(settle_s / one)))
+    replays = min(400, max(replays, int(min_timed_s / one) + 1))
+    for _ in range(settle):
+        graph.replay()
     e0.record()
     for _ in range(replays):
         graph.replay()
