@@ -16,9 +16,11 @@ MFMA_I8_PEAK_TOPS = 5000.0
 MFMA_FP8_PEAK_TFLOPS = 5000.0
 
 
-def _time(fn, iters=10, warmup=2, settle_s=0.03):
+def _time(fn, iters=10, warmup=2, settle_s=0.03, settle_n=None):
     """Eager launches timed with HIP events, after ``warmup`` calls and ``settle_s`` of back-to-back device work (the
-    power-management transient after an idle moment, see _time_graph, lasts 10-30 ms)."""
+    power-management transient after an idle moment, see _time_graph, lasts 10-30 ms).  ``settle_n`` fixes the number of
+    settle calls instead: a case that contains collectives must make the SAME number of calls on every rank, and a count
+    derived from a rank's own clock would not."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -28,7 +30,7 @@ def _time(fn, iters=10, warmup=2, settle_s=0.03):
     e1.record()
     torch.cuda.synchronize()
     one = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
-    for _ in range(min(200, int(settle_s / one))):
+    for _ in range(min(200, int(settle_s / one)) if settle_n is None else settle_n):
         fn()
     e0.record()
     for _ in range(iters):
@@ -384,7 +386,7 @@ def bench_compute_comm(device, world, rank):
     link_peak = 153.0                                   # GB/s per xGMI link
 
     def timed(fn):
-        return _time(fn, 5, 2)
+        return _time(fn, 5, 2, settle_n=12)             # a fixed call count: every rank must issue the same collectives
 
     def with_direct(flag, fn):
         old = os.environ.get("MOJO_HIP_COMM_DIRECT")

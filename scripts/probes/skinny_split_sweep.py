@@ -45,3 +45,20 @@ for m, k, n in shapes:
     del ws, x
     torch.cuda.empty_cache()
 os.environ.pop("MOJO_HIP_GEMM_SKINNY_SPLITK", None)
+
+# calibration: what the vendor library (torch.nn.functional.linear -> hipBLASLt) takes for the same products; not a product path
+import torch.nn.functional as F  # noqa: E402
+print("calibration: torch F.linear (hipBLASLt) under the same replay timing")
+for m, k, n in shapes:
+    x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
+    ws = [torch.randn(n, k, device=dev, dtype=torch.bfloat16) for _ in range(max(2, min(8, int(600e6 // (n * k * 2)))))]
+    it = [0]
+
+    def fn():
+        it[0] += 1
+        return F.linear(x, ws[it[0] % len(ws)])
+
+    t = _time_graph(fn, reps=len(ws) * 4, replays=5)
+    print(f"M={m} K={k} N={n}: {t * 1e6:6.1f} us {n * k * 2 / t / 1e12:4.2f} TB/s", flush=True)
+    del ws, x
+    torch.cuda.empty_cache()

@@ -105,7 +105,10 @@ for path in sorted(glob.glob(os.path.join(SRC, "case_*"))):
     for k, v in d.items():
         if not k.startswith("mojo::") and "mojo" not in k:
             continue
-        timed = v[len(v) // 3:] if len(v) >= 6 else v      # drop the warm-up third (warmup <= iters / 2 in every case)
+        # benchmarks/extras now replays every case for 30 ms before it times (the post-idle power transient,
+        # profiles/r2_decode_sustain.txt), so a trace is: warm-up, settle launches, timed launches.  The LAST THIRD of a
+        # kernel's launches is past the transient in every case (settle >= 2 x timed) and contains all timed launches.
+        timed = v[-max(1, len(v) // 3):] if len(v) >= 6 else v
         rows.append({"case": tag, "kernel": k[:160], "launches": len(v), "timed_launches": len(timed),
                      "avg_us_timed": round(sum(timed) / len(timed) / 1e3, 2), "min_us": round(min(v) / 1e3, 2)})
 if rows:
