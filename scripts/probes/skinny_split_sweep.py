@@ -23,7 +23,7 @@ for m, k, n in shapes:
     ref = None
     row = []
     for sk in (0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
-        if sk:
+        if sk > 0:
             os.environ["MOJO_HIP_GEMM_SKINNY_SPLITK"] = str(sk)
         else:
             os.environ.pop("MOJO_HIP_GEMM_SKINNY_SPLITK", None)
