@@ -167,3 +167,92 @@ def test_mla_decode_step_replays():
         want = step()
         torch.cuda.synchronize()
         assert torch.equal(got, want)
+
+
+def test_decoder_layer_as_one_graph_matches_the_oracle_chain():
+    """One whole decoder layer at decode (the operators of this package close a full layer): residual-add
+    RMSNorm -> QKV projection -> RoPE -> paged KV store -> paged decode attention -> output projection -> residual-add
+    RMSNorm -> gate|up projection -> SwiGLU -> down projection, captured as ONE HIP graph and replayed on new inputs, against
+    the same chain on the oracle's operators on the CPU (projections: fp32 accumulation, rounded once, as the GEMM does).
+    Ragged contexts, pages in random order; the stored K/V are compared as well as the layer's two outputs."""
+    import torch.nn.functional as F
+
+    from hip_utils import to_cpu, torch_cls
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+
+    torch.manual_seed(7)
+    b, hq, hkv, d, page, hidden, inter, max_len = 6, 8, 2, 128, 16, 1024, 2048, 256
+    dt = torch.bfloat16
+    pages = max_len // page
+    n_blocks = b * pages + 3
+    table_cpu = torch.randperm(n_blocks, dtype=torch.int32)[: b * pages].view(b, pages)
+    w = {"qkv": torch.randn((hq + 2 * hkv) * d, hidden) * hidden ** -0.5, "o": torch.randn(hidden, hq * d) * (hq * d) ** -0.5,
+         "gu": torch.randn(2 * inter, hidden) * hidden ** -0.5, "dn": torch.randn(hidden, inter) * inter ** -0.5,
+         "n1": 1 + 0.1 * torch.randn(hidden), "n2": 1 + 0.1 * torch.randn(hidden)}
+    w = {k: v.to(dt) for k, v in w.items()}
+    wd = {k: v.to(DEV) for k, v in w.items()}
+    k_cache0 = torch.randn(n_blocks, hkv, page, d).to(dt)
+    v_cache0 = torch.randn(n_blocks, hkv, page, d).to(dt)
+
+    def make_ops(cls, **kw):
+        n1 = cls("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, **kw)
+        n2 = cls("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, **kw)
+        with torch.no_grad():
+            n1.weight.copy_(w["n1"])
+            n2.weight.copy_(w["n2"])
+        return n1, n2, cls("MojoApplyRoPE")(), cls("MojoStorePagedKVCache")(), cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout="AABB"), cls("MojoSwiGLU")()
+
+    def layer(ops, lin, ww, x, resid, cos, sin, k_cache, v_cache, table, ctx, total):
+        n1, n2, rope, store, attn, act = ops
+        h, r1 = n1(x, resid)
+        qkv = lin(h, ww["qkv"])
+        q = qkv[:, : hq * d].reshape(b, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].reshape(b, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].reshape(b, hkv, d).contiguous()
+        q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
+        store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, None, ctx)
+        o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, total, table)
+        a = lin(o.reshape(b, hq * d), ww["o"])
+        h2, r2 = n2(a, r1)
+        gu = lin(h2, ww["gu"])
+        m = act(gu[:, :inter].contiguous(), gu[:, inter:].contiguous())
+        return lin(m, ww["dn"]), r2
+
+    # static device buffers of the captured step
+    x = torch.zeros(b, hidden, dtype=dt, device=DEV)
+    resid = torch.zeros_like(x)
+    cos, sin = torch.zeros(b, d, device=DEV), torch.zeros(b, d, device=DEV)
+    ctx = torch.zeros(b, dtype=torch.int32, device=DEV)
+    total = torch.ones(b, dtype=torch.int32, device=DEV)
+    k_cache, v_cache, table = k_cache0.to(DEV), v_cache0.to(DEV), table_cpu.to(DEV)
+    hip_ops = make_ops(hip_cls, device=DEV)
+    ref_ops = make_ops(torch_cls)
+    graph, static_out = _capture(lambda: layer(hip_ops, lambda t, m: dense_gemm(t, m, None, False), wd, x, resid, cos, sin,
+                                               k_cache, v_cache, table, ctx, total))
+    for i in range(3):
+        g = torch.Generator().manual_seed(50 + i)
+        x_c, r_c = torch.randn(b, hidden, generator=g).to(dt), torch.randn(b, hidden, generator=g).to(dt)
+        ang = torch.rand(b, d, generator=g) * 6.28
+        cos_c, sin_c = torch.cos(ang), torch.sin(ang)
+        lens = torch.randint(1, max_len - 1, (b,), generator=g).to(torch.int32)
+        lens[i] = page * (i + 1) - 1                        # a row whose new token fills the last slot of a page
+        for dst, src in ((x, x_c), (resid, r_c), (cos, cos_c), (sin, sin_c), (ctx, lens), (total, lens + 1)):
+            dst.copy_(src)
+        k_cache.copy_(k_cache0)
+        v_cache.copy_(v_cache0)
+        graph.replay()
+        torch.cuda.synchronize()
+        got_out, got_res = to_cpu(static_out)
+        kc, vc = k_cache0.clone(), v_cache0.clone()
+        want_out, want_res = layer(ref_ops, lambda t, m: F.linear(t.float(), m.float()).to(dt), w, x_c, r_c, cos_c, sin_c,
+                                   kc, vc, table_cpu, lens, lens + 1)
+        # bf16 chain of ten operators: every stage rounds to bf16 (2^-8 relative), the projections sum K in another order
+        for name, got, want in (("out", got_out, want_out), ("residual", got_res, want_res), ("k_cache", to_cpu(k_cache), kc),
+                                ("v_cache", to_cpu(v_cache), vc)):
+            err = (got.float() - want.float()).abs().max().item()
+            scale = want.float().abs().max().item()
+            print(f"decoder layer replay {i}: {name}: max |hip - oracle| = {err:.4g} at scale {scale:.4g} ({err / scale:.2%})")
+            assert err <= 1.5e-2 * scale, f"replay {i}: {name} differs by {err:.4g} (scale {scale:.4g})"   # measured <= 0.6 %
+        # the step wrote exactly one token per sequence into the cache
+        changed = (to_cpu(k_cache) != k_cache0).flatten(2).any(-1)          # [blocks, hkv]
+        assert int(changed.any(-1).sum()) <= b
