@@ -524,6 +524,14 @@ def bench_moe(device):
         gd.gate_weight.copy_(torch.randn(7168, 256) * 0.02)
     out["gating_T8192_E256_k8_H7168"] = _mfma(_time(lambda: gd(xd), 20, 3), 2.0 * t_ * 7168 * 256 * 2)
     del xd, gd
+    # the router at decode: 64 tokens (graph replay; the few-token kernel: a grid over slices of H, fp32 FMAs, slabs + select)
+    for name, (td, ed, kd, hd) in {"gating_decode_T64_E64_k8_H4096": (64, 64, 8, 4096), "gating_decode_T64_E256_k8_H7168": (64, 256, 8, 7168)}.items():
+        xs = torch.rand(td, hd, device=device, dtype=torch.bfloat16)
+        gs = hip("MojoMoEGating")(hidden_size=hd, num_experts=ed, top_k=kd).to(device)
+        with torch.no_grad():
+            gs.gate_weight.copy_(torch.randn(hd, ed) * 0.02)
+        out[name] = _hbm(_time_graph(lambda: gs(xs), reps=10), hd * ed * 4 + td * hd * 2)
+        del xs, gs
     idx, gates = gating(x)
     dispatch = hip("MojoMoEDispatch")(num_experts=e_)
     out["dispatch_T8192_E8_k2_H4096"] = _hbm(_time(lambda: dispatch(x, gates, idx), 20, 3), t_ * h_ * 2 + t_ * k_ * (h_ * 2 + 16))

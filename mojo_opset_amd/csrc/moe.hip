@@ -250,6 +250,136 @@ __global__ __launch_bounds__(256, 2) void moe_gating_e8_kernel(const T* __restri
     }
 }
 
+// Sum of many slabs + softmax + top-k, one WORKGROUP per token: wave w sums the slabs p = w, w + 4, ... (four loads in
+// flight), the four partial sums meet in LDS and wave 0 selects.  (moe_gate_select_kernel gives a token one wave, which
+// then walks all slabs through dependent loads: 39 us for 64 slabs x 256 experts.)
+__global__ __launch_bounds__(256) void moe_gate_reduce_select_kernel(const float* __restrict__ logits, int64_t part_stride, int parts,
+                                                                     int e_pad, int32_t* __restrict__ out_idx,
+                                                                     float* __restrict__ out_gate, int experts, int top_k) {
+  extern __shared__ float s_lg[];                                         // [4][e_pad]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t token = blockIdx.x;
+  const float* src = logits + token * e_pad;
+  for (int e0 = lane; e0 < experts; e0 += 256) {                          // four expert slots per lane and pass: 16 loads in flight
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = wave; p < parts; p += 16) {
+      float v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[q][u] = (e0 + 64 * q < experts && p + 4 * u < parts) ? src[e0 + 64 * q + (p + 4 * u) * part_stride] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = (((acc[q] + v[q][0]) + v[q][1]) + v[q][2]) + v[q][3];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (e0 + 64 * q < experts) s_lg[wave * e_pad + e0 + 64 * q] = acc[q];
+  }
+  __syncthreads();
+  if (wave == 0) gate_softmax_topk(s_lg, e_pad, 4, experts, top_k, lane, out_idx + token * top_k, out_gate + token * top_k);
+}
+
+// Few tokens (a decode step): the router is a tiny product — T x H x E multiply-adds against an fp32 weight of 1-7 MB —
+// and what matters is spreading it over the chip.  The kernels above put one token (E <= 64) or a few on a workgroup and
+// each workgroup walked the WHOLE weight through 4-byte loads: 53 us for 64 tokens x 64 experts, 204 us for 64 x 256 at
+// H = 7168 (a DeepSeek-V3 decode step pays that in every MoE layer).  Here the grid is (slice of H, 8 tokens, 256 experts):
+// a thread owns one expert and 16 hidden positions per step (its 16 weights are coalesced 4-byte loads across the experts,
+// the 8 x 16 activations a broadcast read of an LDS image), a workgroup's step covers 256 / EP sub-slices of 16 positions
+// (EP = experts per workgroup, a power of two), fp32 FMAs in index order; the sub-slices are summed in LDS in fixed order,
+// the slices go to fp32 slabs [slice][token][e_pad] and moe_gate_select_kernel sums them in slice order.
+constexpr int GS_TC = 8;      // tokens per workgroup
+constexpr int GS_HB = 16;     // hidden positions per thread and step
+constexpr int GS_XC = 512;    // hidden positions of the activation image in LDS (a multiple of every step: 16 .. 256)
+struct GateSmallPlan { int ep_log2, slice_len, slices, e_chunks, t_chunks; };
+static GateSmallPlan gate_small_plan(int64_t tokens, int64_t hidden, int64_t experts) {
+  GateSmallPlan p;
+  p.ep_log2 = 4;
+  while ((1 << p.ep_log2) < experts && p.ep_log2 < 8) ++p.ep_log2;
+  const int ep = 1 << p.ep_log2, step = (256 / ep) * GS_HB;
+  p.e_chunks = static_cast<int>(ceil_div(experts, static_cast<int64_t>(ep)));
+  p.t_chunks = static_cast<int>(ceil_div(tokens, static_cast<int64_t>(GS_TC)));
+  const int64_t max_slices = ceil_div(hidden, static_cast<int64_t>(step));
+  int64_t want = 512 / (static_cast<int64_t>(p.e_chunks) * p.t_chunks);       // ~2 workgroups per CU
+  if (want > 64) want = 64;
+  if (want > max_slices) want = max_slices;
+  if (want < 1) want = 1;
+  p.slice_len = static_cast<int>(ceil_div(ceil_div(hidden, want), static_cast<int64_t>(step)) * step);
+  p.slices = static_cast<int>(ceil_div(hidden, static_cast<int64_t>(p.slice_len)));
+  return p;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void moe_gating_small_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                               float* __restrict__ slabs, int tokens, int hidden, int experts,
+                                                               int e_pad, int ep_log2, int slice_len) {
+  __shared__ __attribute__((aligned(16))) float s_x[GS_TC][GS_XC];        // [token][position inside the chunk]
+  __shared__ float s_red[256 * GS_TC];                                    // [sub-slice][token][expert of the workgroup]
+  const int ep = 1 << ep_log2, hs_n = 256 >> ep_log2, step = hs_n * GS_HB;
+  const int e_local = threadIdx.x & (ep - 1), hs = threadIdx.x >> ep_log2;
+  const int e = static_cast<int>(blockIdx.z) * ep + e_local;
+  const int t0 = static_cast<int>(blockIdx.y) * GS_TC;
+  const int hb0 = static_cast<int>(blockIdx.x) * slice_len, hb1 = min(hidden, hb0 + slice_len);
+  float acc[GS_TC];
+#pragma unroll
+  for (int t = 0; t < GS_TC; ++t) acc[t] = 0.f;
+  // the weights of the next step are requested before this step's arithmetic (one step is 16 dependent-free 4-byte loads
+  // per thread; without the look-ahead every step waited out a full memory round trip)
+  float wn[GS_HB];
+  auto load_w = [&](int h0, float (&dst)[GS_HB]) {
+    const int hh = h0 + hs * GS_HB;
+#pragma unroll
+    for (int j = 0; j < GS_HB; ++j) dst[j] = (hh + j < hb1 && e < experts) ? w[static_cast<int64_t>(hh + j) * experts + e] : 0.f;
+  };
+  load_w(hb0, wn);
+  // the activations of up to GS_XC positions are staged at once (one memory round trip and two barriers per chunk, not per step)
+  for (int c0 = hb0; c0 < hb1; c0 += GS_XC) {
+    const int c1 = min(hb1, c0 + GS_XC);
+    const int cw = (c1 - c0 + step - 1) / step * step;                    // positions the steps of this chunk read (zeros behind c1)
+    for (int i = threadIdx.x; i < GS_TC * cw; i += 256) {
+      const int t = i / cw, c = i - t * cw;
+      const int h = c0 + c, tok = t0 + t;
+      s_x[t][c] = (h < c1 && tok < tokens) ? elt<T>::to_f(x[static_cast<int64_t>(tok) * hidden + h]) : 0.f;
+    }
+    __syncthreads();
+    for (int h0 = c0; h0 < c1; h0 += step) {
+      float wv[GS_HB];
+#pragma unroll
+      for (int j = 0; j < GS_HB; ++j) wv[j] = wn[j];
+      if (h0 + step < hb1) load_w(h0 + step, wn);
+#pragma unroll
+      for (int t = 0; t < GS_TC; ++t) {
+        const f32x4* xp = reinterpret_cast<const f32x4*>(&s_x[t][h0 - c0 + hs * GS_HB]);
+#pragma unroll
+        for (int q = 0; q < GS_HB / 4; ++q) {
+          const f32x4 xv = xp[q];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[t] = fmaf(xv[c], wv[4 * q + c], acc[t]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (hs_n > 1) {
+#pragma unroll
+    for (int t = 0; t < GS_TC; ++t) s_red[(hs * GS_TC + t) * ep + e_local] = acc[t];
+    __syncthreads();
+    if (hs == 0) {
+#pragma unroll
+      for (int t = 0; t < GS_TC; ++t) {
+        float v = acc[t];
+        for (int k = 1; k < hs_n; ++k) v += s_red[(k * GS_TC + t) * ep + e_local];
+        acc[t] = v;
+      }
+    }
+  }
+  if (hs == 0 && e < e_pad) {
+#pragma unroll
+    for (int t = 0; t < GS_TC; ++t)
+      if (t0 + t < tokens) slabs[(static_cast<int64_t>(blockIdx.x) * tokens + t0 + t) * e_pad + e] = acc[t];
+  }
+}
+
 // large expert counts: logits come from the MFMA GEMM (x @ w_hi + x @ w_lo, `parts` fp32 slabs of [tokens, e_pad]);
 // one wave per token
 __global__ __launch_bounds__(256) void moe_gate_select_kernel(const float* __restrict__ logits, int64_t part_stride, int parts,
@@ -670,7 +800,17 @@ static int gate_splitk(int64_t tokens, int64_t hidden, int64_t e_pad) {
   return sk < 1 ? 1 : static_cast<int>(sk);
 }
 
+// Few tokens and more than the eight experts the streaming kernel covers: moe_gating_small_kernel (any dtype).
+// MOJO_HIP_GATING_SMALL=0/1 forces the choice (read per call).
+static bool gate_use_small(int64_t tokens, int64_t hidden, int64_t experts) {
+  if (hidden >= (1LL << 30) || tokens >= (1LL << 24)) return false;
+  if (const char* e = getenv("MOJO_HIP_GATING_SMALL")) return e[0] != '0';
+  return tokens <= 256 && experts > 8;
+}
+
 extern "C" int64_t mojo_hip_moe_gating_workspace_bytes(int64_t tokens, int64_t hidden_size, int64_t num_experts, int dtype) {
+  if (gate_use_small(tokens, hidden_size, num_experts))
+    return static_cast<int64_t>(gate_small_plan(tokens, hidden_size, num_experts).slices) * tokens * gate_e_pad(num_experts) * 4 + 256;
   if (!gate_use_mfma(tokens, hidden_size, num_experts, dtype)) return 64;
   const int64_t e_pad = gate_e_pad(num_experts);
   const int sk = gate_splitk(tokens, hidden_size, e_pad);
@@ -723,6 +863,24 @@ extern "C" int mojo_hip_moe_gating(const void* hidden, const float* gate_weight,
   MOJO_REQUIRE(aligned_to(hidden, 16), MOJO_EUNSUPPORTED, "moe_gating: hidden_states must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int h = static_cast<int>(hidden_size), e = static_cast<int>(num_experts), k = static_cast<int>(top_k);
+  if (gate_use_small(tokens, hidden_size, num_experts)) {
+    MOJO_REQUIRE(dtype == MOJO_F32 || dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED, "moe_gating: dtype %d not supported", dtype);
+    MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_moe_gating_workspace_bytes(tokens, hidden_size, num_experts, dtype) &&
+                     aligned_to(workspace, 16),
+                 MOJO_EWORKSPACE, "moe_gating: workspace too small");
+    const GateSmallPlan p = gate_small_plan(tokens, hidden_size, num_experts);
+    const int e_pad = static_cast<int>(gate_e_pad(num_experts)), t = static_cast<int>(tokens);
+    float* slabs = static_cast<float*>(workspace);
+    const dim3 grid(static_cast<unsigned>(p.slices), static_cast<unsigned>(p.t_chunks), static_cast<unsigned>(p.e_chunks));
+#define GATE_SMALL(TY) hipLaunchKernelGGL(moe_gating_small_kernel<TY>, grid, dim3(256), 0, s, static_cast<const TY*>(hidden), gate_weight, slabs, t, h, e, e_pad, p.ep_log2, p.slice_len)
+    if (dtype == MOJO_F32) GATE_SMALL(float); else if (dtype == MOJO_F16) GATE_SMALL(f16_t); else GATE_SMALL(bf16_t);
+#undef GATE_SMALL
+    MOJO_CHECK_LAUNCH("moe_gating(small)");
+    hipLaunchKernelGGL(moe_gate_reduce_select_kernel, dim3(static_cast<unsigned>(tokens)), dim3(256), static_cast<size_t>(4) * e_pad * sizeof(float), s,
+                       slabs, tokens * e_pad, p.slices, e_pad, top_k_indices, top_k_gates, e, k);
+    MOJO_CHECK_LAUNCH("moe_gating(select)");
+    return MOJO_OK;
+  }
   if (gate_use_mfma(tokens, hidden_size, num_experts, dtype)) {
     MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_moe_gating_workspace_bytes(tokens, hidden_size, num_experts, dtype) &&
                      aligned_to(workspace, 256),

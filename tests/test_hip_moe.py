@@ -316,3 +316,30 @@ def test_gating_mfma_route_agrees_with_vector_route(dtype, monkeypatch):
     same = idx_m == idx_v
     assert float(same.float().mean()) >= 0.999
     torch.testing.assert_close(g_m[same], g_v[same], atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("tokens,experts,k,hidden", [(1, 64, 8, 4096), (7, 9, 3, 100), (64, 256, 8, 7168), (200, 384, 8, 3584),
+                                                     (256, 1024, 64, 256), (33, 17, 17, 48), (64, 64, 6, 4104)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gating_few_token_kernel_matches_the_oracle(tokens, experts, k, hidden, dtype, monkeypatch):
+    """The router of a decode step (<= 256 tokens, more than 8 experts) runs moe_gating_small_kernel + a workgroup-per-token
+    select: against the golden (fp32 product) and against the general kernel — odd expert counts, hidden sizes that are no
+    multiple of a step, the maximum expert count, fp32 activations."""
+    torch.manual_seed(tokens * 131 + experts)
+    ref = torch_cls("MojoMoEGating")(hidden_size=hidden, num_experts=experts, top_k=k)
+    torch.nn.init.normal_(ref.gate_weight, std=0.05)
+    op = hip_cls("MojoMoEGating")(hidden_size=hidden, num_experts=experts, top_k=k).to(DEV)
+    op.load_state_dict(ref.state_dict())
+    x = torch.rand(tokens, hidden).to(dtype)
+    monkeypatch.setenv("MOJO_HIP_GATING_SMALL", "1")
+    idx_s, gate_s = to_cpu(op(x.to(DEV)))
+    idx_w, gate_w = ref(x)
+    monkeypatch.setenv("MOJO_HIP_GATING_SMALL", "0")
+    monkeypatch.setenv("MOJO_HIP_GATING_MFMA", "0")
+    idx_g, gate_g = to_cpu(op(x.to(DEV)))
+    # selections can only differ where two probabilities are closer than fp32 summation-order noise
+    for idx_o, gate_o in ((idx_w.to(torch.int32), gate_w), (idx_g, gate_g)):
+        same = (idx_s == idx_o).all(-1)
+        assert same.float().mean().item() >= 0.99
+        assert torch.allclose(gate_s[same], gate_o[same].float(), atol=2e-5, rtol=1e-4)
+    assert idx_s.dtype == torch.int32 and gate_s.dtype == torch.float32
