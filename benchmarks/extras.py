@@ -552,10 +552,11 @@ def bench_moe(device):
         return combine(buf, experts(a, c), b, d)
     out["moe_layer_T8192_E8_k2"] = _mfma(_time(layer, 5, 1), flops)
     del experts
-    # MoE at decode: 64 tokens, top-8 of 64 experts (hidden 4096, inter 2048): a few rows per expert, the experts' weights are
-    # a stream (6.4 GB/s ... 64 x 3 x 4096 x 2048 x 2 B = 3.2 GB touched)
+    # MoE at decode: 64 tokens, top-8 of 64 experts (hidden 4096, inter 2048): a few rows per expert, the weights of the experts
+    # that received rows are a stream (50 MB each: 3 x 4096 x 2048 x 2 B); zero-mean inputs so that the routing spreads
     td, ed, kd, hd, idm = 64, 64, 8, 4096, 2048
-    xd = torch.rand(td, hd, device=device, dtype=torch.bfloat16)
+    torch.manual_seed(20260717)
+    xd = torch.randn(td, hd, device=device, dtype=torch.bfloat16)
     gd = hip("MojoMoEGating")(hidden_size=hd, num_experts=ed, top_k=kd).to(device)
     exd = hip("MojoExperts")(num_experts=ed, hidden_size=hd, intermediate_size=idm).to(torch.bfloat16).to(device)
     with torch.no_grad():
@@ -564,12 +565,19 @@ def bench_moe(device):
         exd.down_proj_weight.normal_(std=0.02)
     dd, cd = hip("MojoMoEDispatch")(num_experts=ed), hip("MojoMoECombine")()
     bufd = torch.empty_like(xd)
+    i0, g0 = gd(xd)
+    rows0, counts0, _, _ = dd(xd, g0, i0)
+    used = int((counts0 > 0).sum())                        # (read once, outside the timed region)
 
     def decode_layer():
         i2, g2 = gd(xd)
         a, c, b, d = dd(xd, g2, i2)
         return cd(bufd, exd(a, c), b, d)
-    out["moe_layer_decode_T64_E64_k8_H4096_I2048"] = _hbm(_time_graph(decode_layer, reps=5, replays=3), ed * 3 * hd * idm * 2)
+    w_bytes = used * 3 * hd * idm * 2
+    res = _hbm(_time_graph(decode_layer, reps=5, replays=3), w_bytes)
+    res["experts_with_rows"] = used
+    res["experts_only"] = _hbm(_time_graph(lambda: exd(rows0, counts0), reps=5, replays=3), w_bytes)
+    out["moe_layer_decode_T64_E64_k8_H4096_I2048"] = res
     del exd
     return out
 

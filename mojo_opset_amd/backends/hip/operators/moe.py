@@ -108,6 +108,12 @@ class HIPExperts(MojoExperts):
         [M, 2I] product never goes to HBM).  False when the shape is outside the fused kernel's preconditions."""
         if os.environ.get("MOJO_HIP_EXPERTS_FUSED", "1") == "0" or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[0] == 0:
             return False
+        # A decode step (at most 64 rows per expert on average): the projections are weight streams, and the grouped GEMM
+        # has a 64-row streaming form for ragged groups (csrc/gemm_skinny.hip, RAGGED) that the fused 256-row tile kernel
+        # cannot use; the [M, 2I] round trip of the two-kernel path is a few hundred KB there.
+        if (x.shape[0] <= 64 * w.shape[0] and x.shape[1] % 128 == 0 and w.shape[1] % 64 == 0 and w.shape[0] >= 2
+                and os.environ.get("MOJO_HIP_GEMM_SKINNY_RAGGED", "1") != "0"):
+            return False
         lib = L.load()
         groups = w.shape[0]
         ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(groups), dtype=torch.uint8, device=x.device)

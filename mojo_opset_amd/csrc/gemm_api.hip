@@ -9,6 +9,7 @@ static int run_gemm(GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
   static const int abl = [] { const char* e = getenv("MOJO_HIP_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = abl;
   if (gemm_skinny_ok(a, dtype)) return launch_gemm_skinny(a, dtype, s);      // <= 128 rows per (equal-sized) group, [N,K] weights
+  if (gemm_skinny_ragged_ok(a, dtype, m_total)) return launch_gemm_skinny_ragged(a, dtype, m_total, s);   // ragged, <= 64 rows per group on average
   if (gemm_mfma256_ok(a, dtype)) return launch_gemm_mfma256(a, dtype, m_total, s);
   return launch_gemm_generic(a, dtype, m_total, s);
 }
@@ -52,7 +53,7 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
   if (!group_list) {
     a.uniform_rows = static_cast<int>(m_total / num_groups);
   } else {
-    const int bm = gemm_mfma256_ok(a, dtype) ? 256 : 64;
+    const int bm = gemm_skinny_ragged_ok(a, dtype, m_total) ? 64 : (gemm_mfma256_ok(a, dtype) ? 256 : 64);   // the tile height run_gemm's choice walks
     GemmTail tail;
     const int64_t elt = dtype == MOJO_F32 ? 4 : 2;
     if (!c_map) { tail.C = out; tail.ld_bytes = ldc * elt; tail.row_bytes = n * elt; }

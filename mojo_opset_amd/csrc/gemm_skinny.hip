@@ -29,7 +29,11 @@ template <> struct skinny_mfma<f16_t> {
 // 104 KiB of LDS (one workgroup of four waves per CU) and reads its activation fragments from LDS eight times per weight
 // byte; two 64-row workgroups share a CU, and the second reads the weight lines the first just pulled into L2 (default
 // cache policy instead of non-temporal loads).
-template <typename T, int MT, int RB>
+//
+// RAGGED: groups of different sizes (the experts of an MoE layer at decode: a few rows each, counts known on the device
+// only).  blockIdx.y is then a 64-row block of the prefix arrays built for tile height 64 (gemm_locate_tile): group, first
+// row and the group's end; blocks past the last one exit.  Row maps are not supported in this form.
+template <typename T, int MT, int RB, bool RAGGED = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
   constexpr int KB = 128;                                    // elements of K per block
@@ -37,9 +41,20 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
-  const int grp = blockIdx.y / RB;
-  const int t0 = (blockIdx.y % RB) * (MT * 16);              // first row of this block inside the group
-  const int R = a.uniform_rows;
+  int grp, t0, R, row_base;                                  // group; first row of this block inside the group; rows of the group; the group's first row
+  if constexpr (RAGGED) {
+    if (static_cast<int>(blockIdx.y) >= a.tile_start[a.G]) return;
+    int m0, m_end;
+    gemm_locate_tile(a, static_cast<int>(blockIdx.y), MT * 16, grp, m0, m_end);
+    row_base = m0;                                           // (rows are counted from this block's first row)
+    t0 = 0;
+    R = min(MT * 16, m_end - m0);
+  } else {
+    grp = blockIdx.y / RB;
+    t0 = (blockIdx.y % RB) * (MT * 16);
+    R = a.uniform_rows;
+    row_base = grp * R;
+  }
   const int n0 = blockIdx.x * 64 + wave * 16;
   const int nkb = a.K / KB;
   const int slice = blockIdx.z;
@@ -60,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   for (int p = 0; p < MT; ++p) {
     const int idx = threadIdx.x + 256 * p;
     const int t = min(t0 + (idx >> 4), R - 1);
-    arow[p] = A + static_cast<int64_t>(map_row(grp * R + t, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda + (idx & 15) * 8;
+    arow[p] = A + static_cast<int64_t>(RAGGED ? row_base + t : map_row(row_base + t, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda + (idx & 15) * 8;
   }
   constexpr int DEPTH = 3;
   u32x4 wreg[DEPTH + 1][4], areg[2][MT];
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
     }
-    *reinterpret_cast<V4*>(C + static_cast<int64_t>(map_row(grp * R + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
+    *reinterpret_cast<V4*>(C + static_cast<int64_t>(RAGGED ? row_base + t : map_row(row_base + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
   }
 }
 
@@ -201,6 +216,27 @@ bool gemm_skinny_ok(const GemmArgs& a, int dtype) {
   return a.uniform_rows > 0 && a.uniform_rows <= 128 && a.w_k == 1 && a.K % 128 == 0 && a.N % 64 == 0 && a.lda % 8 == 0 &&
          a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && (a.splitk == 1 || (a.G == 1 && a.slab)) && aligned_to(a.A, 16) && aligned_to(a.W, 16) &&
          aligned_to(a.C, 8);
+}
+
+// Ragged groups whose rows average at most 64 per group (the experts of a decode step): the product is the weight stream of
+// the groups that have rows, which the 256-row tile kernel reads at ~4 TB/s (it pads every group to 256 rows; measured 500 us
+// for 40 experts x 50 MB).  Needs prefix arrays built for tile height 64.  MOJO_HIP_GEMM_SKINNY_RAGGED=0 disables (per call).
+bool gemm_skinny_ragged_ok(const GemmArgs& a, int dtype, int64_t m_total) {
+  if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
+  if (const char* e = getenv("MOJO_HIP_GEMM_SKINNY_RAGGED")) { if (e[0] == '0') return false; }
+  return a.uniform_rows == 0 && a.G >= 2 && m_total > 0 && m_total <= static_cast<int64_t>(64) * a.G && a.w_k == 1 && a.K % 128 == 0 &&
+         a.N % 64 == 0 && a.lda % 8 == 0 && a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && a.splitk == 1 && !a.glu &&
+         a.a_rc == 0 && a.c_rc == 0 && !a.bias && aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
+}
+
+int launch_gemm_skinny_ragged(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
+  MOJO_REQUIRE(gemm_skinny_ragged_ok(a, dtype, m_total), MOJO_EUNSUPPORTED, "gemm_skinny(ragged): preconditions not met");
+  // sum over groups of ceil(rows / 64) <= G + m_total / 64: the grid's y extent; blocks past the real count exit at once
+  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G + m_total / 64), 1u);
+  if (dtype == MOJO_BF16) hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, 4, 1, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<f16_t, 4, 1, true>), grid, dim3(256), 0, s, a);
+  MOJO_CHECK_LAUNCH("gemm_skinny(ragged)");
+  return MOJO_OK;
 }
 
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {

@@ -214,11 +214,44 @@ def test_experts_fused_swiglu_epilogue_is_bit_identical_to_the_two_kernel_path(e
     x = torch.randn(sum(counts), hidden, dtype=dtype, device=DEV)
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
     act = torch.empty(x.shape[0], inter, dtype=dtype, device=DEV)
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY_RAGGED", "0")       # (a decode-sized case would otherwise take the streaming form)
     assert op._fused_up_swiglu(x, op.up_proj_weight.detach(), cnt, act, inter)
     fused = op(x, cnt)
     monkeypatch.setenv("MOJO_HIP_EXPERTS_FUSED", "0")
     plain = op(x, cnt)
     assert torch.equal(fused, plain)
+    monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY_RAGGED")
+    monkeypatch.delenv("MOJO_HIP_EXPERTS_FUSED")
+    assert torch.equal(op(x, cnt), fused)                        # whatever the library picks by itself: the same bits
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("experts,hidden,inter,counts", [
+    (4, 256, 512, [3, 0, 5, 4]), (8, 1024, 1024, [64, 64, 64, 64, 64, 64, 64, 64]), (6, 384, 640, [0, 0, 130, 1, 0, 65]),
+    (64, 512, 256, None), (2, 128, 64, [1, 0]),
+])
+def test_experts_streaming_form_for_ragged_decode_groups_is_bit_identical(experts, hidden, inter, counts, dtype, monkeypatch):
+    """At most 64 rows per expert on average (a decode step): both projections run the 64-row streaming grouped GEMM on
+    ragged groups (gemm_skinny_kernel<.., RAGGED>) — empty groups, groups of more than 64 rows (several blocks), a group
+    that ends on a block boundary; same bits as the 256-row tile kernel, and against the oracle."""
+    torch.manual_seed(3)
+    if counts is None:
+        counts = torch.randint(0, 17, (experts,)).tolist()
+    ref = torch_cls("MojoExperts")(num_experts=experts, hidden_size=hidden, intermediate_size=inter)
+    for p in ref.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    ref = ref.to(dtype)
+    op = hip_cls("MojoExperts")(num_experts=experts, hidden_size=hidden, intermediate_size=inter).to(dtype).to(DEV)
+    op.load_state_dict(ref.state_dict())
+    assert sum(counts) <= 64 * experts
+    x = torch.rand(sum(counts), hidden, dtype=dtype, device=DEV)          # (the data of the reference's own experts test)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    streamed = op(x, cnt)
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY_RAGGED", "0")
+    tiled = op(x, cnt)
+    assert torch.equal(streamed, tiled)
+    monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY_RAGGED")
+    op.forward_diff_with(ref, x, cnt, mixed_tol=True, ref_device="cpu")
 
 
 def test_moe_layer_end_to_end_matches_the_oracle_chain():
