@@ -1,4 +1,5 @@
-// Grouped GEMM for decode-sized groups (<= 128 rows per group, equal-sized groups, K-major "[N,K]" weights, 16-bit types).
+// Grouped GEMM for decode-sized groups (K-major "[N,K]" weights, 16-bit types): equal-sized groups of <= 128 rows (dense
+// products, the MLA per-head projections) and, in the RAGGED form, groups of any size that average <= 64 rows (MoE experts at decode).
 //
 // With few rows per group the product is a weight STREAM: the 256x256 tile kernel pads every group to 256 rows and spends
 // its time in prologue and epilogue (MLA's per-head projections: 64 rows per head, K = 128 or 512).  Here one workgroup =
