@@ -800,12 +800,13 @@ static int gate_splitk(int64_t tokens, int64_t hidden, int64_t e_pad) {
   return sk < 1 ? 1 : static_cast<int>(sk);
 }
 
-// Few tokens and more than the eight experts the streaming kernel covers: moe_gating_small_kernel (any dtype).
+// Fewer than 512 tokens, and more than the eight experts or fewer than the 32 tokens the streaming kernel covers:
+// moe_gating_small_kernel (any dtype).
 // MOJO_HIP_GATING_SMALL=0/1 forces the choice (read per call).
 static bool gate_use_small(int64_t tokens, int64_t hidden, int64_t experts) {
   if (hidden >= (1LL << 30) || tokens >= (1LL << 24)) return false;
   if (const char* e = getenv("MOJO_HIP_GATING_SMALL")) return e[0] != '0';
-  return tokens <= 256 && experts > 8;
+  return tokens < 512 && (experts > 8 || tokens < 32);                   // (from 512 tokens and 32 experts on the matrix-core route takes over)
 }
 
 extern "C" int64_t mojo_hip_moe_gating_workspace_bytes(int64_t tokens, int64_t hidden_size, int64_t num_experts, int dtype) {
