@@ -84,6 +84,7 @@ bool gemm_mfma256_glu_ok(const GemmArgs& a, int dtype);
 bool gemm_skinny_ok(const GemmArgs& a, int dtype);
 int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups);
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s);
+int launch_gemm_splitk_finalize(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);   // C = round(sum of the fp32 K-slice slabs) (+ bias)
 bool gemm_skinny_ragged_ok(const GemmArgs& a, int dtype, int64_t m_total);        // ragged groups of <= 64 rows on average; prefix arrays for tile height 64
 int launch_gemm_skinny_ragged(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
 int launch_gemm_mfma256_f32out(const GemmArgs& a, int dtype, int accumulate, int64_t m_total, hipStream_t s);

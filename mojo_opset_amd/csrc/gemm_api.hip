@@ -102,8 +102,39 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
   return launch_gemm_mfma256(a, dtype, m_total, s);
 }
 
+// Dense 16-bit products of more than 128 rows with few 256x256 output tiles (a prefill chunk of a few hundred tokens
+// against a 4096..8192-wide projection: 16-64 tiles on 256 CUs): every tile walked the whole K and the launch took the
+// same 68 us (K = 4096) from 129 to 2048 rows, 2-4 x the vendor library's time.  K is cut so that ~256 workgroups run; the
+// slices go to fp32 slabs and launch_gemm_splitk_finalize sums them in slice order (deterministic).
+// MOJO_HIP_GEMM_SPLITK256=<n> forces the split (1 = off; read per call).
+static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n) {
+  if (m <= 128 || n % 4 != 0 || k % 64 != 0) return 1;
+  const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), nkt = k / 64;
+  if (const char* e = getenv("MOJO_HIP_GEMM_SPLITK256")) {
+    int64_t sk = atoi(e);
+    if (sk > nkt / 8) sk = nkt / 8;
+    return sk < 1 ? 1 : static_cast<int>(sk);
+  }
+  // time of a split in us, from measurements on this chip: a workgroup's K-tile takes ~1.06 us (68 us for the 64 K-tiles of
+  // K = 4096), one workgroup per CU, so rounds(tiles * sk) x K-tiles per slice; the slabs are written and read once each at
+  // ~5 TB/s, and the second launch costs ~4 us.  The smallest split within 10 % of the best wins; at least 8 K-tiles per slice.
+  auto cost = [&](int64_t sk) {
+    const double gemm = static_cast<double>(ceil_div(tiles * sk, 256)) * (static_cast<double>(nkt) / sk) * 1.06;
+    return sk == 1 ? gemm : gemm + 2.0 * sk * m * n * 4.0 / 5e6 + 4.0;
+  };
+  int64_t best = 1;
+  double best_cost = cost(1) * 0.9;                     // a split has to gain 10 % before it is worth a second launch
+  for (int64_t sk = 2; sk <= 16 && sk <= nkt / 8; ++sk) {
+    const double c = cost(sk);
+    if (c < best_cost * 0.999) { best = sk; best_cost = c; }
+  }
+  return static_cast<int>(best);
+}
+
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
-  const int sk = gemm_skinny_splitk(m, k, n, 1);
+  int sk = gemm_skinny_splitk(m, k, n, 1);
+  const int sk256 = gemm_dense_splitk256(m, k, n);
+  if (sk256 > sk) sk = sk256;
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
 }
 
@@ -139,6 +170,15 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
     if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {
       a.splitk = sk; a.slab = static_cast<char*>(workspace) + 64; a.slab_rows = static_cast<int>(m);
       if (!gemm_skinny_ok(a, dtype)) { a.splitk = 1; a.slab = nullptr; }
+    }
+  }
+  if (a.splitk == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && !gemm_skinny_ok(a, dtype) && gemm_mfma256_ok(a, dtype)) {
+    const int sk = gemm_dense_splitk256(m, k, n);       // few output tiles: cut K, sum the slices in a second launch
+    if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {
+      a.splitk = sk; a.slab = static_cast<char*>(workspace) + 64; a.slab_rows = static_cast<int>(m);
+      const int rc = launch_gemm_mfma256(a, dtype, m, s);
+      if (rc) return rc;
+      return launch_gemm_splitk_finalize(a, dtype, m, s);
     }
   }
   return run_gemm(a, dtype, m, s);

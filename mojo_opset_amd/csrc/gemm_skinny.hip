@@ -253,14 +253,19 @@ int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
 #undef SKINNY_MT
 #undef SKINNY
   MOJO_CHECK_LAUNCH("gemm_skinny");
-  if (a.splitk > 1) {
-    const int64_t m_total = a.uniform_rows;
-    int64_t blocks = ceil_div(m_total * a.N / 4, 256);
-    if (blocks > 2048) blocks = 2048;
-    if (dtype == MOJO_BF16) hipLaunchKernelGGL(gemm_skinny_finalize_kernel<bf16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, m_total);
-    else hipLaunchKernelGGL(gemm_skinny_finalize_kernel<f16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, m_total);
-    MOJO_CHECK_LAUNCH("gemm_skinny(finalize)");
-  }
+  if (a.splitk > 1) return launch_gemm_splitk_finalize(a, dtype, a.uniform_rows, s);
+  return MOJO_OK;
+}
+
+// C = round(sum over the K slices of slab[s][m][n]) (+ bias): shared by the decode-sized kernel above and the 256x256 tile
+// kernel's dense split (gemm_api.hip); a.slab holds [splitk][m_total][N] fp32, N % 4 == 0.
+int launch_gemm_splitk_finalize(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
+  MOJO_REQUIRE((dtype == MOJO_BF16 || dtype == MOJO_F16) && a.slab && a.N % 4 == 0, MOJO_EUNSUPPORTED, "gemm split-K finalize: preconditions not met");
+  int64_t blocks = ceil_div(m_total * a.N / 4, 256);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == MOJO_BF16) hipLaunchKernelGGL(gemm_skinny_finalize_kernel<bf16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, m_total);
+  else hipLaunchKernelGGL(gemm_skinny_finalize_kernel<f16_t>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a, m_total);
+  MOJO_CHECK_LAUNCH("gemm(split-K finalize)");
   return MOJO_OK;
 }
 

@@ -78,3 +78,35 @@ def test_ragged_decode_groups_integer_data_is_exact(dtype, counts, k, n):
     want = torch_cls("MojoGroupGemm")(w.float(), True)(x.float(), gl).to(dtype)
     got = hip_cls("MojoGroupGemm")(w.to(DEV), True)(x.to(DEV), gl.to(DEV))
     assert torch.equal(to_cpu(got).float(), want.float())
+
+
+@pytest.mark.parametrize("m,k,n,bias", [(129, 4096, 4096, False), (256, 4096, 4096, True), (300, 1024, 520, True), (1000, 8192, 4096, False),
+                                        (513, 512, 260, False), (200, 4160, 4100, True), (1024, 8192, 8192, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_gemm_split_over_k_for_few_output_tiles_is_exact(m, k, n, bias, dtype, monkeypatch):
+    """More than 128 rows but few 256x256 output tiles: K is cut into slices that go to fp32 slabs and a second launch sums
+    them in slice order (gemm_api.hip, gemm_dense_splitk256).  Small-integer data makes every product and partial sum exact,
+    so the split, the unsplit (MOJO_HIP_GEMM_SPLITK256=1) and the fp32 reference must agree to the bit — ragged edges in M
+    and N, bias added after the rounding."""
+    import torch.nn.functional as F
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+    torch.manual_seed(m + n)
+    x = torch.randint(-4, 5, (m, k)).to(dtype).to(DEV)
+    w = torch.randint(-4, 5, (n, k)).to(dtype).to(DEV)
+    b = torch.randint(-8, 9, (n,)).to(dtype).to(DEV) if bias else None
+    want = F.linear(x.float(), w.float()).to(dtype)
+    if b is not None:
+        want = (want.float() + b.float()).to(dtype)
+    got = dense_gemm(x, w, b, False)
+    assert torch.equal(got, want)
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK256", "1")
+    assert torch.equal(dense_gemm(x, w, b, False), want)
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK256", "3")
+    assert torch.equal(dense_gemm(x, w, b, False), want)
+    monkeypatch.delenv("MOJO_HIP_GEMM_SPLITK256")
+    # random data: the split only reorders fp32 partial sums
+    xr, wr = torch.randn(m, k, device=DEV, dtype=dtype), torch.randn(n, k, device=DEV, dtype=dtype)
+    ref = F.linear(xr.float(), wr.float())
+    out = dense_gemm(xr, wr, None, False).float()
+    assert (out - ref).abs().max() <= 1e-2 * ref.abs().max()
+    assert torch.equal(out, dense_gemm(xr, wr, None, False).float())          # same bits on a second launch
