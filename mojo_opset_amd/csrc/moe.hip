@@ -500,6 +500,59 @@ __global__ __launch_bounds__(1024) void moe_scan_kernel(int32_t* __restrict__ bl
   }
 }
 
+// Many experts or many blocks: the same per-expert prefix over the blocks, one wave per expert pair but spread over as many
+// workgroups as there are pairs / 16 (the single workgroup above walks 32 experts per pass and blocks / 64 steps per expert
+// one after the other: 80 us for 256 experts x 256 blocks, 164 us for 1024 experts); the next step's counters are
+// requested before this step's scan.  The experts' totals are then scanned by moe_expert_start_kernel.
+__global__ __launch_bounds__(1024) void moe_block_prefix_kernel(int32_t* __restrict__ block_hist, int blocks, int experts,
+                                                                int32_t* __restrict__ tokens_per_expert) {
+  const int lane = threadIdx.x & 63, wave = static_cast<int>(blockIdx.x) * 16 + (threadIdx.x >> 6);
+  const int e0 = 2 * wave;
+  if (e0 >= experts) return;
+  const int e1 = e0 + 1 < experts ? e0 + 1 : e0;
+  int carry0 = 0, carry1 = 0;
+  auto fetch = [&](int base, int& c0, int& c1) {
+    const int blk = base + lane;
+    const bool live = blk < blocks;
+    c0 = live ? block_hist[static_cast<int64_t>(blk) * experts + e0] : 0;
+    c1 = live ? block_hist[static_cast<int64_t>(blk) * experts + e1] : 0;
+  };
+  int n0, n1;
+  fetch(0, n0, n1);
+  for (int base = 0; base < blocks; base += 64) {
+    const int c0 = n0, c1 = n1;
+    if (base + 64 < blocks) fetch(base + 64, n0, n1);
+    const int blk = base + lane;
+    const int i0 = wave_incl_scan(c0, lane), i1 = wave_incl_scan(c1, lane);
+    if (blk < blocks) {
+      block_hist[static_cast<int64_t>(blk) * experts + e0] = carry0 + i0 - c0;
+      if (e1 != e0) block_hist[static_cast<int64_t>(blk) * experts + e1] = carry1 + i1 - c1;
+    }
+    carry0 += __builtin_amdgcn_readlane(i0, 63);
+    carry1 += __builtin_amdgcn_readlane(i1, 63);
+  }
+  if (lane == 0) {
+    tokens_per_expert[e0] = carry0;
+    if (e1 != e0) tokens_per_expert[e1] = carry1;
+  }
+}
+
+__global__ __launch_bounds__(1024) void moe_expert_start_kernel(const int32_t* __restrict__ tokens_per_expert, int experts,
+                                                                int32_t* __restrict__ expert_start) {
+  __shared__ int s_wave[16];
+  const int chunk = (experts + 1023) / 1024;
+  int local = 0;
+  for (int j = 0; j < chunk; ++j) {
+    const int e = threadIdx.x * chunk + j;
+    if (e < experts) local += tokens_per_expert[e];
+  }
+  int run = block_excl_scan(local, s_wave, nullptr);
+  for (int j = 0; j < chunk; ++j) {
+    const int e = threadIdx.x * chunk + j;
+    if (e < experts) { expert_start[e] = run; run += tokens_per_expert[e]; }
+  }
+}
+
 __global__ __launch_bounds__(256) void moe_scatter_kernel(const float* __restrict__ gates, const int32_t* __restrict__ ids,
                                                           const int32_t* __restrict__ block_hist,
                                                           const int32_t* __restrict__ expert_start,
@@ -932,8 +985,15 @@ extern "C" int mojo_hip_moe_dispatch(const void* hidden, const float* top_k_gate
   int32_t* expert_start = block_hist + static_cast<int64_t>(blocks) * e;
   hipLaunchKernelGGL(moe_hist_kernel, dim3(blocks), dim3(256), e * sizeof(int), s, top_k_indices, n, e, block_hist);
   MOJO_CHECK_LAUNCH("moe_dispatch(hist)");
-  hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), 0, s, block_hist, blocks, e, tokens_per_expert, expert_start);
-  MOJO_CHECK_LAUNCH("moe_dispatch(scan)");
+  if (static_cast<int64_t>(e) * blocks <= 64 * 64) {     // few counters: one workgroup does the block prefix and the experts' scan
+    hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(1024), 0, s, block_hist, blocks, e, tokens_per_expert, expert_start);
+    MOJO_CHECK_LAUNCH("moe_dispatch(scan)");
+  } else {
+    hipLaunchKernelGGL(moe_block_prefix_kernel, dim3(static_cast<unsigned>(ceil_div((e + 1) / 2, 16))), dim3(1024), 0, s, block_hist, blocks, e, tokens_per_expert);
+    MOJO_CHECK_LAUNCH("moe_dispatch(block prefix)");
+    hipLaunchKernelGGL(moe_expert_start_kernel, dim3(1), dim3(1024), 0, s, tokens_per_expert, e, expert_start);
+    MOJO_CHECK_LAUNCH("moe_dispatch(expert start)");
+  }
   const size_t lds = static_cast<size_t>(4) * e * sizeof(int);
   const int k = static_cast<int>(top_k), h = static_cast<int>(hidden_size);
   hipLaunchKernelGGL(moe_scatter_kernel, dim3(blocks), dim3(256), lds, s, top_k_gates, top_k_indices, block_hist, expert_start,
