@@ -56,7 +56,8 @@ struct DecodeArgs {
   void* out;
   float* ws_acc;     // [B*Hkv][chunks][G][D] fp32, un-normalised
   float* ws_ml;      // [B*Hkv][chunks][G][2]  (running max in log2 units, running sum)
-  int hq, hkv, dim, page, page_shift, max_pages, batch;
+  int hq, hkv, dim, page, page_shift, max_pages, batch;   // hkv: kv heads the GRID sees (= real kv heads << hshift)
+  int hshift;                     // 1: groups of 8 query heads run as two 4-head halves of one kv head (see launch), else 0
   int64_t table_stride, c_blk, c_head, c_tok;
   int chunk_tokens, n_chunks;     // launch-wide bound: no sequence is cut into more than n_chunks pieces of <= chunk_tokens
   float scale_log2;
@@ -87,6 +88,14 @@ __device__ __forceinline__ int decode_seq_chunk(const DecodeArgs& a, int seq_len
 // max_len / 4 tokens; a long row paired with a short one leaves every wave ~(len_long + len_short) / 8, the batch mean / 4.
 // A uniform batch gets 4 + 4 waves per pair, i.e. exactly the MODE 1 work per wave.
 constexpr int DEC_SPLIT = 0, DEC_FUSED = 1, DEC_PAIRED = 2;
+
+// query head of (grid kv head kvh, head g of the kernel's G).  With hshift = 1 the grid's kv heads are the halves of the real
+// ones: real kv head kvh >> 1, heads (kvh & 1) * G + g of its 2 G.
+__device__ __forceinline__ int decode_head(const DecodeArgs& a, int kvh, int g, int G) {
+  if (!a.abab) return kvh * G + g;                        // AABB: (real kv head, half, g) is already kvh * G + g
+  const int real = kvh >> a.hshift, half = kvh & ((1 << a.hshift) - 1);
+  return (half * G + g) * (a.hkv >> a.hshift) + real;
+}
 
 template <typename T, int G, bool NT, int MODE>
 __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_kernel(DecodeArgs a) {
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
   V8 qv[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+    const int h = decode_head(a, kvh, g, G);
     V8 z = {};
     const V8 x = *reinterpret_cast<const V8*>(static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + jd);
     qv[g] = dim_ok ? x : z;
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
   };
   if (has_work) scan_issue(0);
 
-  const T* kbase = static_cast<const T*>(a.kc) + kvh * a.c_head + jd;
-  const T* vbase = static_cast<const T*>(a.vc) + kvh * a.c_head + jd;
+  const T* kbase = static_cast<const T*>(a.kc) + (kvh >> a.hshift) * a.c_head + jd;
+  const T* vbase = static_cast<const T*>(a.vc) + (kvh >> a.hshift) * a.c_head + jd;
   const int last_load = ((tok_end - 1) / DEC_TPL) * DEC_TPL;   // first token of the last non-empty load
   const int last_page = a.max_pages - 1;
 
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
       }
       const int n_chunks_seq = ulen <= 0 ? 0 : min((ulen + uchunk - 1) / uchunk, uwaves);
       if (n_chunks_seq == 0 && a.leave_empty) continue;
-      const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+      const int h = decode_head(a, kvh, g, G);
       float mx = -INFINITY;
       for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, s_part[((slot0 + c) * G + g) * stride + a.dim]);
       f32x4 num = {0.f, 0.f, 0.f, 0.f};
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
     // single chunk: finish here, the merge kernel skips this row
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+      const int h = decode_head(a, kvh, g, G);
       const float inv = 1.0f / l[g];
       V8 o;
 #pragma unroll
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a, int G) 
   const int chunk_tokens = decode_seq_chunk(a, seq_len);
   const int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + chunk_tokens - 1) / chunk_tokens;   // <= a.n_chunks by construction
   if (n_chunks_seq == 1) return;                         // (workgroup-uniform)
-  const int h = a.abab ? g * a.hkv + kvh : kvh * G + g;
+  const int h = decode_head(a, kvh, g, G);
   const int cl = threadIdx.x >> 5, dt = threadIdx.x & 31;
   const int d0 = dt * 4;
   const bool live = d0 < a.dim;
@@ -555,7 +564,8 @@ extern "C" int64_t mojo_hip_paged_decode_gqa_workspace_bytes(int64_t batch, int6
                                                              int64_t max_blocks_per_seq, int64_t max_seq_len_hint) {
   if (batch <= 0 || kv_heads <= 0 || q_heads <= 0) return 0;
   const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
-  const int chunk = decode_chunk_tokens(batch, kv_heads, max_len);
+  const int64_t grid_heads = kv_heads * (q_heads / kv_heads == 8 ? 2 : 1);        // groups of 8 run as two halves (launch)
+  const int chunk = decode_chunk_tokens(batch, grid_heads, max_len);
   const int64_t n_chunks = ceil_div(max_len > 0 ? max_len : 1, chunk);
   const int64_t slots = batch * kv_heads * n_chunks * (q_heads / kv_heads);
   return slots * (head_dim + 2) * static_cast<int64_t>(sizeof(float)) + 256;
@@ -584,7 +594,7 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
                    aligned_to(key_cache, 16) && aligned_to(value_cache, 16) && aligned_to(query, 16) &&
                    aligned_to(out, 16),
                MOJO_EUNSUPPORTED, "paged_decode_gqa: tensors must be 16-byte aligned with 16-byte row strides");
-  MOJO_REQUIRE(max_blocks_per_seq >= 0 && batch * kv_heads <= 65535, MOJO_EUNSUPPORTED,
+  MOJO_REQUIRE(max_blocks_per_seq >= 0 && batch * kv_heads * 2 <= 65535, MOJO_EUNSUPPORTED,
                "paged_decode_gqa: batch*kv_heads %lld exceeds the grid limit", (long long)(batch * kv_heads));
 
   DecodeArgs a;
@@ -595,13 +605,19 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
   a.table_stride = block_table_stride; a.c_blk = cache_block_stride; a.c_head = cache_head_stride;
   a.c_tok = cache_token_stride;
   const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
-  a.chunk_tokens = decode_chunk_tokens(batch, kv_heads, max_len);
+  // Groups of 8 query heads per kv head (Llama-3-70B: 64 / 8): the 8-head instance of the kernel needs more registers than a
+  // wave has at two waves per SIMD and spilled its accumulators (B = 64, ctx 4096: 876 us = 1.2 TB/s).  Such a launch runs
+  // the 4-head instance on twice as many grid heads — the two halves of a real kv head read its K/V one after / next to the
+  // other (twice the bytes, a good part of them from L2 / MALL) at the 4-head kernel's rate.
+  int G = static_cast<int>(q_heads / kv_heads);
+  a.hshift = 0;
+  if (G == 8) { a.hshift = 1; a.hkv *= 2; G = 4; }
+  a.chunk_tokens = decode_chunk_tokens(batch, a.hkv, max_len);
   a.n_chunks = static_cast<int>(ceil_div(max_len > 0 ? max_len : 1, a.chunk_tokens));
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.abab = layout_abab ? 1 : 0;
   a.leave_empty = leave_empty_rows ? 1 : 0;
-  const int G = static_cast<int>(q_heads / kv_heads);
-  const int64_t slots = batch * kv_heads * a.n_chunks * G;
+  const int64_t slots = static_cast<int64_t>(batch) * a.hkv * a.n_chunks * G;
   const int64_t need = slots * (head_dim + 2) * static_cast<int64_t>(sizeof(float));
   MOJO_REQUIRE(workspace && workspace_bytes >= need, MOJO_EWORKSPACE,
                "paged_decode_gqa: workspace %lld B < required %lld B", (long long)workspace_bytes, (long long)need);

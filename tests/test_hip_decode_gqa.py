@@ -242,3 +242,29 @@ def test_decode_paired_workgroups_on_ragged_batches(batch, layout, monkeypatch):
     monkeypatch.delenv("MOJO_HIP_DECODE_PAIR")
     # launch-to-launch determinism
     assert torch.equal(op(*dev, max_total_seq_len=700), got)
+
+
+@pytest.mark.parametrize("layout", ["AABB", "ABAB"])
+@pytest.mark.parametrize("batch,hq,hkv,d,lens", [(5, 64, 8, 128, [1, 700, 64, 333, 2049]), (3, 8, 1, 128, [4096, 17, 900]),
+                                                  (2, 32, 4, 96, [150, 1000]), (9, 16, 2, 64, [33] * 9)])
+def test_decode_groups_of_eight_query_heads_run_as_two_halves(batch, hq, hkv, d, lens, layout):
+    """Hq / Hkv = 8 (Llama-3-70B's 64 / 8, or its per-rank 8 / 1 under TP 8): the launch runs the 4-head kernel on the two
+    halves of every kv head (paged_decode_gqa.hip, hshift).  Against the oracle in both head layouts, ragged lengths, the
+    fused, paired and split + merge forms (short and long rows)."""
+    torch.manual_seed(hq + d)
+    page = 16
+    need = [(n + page - 1) // page for n in lens]
+    total = sum(need) + 3
+    k = torch.randn(total, hkv, page, d).to(torch.bfloat16)
+    v = torch.randn(total, hkv, page, d).to(torch.bfloat16)
+    perm = torch.randperm(total, dtype=torch.int32)
+    table = torch.full((batch, max(need)), -1, dtype=torch.int32)
+    at = 0
+    for i, n in enumerate(need):
+        table[i, :n] = perm[at: at + n]
+        at += n
+    q = torch.randn(batch, hq, d).to(torch.bfloat16)
+    sl = torch.tensor(lens, dtype=torch.int32)
+    want = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)(q, k, v, sl, table)
+    got = to_cpu(hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)(q.to(DEV), k.to(DEV), v.to(DEV), sl.to(DEV), table.to(DEV)))
+    assert (got.float() - want.float()).abs().max().item() <= 2e-2
