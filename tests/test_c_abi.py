@@ -48,3 +48,46 @@ def test_loader_reports_version_and_error_text():
     h = L.load()
     assert b"gfx950" in h.mojo_hip_version()
     assert isinstance(h.mojo_hip_last_error(), bytes)
+
+
+def _split_top_level(args: str):
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return out
+
+
+def test_integration_md_stub_passes_what_the_header_declares():
+    """The ctypes stub a maintainer copies from INTEGRATION.md must pass exactly the parameters of the header
+    (a stale stub once passed the stream where `dtype` belongs)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    blocks = re.findall(r"```python\n(.*?)```", doc, flags=re.S)
+    calls = 0
+    for block in blocks:
+        code = re.sub(r"#[^\n]*", "", block)
+        for m in re.finditer(r"lib\.(mojo_hip_[a-z0-9_]+)\(", code):
+            name, start = m.group(1), m.end()
+            depth, i = 1, start
+            while depth and i < len(code):
+                depth += code[i] in "([{"
+                depth -= code[i] in ")]}"
+                i += 1
+            passed = len(_split_top_level(code[start:i - 1]))
+            decl = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S)
+            assert decl, f"INTEGRATION.md calls {name}, which mojo_hip.h does not declare"
+            params = decl.group(1).strip()
+            declared = 0 if params in ("", "void") else params.count(",") + 1
+            assert passed == declared, f"INTEGRATION.md passes {passed} arguments to {name}; the header declares {declared}"
+            calls += 1
+    assert calls >= 3
