@@ -316,26 +316,32 @@ int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_
  *      mla_unpage: flat row cu[b] + t <- cache[table[b, t / page], 0, t % page, :] for t < kv_len_b (cu = cu_total_seq_lens, or
  *      cu_q_lens when that is NULL), for the compressed latent [.., kv_lora_rank] and the positional key [.., rope_dim];
  *      strides in elements; max_tokens_per_seq only sizes the grid; flat rows are relative to cu[0] (the pointers may address a
- *      slice of the batch) and total_keys_out (nullable, int32 [1]) receives cu[batch] - cu[0], the decompression GEMM's
- *      device-side row count.  The decompression kv = c_kv @ kv_b_proj^T is
+ *      slice of the batch) and total_keys_out (nullable, int32 [1]) receives min(cu[batch] - cu[0], capacity_rows), the
+ *      decompression GEMM's device-side row count.  capacity_rows = rows the flat buffers hold: the lengths live on the device
+ *      and the host sizes the buffers without a sync, so a row at or past the capacity is neither written by mla_unpage nor
+ *      read by mla_prefill_attn (the sequence is truncated there, as the paged GQA ops truncate theirs).  The decompression kv = c_kv @ kv_b_proj^T is
  *      mojo_hip_group_gemm with one group whose row count is the device-side total.
  *      mla_prefill_attn: causal flash attention per head over K = [kv[t, h, :nope] | k_pe[t, :]] and V = kv[t, h, nope:],
  *      kv [T_kv, heads, nope + v_dim] and k_pe [T_kv, rope] contiguous, sequence b's keys at rows cu[b] ..; optional fp32
  *      sink logit per head in the softmax denominator; rows of empty sequences read as zeros, and so do the padding rows
- *      behind cu_q_lens[batch] when zero_padding_rows is set (the last slice of a batch processed in slices).  mla_prefill_supported: 1 when (nope, rope, v_dim, dtype) has an instantiation.                  */
+ *      behind cu_q_lens[batch] when zero_padding_rows is set (the last slice of a batch processed in slices).
+ *      round_scaled_scores: 0 = scores rounded to the storage type, scaled in fp32 (the prefill golden, :425); 1 = the scaled
+ *      scores are rounded to the storage type once more (the DECODE golden multiplies storage-type tensors, :215) — used by
+ *      the golden-rounding decode route of MojoPagedDecodeMLA (one query token per sequence).  mla_prefill_supported: 1 when (nope, rope, v_dim, dtype) has an instantiation.                  */
 int mojo_hip_mla_prefill_supported(int64_t nope, int64_t rope, int64_t v_dim, int dtype);
 int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* k_pe_cache, void* ckv_out, void* kpe_out,
                         const int32_t* cu_q_lens, const int32_t* cu_total_seq_lens, const int32_t* block_tables,
                         int64_t block_table_stride, int64_t max_blocks_per_seq, int64_t batch,
                         int64_t kv_lora_rank, int64_t rope_dim, int64_t block_size, int64_t elt_bytes,
                         int64_t ckv_block_stride, int64_t ckv_token_stride, int64_t kpe_block_stride,
-                        int64_t kpe_token_stride, int64_t max_tokens_per_seq, int32_t* total_keys_out,
-                        mojo_stream_t stream);
+                        int64_t kpe_token_stride, int64_t max_tokens_per_seq, int64_t capacity_rows,
+                        int32_t* total_keys_out, mojo_stream_t stream);
 int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decompressed, const void* k_pe_flat,
                               const float* attn_sink, void* out, const int32_t* cu_q_lens,
                               const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
                               int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
-                              float softmax_scale, int zero_padding_rows, int dtype, mojo_stream_t stream);
+                              int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
+                              int zero_padding_rows, int dtype, mojo_stream_t stream);
 
 /* ---- Direct reduce-scatter / all-gather over HIP-IPC peer buffers: the exchange step of MojoGemmAllReduce /
  *      MojoGemmReduceScatter without a ring (core/operators/compute_with_comm.py:57-116, :264-340; role of

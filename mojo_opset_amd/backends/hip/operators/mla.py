@@ -130,16 +130,20 @@ def _mla_forward(op, query, ckv_cache, kpe_cache, block_tables, softmax_scale, *
 
 
 def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tables, softmax_scale, cu_total_seq_lens,
-                          max_total_seq_len=None):
+                          max_total_seq_len=None, round_scaled_scores=False, max_q_len=None):
     """Prefill in the golden's own formulation (experimental/operators/attention.py:405-447): un-page the latent,
     decompress K_nope / V for every key with ONE GEMM (rounded to the storage type, like `c_kv @ kv_b_proj.T`), then flash
     attention per head with D_qk = nope + rope, D_v = v (csrc/mla_prefill.hip).  3.4x fewer FLOPs than running the
     absorbed decode kernel per query token at DeepSeek-V3 dimensions, and the golden's rounding points.
 
-    The decompressed image needs `keys * H * (nope + v)` elements.  Lengths stay on the device, so the host sizes it from
-    what it knows: the table width (`max_total_seq_len` tightens it), and walks the batch in slices of sequences whose
-    image fits `MOJO_HIP_MLA_PREFILL_BYTES`.  Returns None when this route does not apply (dimensions without an
-    instantiation, or ONE sequence's capacity alone exceeds the budget) — the caller then takes the absorbed route."""
+    The decompressed image needs `keys * H * (nope + v)` elements (64 KiB per key at DeepSeek-V3 dimensions).  Lengths stay
+    on the device, so the host sizes it from what it knows: the table width (`max_total_seq_len` tightens it — pass it), and
+    walks the batch in slices of sequences whose image fits `MOJO_HIP_MLA_PREFILL_BYTES` (default 1 GiB: on a serving box
+    most of HBM is KV cache, and the block stays in torch's caching allocator).  The image's row capacity goes to both
+    kernels: a sequence longer than the host's bound is truncated at the capacity (never written or read past it), as the
+    paged GQA ops truncate; `MOJO_HIP_VALIDATE=1` raises instead (one device sync).  Returns None when this route does not
+    apply (dimensions without an instantiation, or ONE sequence's capacity alone exceeds the budget) — the caller then
+    takes the absorbed route."""
     lib = L.load()
     tq, heads, qk = query.shape
     nope, rope, vdim, r = op.qk_nope_head_dim, op.qk_rope_head_dim, op.v_head_dim, op.kv_lora_rank
@@ -152,7 +156,7 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     page = ckv_cache.shape[2]
     es = query.element_size()
     kv_cols = heads * (nope + vdim)
-    budget = int(os.environ.get("MOJO_HIP_MLA_PREFILL_BYTES", str(8 << 30)))
+    budget = int(os.environ.get("MOJO_HIP_MLA_PREFILL_BYTES", str(1 << 30)))
     # host-side bound of one sequence's keys (lengths stay on the device: no sync)
     per_seq = width * page
     if max_total_seq_len is not None:
@@ -176,9 +180,16 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     sink = getattr(op, "attn_sink", None)
     sink = None if sink is None else sink.detach().to(torch.float32).contiguous()
     scale = 1.0 / math.sqrt(nope + rope) if softmax_scale is None else float(softmax_scale)
-    cap = min(seqs_per_slice * per_seq, ckv_cache.shape[0] * page)
+    # (no clamp to the cache's own token count: sequences that share prefix pages sum to more than the cache holds)
+    cap = seqs_per_slice * per_seq
     if cu_total_seq_lens is None:
         cap = min(cap, tq)
+    if os.environ.get("MOJO_HIP_VALIDATE", "0") == "1" and not torch.cuda.is_current_stream_capturing():
+        cu = (cu_q if cu_kv is None else cu_kv).to(torch.int64)
+        longest = int((cu[1:] - cu[:-1]).max()) if batch > 0 else 0
+        if longest > per_seq:
+            raise ValueError(f"HIPPagedPrefillMLA: a sequence holds {longest} keys, above the bound {per_seq} the call was "
+                             "sized for (block table width x page, or max_total_seq_len)")
     ckv_flat = torch.empty(cap, r, dtype=dt, device=dev)
     kpe_flat = torch.empty(cap, rope, dtype=dt, device=dev)
     kv = torch.empty(cap, kv_cols, dtype=dt, device=dev)
@@ -191,7 +202,7 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
         tb = L.c_void_p(tables.data_ptr() + 4 * b0 * tables.stride(0))
         L.check(lib.mojo_hip_mla_unpage(L.ptr(ckv_cache), L.ptr(kpe_cache), L.ptr(ckv_flat), L.ptr(kpe_flat), cq, ck, tb,
                                         tables.stride(0), width, nb, r, rope, page, es, ckv_cache.stride(0),
-                                        ckv_cache.stride(2), kpe_cache.stride(0), kpe_cache.stride(2), per_seq, L.ptr(count),
+                                        ckv_cache.stride(2), kpe_cache.stride(0), kpe_cache.stride(2), per_seq, cap, L.ptr(count),
                                         stream), "hip mla un-page")
         # kv[t, h*(nope+v) + j] = sum_k ckv[t, k] * kv_b_proj[h*(nope+v) + j, k]: one group whose row count is the slice's
         # device-side number of keys, so rows past it are never computed
@@ -199,17 +210,51 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
                                         L.dtype_code(dt), L.ptr(ws), ws.numel(), stream), "hip mla decompression")
         last = b0 + nb >= batch
         L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), cq, ck, tq,
-                                              nb, heads, nope, rope, vdim, min(tq, per_seq), scale, 1 if last else 0,
+                                              nb, heads, nope, rope, vdim,
+                                              min(tq, per_seq) if max_q_len is None else max_q_len, cap, scale,
+                                              1 if round_scaled_scores else 0, 1 if last else 0,
                                               L.dtype_code(dt), stream), "hip mla prefill attention")
     return out
+
+
+def _decode_decompressed(op, query, ckv_cache, kpe_cache, total_seq_lens, block_tables, softmax_scale, max_total_seq_len):
+    """Decode in the golden's own formulation (experimental/operators/attention.py:184-220): every sequence is a one-token
+    "prefill" over its cached keys — un-page, decompress K_nope / V with the GEMM (rounded to the storage type like
+    `c_kv @ kv_b_proj.T`), scores rounded to the storage type before the scale, probabilities rounded to the storage type.
+    It spends 64 KiB of HBM traffic per key where the absorbed kernel spends 1.1 KiB, so it is the selectable PARITY route
+    (`MOJO_HIP_MLA_DECODE=golden` or `op.decode_route = "golden"`), not the default: it reproduces the golden's rounding
+    points and holds the reference test's atol = rtol = 1e-2 against the golden, which the (more accurate) absorbed
+    form cannot where the golden's own rounding error exceeds that bound.  Returns None when the route does not apply."""
+    batch = query.shape[0]
+    dev = query.device
+    lens = total_seq_lens.to(torch.int32).clamp_(min=0)
+    cu_kv = torch.zeros(batch + 1, dtype=torch.int32, device=dev)
+    torch.cumsum(lens, 0, out=cu_kv[1:])
+    cu_q = torch.arange(batch + 1, dtype=torch.int32, device=dev)
+    return _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q, block_tables, softmax_scale, cu_kv, max_total_seq_len,
+                                 round_scaled_scores=True, max_q_len=1)
 
 
 class HIPPagedDecodeMLA(_AbsorbedWeightCache, MojoPagedDecodeMLA):
     supported_platforms_list = _ROCM
 
     def forward(self, query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables,
-                softmax_scale: Optional[float] = None):
+                softmax_scale: Optional[float] = None, *, max_total_seq_len: Optional[int] = None):
+        """``max_total_seq_len`` (extension, kw-only host int): upper bound of any sequence's length; only the
+        golden-rounding route uses it (it sizes the decompressed K/V image)."""
         assert_paged_decode_contract(block_tables, total_seq_lens)
+        route = getattr(self, "decode_route", None) or os.environ.get("MOJO_HIP_MLA_DECODE", "absorbed")
+        if route == "golden" and query.shape[0] > 0 and query.is_cuda \
+                and self.kv_b_proj.dtype == query.dtype == compressed_kv_cache.dtype == k_pe_cache.dtype \
+                and compressed_kv_cache.stride(3) == 1 and k_pe_cache.stride(3) == 1:
+            L.require_cuda(query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables, self.kv_b_proj)
+            if os.environ.get("MOJO_HIP_VALIDATE", "0") == "1" and block_tables.shape[1] > 0 \
+                    and bool(((total_seq_lens > 0) & (block_tables[:, 0] < 0)).any()):
+                raise ValueError("Paged decode requires a valid block table for rows with kv lens > 0.")
+            out = _decode_decompressed(self, query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables,
+                                       softmax_scale, max_total_seq_len)
+            if out is not None:
+                return out
         return _mla_forward(self, query, compressed_kv_cache, k_pe_cache, block_tables, softmax_scale,
                             total_seq_lens=total_seq_lens)
 

@@ -209,6 +209,11 @@ def direct_enabled(group, x: torch.Tensor) -> bool:
     collective library's ring (default until the direct path has been measured on an 8-GPU node)."""
     if group is None or not x.is_cuda:
         return False
+    if torch.cuda.is_current_stream_capturing():
+        # the exchange keeps its epoch / parity on the host and bakes them into kernel arguments: a replay would find every
+        # flag already at the captured epoch and read the peers' partials before they are written.  Captured steps take the
+        # collective library's path.
+        return False
     return os.environ.get("MOJO_HIP_COMM_DIRECT", "0") == "1" and dist.get_world_size(group) > 1
 
 

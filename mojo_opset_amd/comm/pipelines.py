@@ -65,23 +65,45 @@ def _group_info(group):
 
 
 class _Done:
-    """Work handle of a collective that already completed (the host-staged gloo route below)."""
+    """Work handle of a collective that already completed (the synchronous host-staged gloo route below)."""
 
     def wait(self):
         return True
 
 
+class _Staged:
+    """Work handle of an ASYNCHRONOUS gloo collective on a host copy of a device tensor: ``wait()`` waits for the
+    collective and then copies the host result to its device destination (``finish`` does the copy)."""
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self):
+        self._work.wait()
+        self._finish()
+        return True
+
+
 def _host_staged(group, t: torch.Tensor) -> bool:
-    """gloo moves device tensors through the host anyway, and its asynchronous device-tensor collectives proved unreliable
+    """gloo moves device tensors through the host anyway, and its asynchronous DEVICE-tensor collectives proved unreliable
     when several are in flight (an `all_gather_into_tensor` of a 33 MB device tensor hung both ranks of the two-rank GPU
-    test once in three runs).  On a gloo group the exchange therefore runs on explicit host copies, synchronously.  Only
-    the single-GPU multi-rank TESTS use gloo with device tensors; on a node the group is RCCL and this is never taken."""
+    test once in three runs).  On a gloo group the exchange therefore runs on explicit HOST copies.  Only the single-GPU
+    multi-rank TESTS use gloo with device tensors; on a node the group is RCCL and this is never taken."""
     return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _staged_async() -> bool:
+    """On the host-staged route the collective itself is still asynchronous by default (gloo's own threads reduce chunk c
+    while the GEMM of chunk c + 1 runs on the device, several chunks in flight, waited for in order at the end — the same
+    issue / wait ordering the RCCL route has).  ``MOJO_HIP_COMM_GLOO_ASYNC=0`` makes it synchronous."""
+    return os.environ.get("MOJO_HIP_COMM_GLOO_ASYNC", "1") != "0"
 
 
 def _all_reduce(t, group):
     if _host_staged(group, t):
-        h = t.cpu()
+        h = t.cpu()                                                     # (waits for this chunk's GEMM only)
+        if _staged_async():
+            return _Staged(dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group, async_op=True), lambda: t.copy_(h))
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
         t.copy_(h)
         return _Done()
@@ -92,9 +114,15 @@ def _reduce_scatter_tensor(out, buf, group):
     if _host_staged(group, buf):
         ws, rank = _group_info(group)
         h = buf.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)          # gloo has no reduce_scatter for every dtype
         rows = h.shape[0] // ws
-        out.copy_(h[rank * rows:(rank + 1) * rows])
+
+        def finish():
+            out.copy_(h[rank * rows:(rank + 1) * rows])
+
+        if _staged_async():                                             # gloo has no reduce_scatter for every dtype
+            return _Staged(dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group, async_op=True), finish)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        finish()
         return _Done()
     return dist.reduce_scatter_tensor(out, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
 
@@ -102,7 +130,10 @@ def _reduce_scatter_tensor(out, buf, group):
 def _all_gather_into_tensor(buf, x, group):
     if _host_staged(group, x):
         h = torch.empty(buf.shape, dtype=buf.dtype)
-        dist.all_gather_into_tensor(h, x.cpu().contiguous(), group=group)
+        src = x.cpu().contiguous()
+        if _staged_async():
+            return _Staged(dist.all_gather_into_tensor(h, src, group=group, async_op=True), lambda: buf.copy_(h))
+        dist.all_gather_into_tensor(h, src, group=group)
         buf.copy_(h)
         return _Done()
     return dist.all_gather_into_tensor(buf, x.contiguous(), group=group, async_op=True)

@@ -38,14 +38,19 @@ struct UnpageArgs {
   int32_t* count_out;                                          // [1]: total keys of these sequences (the GEMM's row count)
   int64_t table_stride, ckv_blk, ckv_tok, kpe_blk, kpe_tok;     // bytes
   int ckv_row_bytes, kpe_row_bytes, page, max_pages, batch;
+  int capacity_rows;                                           // rows the flat buffers hold: nothing is written at or past it
 };
 
 __global__ __launch_bounds__(256) void mla_unpage_kernel(UnpageArgs a) {
   const int b = blockIdx.y;
   // (flat rows are relative to the first sequence handed in: a caller may pass a slice of the batch)
   const int32_t* cu = a.cu_kv ? a.cu_kv : a.cu_q;
-  const int start = cu[b] - cu[0], len = cu[b + 1] - cu[b];
-  if (a.count_out && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = cu[a.batch] - cu[0];
+  // The host sizes the flat buffers from what it knows without a sync (table width, a caller's hint): lengths above that are
+  // truncated here and — through the same capacity — in the attention kernel, as the paged GQA ops truncate theirs.
+  const int start = cu[b] - cu[0];
+  int len = cu[b + 1] - cu[b];
+  if (len > a.capacity_rows - start) len = a.capacity_rows - start;
+  if (a.count_out && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = min(cu[a.batch] - cu[0], a.capacity_rows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
   for (int t = blockIdx.x * 4 + wave; t < len; t += gridDim.x * 4) {
@@ -72,8 +77,11 @@ struct MlaPfArgs {
   const int32_t* cu_q;
   const int32_t* cu_kv;      // may be null: kv_len = q_len
   int heads, batch, n_qb;
+  int capacity_rows;         // rows of `kv` / `kpe`: keys at or past it do not exist (mla_unpage wrote none)
   int64_t total_tokens;      // rows of `out`; rows behind cu_q[batch] are zeroed when zero_tail is set
-  float scale_log2;
+  float scale_log2;          // softmax_scale * log2(e); log2(e) alone when the scores are scaled before the exponent (below)
+  float pre_scale;           // decode golden: scores = round(round(q k) * softmax_scale) in the storage type (attention.py:215)
+  int round_scaled;          // 1 = apply pre_scale and round once more; 0 = the prefill golden (fp32 scaling, attention.py:425)
   int zero_tail;
   int n_slots;               // dispatch slots per unit: n_qb, made odd (see the kernel)
 };
@@ -144,7 +152,8 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_start = a.cu_kv ? a.cu_kv[b] - a.cu_kv[0] : q_start - a.cu_q[0];      // row in the (slice-relative) flat buffers
-  const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
+  int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
+  if (kv_len > a.capacity_rows - kv_start) kv_len = a.capacity_rows - kv_start;
   if (qb * MPF_QPB >= q_len) return;
 
   const int lane = threadIdx.x & 63;
@@ -329,6 +338,12 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[t][r] = static_cast<float>(static_cast<T>(sc[t][r]));
+      if (a.round_scaled) {                                // wave-uniform: the decode golden multiplies in the storage type
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[t][r] = static_cast<float>(static_cast<T>(sc[t][r] * a.pre_scale));
+      }
       if constexpr (MASKED) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -460,9 +475,11 @@ extern "C" int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* 
                                    int64_t block_table_stride, int64_t max_blocks_per_seq, int64_t batch,
                                    int64_t kv_lora_rank, int64_t rope_dim, int64_t block_size, int64_t elt_bytes,
                                    int64_t ckv_block_stride, int64_t ckv_token_stride, int64_t kpe_block_stride,
-                                   int64_t kpe_token_stride, int64_t max_tokens_per_seq, int32_t* total_keys_out,
-                                   mojo_stream_t stream) {
+                                   int64_t kpe_token_stride, int64_t max_tokens_per_seq, int64_t capacity_rows,
+                                   int32_t* total_keys_out, mojo_stream_t stream) {
   if (batch == 0 || max_tokens_per_seq <= 0) return MOJO_OK;
+  MOJO_REQUIRE(capacity_rows > 0 && capacity_rows < (int64_t{1} << 31), MOJO_EINVAL, "mla_unpage: capacity_rows %lld",
+               (long long)capacity_rows);
   MOJO_REQUIRE(compressed_kv_cache && k_pe_cache && ckv_out && kpe_out && cu_q_lens && block_tables, MOJO_EINVAL,
                "mla_unpage: null pointer");
   MOJO_REQUIRE((kv_lora_rank * elt_bytes) % 16 == 0 && (rope_dim * elt_bytes) % 16 == 0 && aligned_to(compressed_kv_cache, 16) &&
@@ -480,6 +497,7 @@ extern "C" int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* 
   a.kpe_blk = kpe_block_stride * elt_bytes; a.kpe_tok = kpe_token_stride * elt_bytes;
   a.ckv_row_bytes = static_cast<int>(kv_lora_rank * elt_bytes); a.kpe_row_bytes = static_cast<int>(rope_dim * elt_bytes);
   a.page = static_cast<int>(block_size); a.max_pages = static_cast<int>(max_blocks_per_seq); a.batch = static_cast<int>(batch);
+  a.capacity_rows = static_cast<int>(capacity_rows);
   int64_t gx = ceil_div(max_tokens_per_seq, 4);
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(mla_unpage_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(batch)), dim3(256), 0,
@@ -492,8 +510,11 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
                                          const float* attn_sink, void* out, const int32_t* cu_q_lens,
                                          const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
                                          int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
-                                         float softmax_scale, int zero_padding_rows, int dtype, mojo_stream_t stream) {
+                                         int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
+                                         int zero_padding_rows, int dtype, mojo_stream_t stream) {
   if (total_tokens == 0) return MOJO_OK;
+  MOJO_REQUIRE(capacity_rows > 0 && capacity_rows < (int64_t{1} << 31), MOJO_EINVAL, "mla_prefill_attn: capacity_rows %lld",
+               (long long)capacity_rows);
   MOJO_REQUIRE(query && kv_decompressed && k_pe_flat && out && cu_q_lens, MOJO_EINVAL, "mla_prefill_attn: null pointer");
   MOJO_REQUIRE(mojo_hip_mla_prefill_supported(nope, rope, v_dim, dtype), MOJO_EUNSUPPORTED,
                "mla_prefill_attn: (nope, rope, v) = (%lld, %lld, %lld) has no instantiation", (long long)nope, (long long)rope, (long long)v_dim);
@@ -509,11 +530,14 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   a.q = query; a.kv = kv_decompressed; a.kpe = k_pe_flat; a.sink = attn_sink; a.out = out;
   a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens;
   a.heads = static_cast<int>(heads); a.batch = static_cast<int>(batch);
+  a.capacity_rows = static_cast<int>(capacity_rows);
   const int64_t mq = (max_q_len > 0 && max_q_len < total_tokens) ? max_q_len : total_tokens;
   a.n_qb = static_cast<int>(ceil_div(mq, MPF_QPB));
   { const char* e = getenv("MOJO_HIP_MLA_PREFILL_ODD_SLOTS"); a.n_slots = (e && e[0] == '0') ? a.n_qb : (a.n_qb | 1); }
   a.total_tokens = total_tokens;
-  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.round_scaled = round_scaled_scores ? 1 : 0;
+  a.pre_scale = softmax_scale;
+  a.scale_log2 = (round_scaled_scores ? 1.0f : softmax_scale) * 1.4426950408889634f;
   a.zero_tail = zero_padding_rows ? 1 : 0;
 #define MPF_LAUNCH(T)                                                                  \
   (nope == 128 ? launch_mla_pf<T, 4, 2, 4>(a, s) : nope == 64 ? launch_mla_pf<T, 2, 1, 2>(a, s) : launch_mla_pf<T, 3, 1, 4>(a, s))

@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerPtrs pp, int ws, i
   __shared__ int s_ok;
   const int p = (rank + 1 + blockIdx.y) % ws;                               // start with the next rank: links are used evenly
   uint32_t* my_flags = pp.flags[rank];
+  const long long r0 = rows * p / ws, r1 = rows * (p + 1) / ws;
+  if (r1 == r0) return;                                                     // rank p owns no row of this chunk: nothing to wait for
   if (threadIdx.x == 0) s_ok = wait_flag(flag_word(my_flags, 1, p, chunk), epoch, my_flags + PEER_ERR_WORD, timeout_ticks) ? 1 : 0;
   __syncthreads();
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   const bool ok = s_ok != 0;
-  const long long r0 = rows * p / ws, r1 = rows * (p + 1) / ws;
   const int vec_per_row = n / VE;
   const long long total = (r1 - r0) * vec_per_row;
   const char* src = pp.data[p] + chunk_off;
@@ -356,12 +357,15 @@ extern "C" int mojo_hip_peer_reduce(void* const* peer_data, void* const* peer_fl
                                     void* dst, int64_t ld_dst, int write_back, int dtype, mojo_stream_t stream) {
   MOJO_REQUIRE(world >= 1 && world <= PEER_MAX && rank >= 0 && rank < world && chunk >= 0 && chunk < PEER_MAX_CHUNKS,
                MOJO_EINVAL, "peer_reduce: bad arguments");
-  if (rows == 0) return MOJO_OK;
-  MOJO_REQUIRE(dst && rows > 0 && n > 0 && n < (1LL << 31) && src_offset_bytes >= 0, MOJO_EINVAL, "peer_reduce: bad shape");
+  // An empty share (a chunk with fewer rows than ranks: decode-sized M under TP 8) moves no data, but with write_back the
+  // peers' gather step still waits for this rank's "share ready" flag: the launch must run its flag-raising tail.
+  if (rows == 0 && !write_back) return MOJO_OK;
+  MOJO_REQUIRE((dst || rows == 0) && rows >= 0 && n > 0 && n < (1LL << 31) && src_offset_bytes >= 0, MOJO_EINVAL,
+               "peer_reduce: bad shape");
   MOJO_REQUIRE(dtype == MOJO_BF16 || dtype == MOJO_F16 || dtype == MOJO_F32, MOJO_EUNSUPPORTED, "peer_reduce: dtype %d", dtype);
   const int64_t ve = dtype == MOJO_F32 ? 4 : 8;
-  MOJO_REQUIRE(n % ve == 0 && ld_dst % ve == 0 && aligned_to(dst, 16) && src_offset_bytes % 16 == 0, MOJO_EUNSUPPORTED,
-               "peer_reduce: rows must be whole 16-byte vectors");
+  MOJO_REQUIRE(n % ve == 0 && ld_dst % ve == 0 && (rows == 0 || aligned_to(dst, 16)) && src_offset_bytes % 16 == 0,
+               MOJO_EUNSUPPORTED, "peer_reduce: rows must be whole 16-byte vectors");
   PeerPtrs pp;
   MOJO_REQUIRE(fill_ptrs(pp, peer_data, peer_flags, static_cast<int>(world)) == MOJO_OK, MOJO_EINVAL, "peer_reduce: null peer pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -182,6 +182,87 @@ def check_reference_shapes(rank, ws, group):
     _compare(rank, "closed_form:MojoGemmAll2All:32x64x128:float32", got, want, 1e-4)
 
 
+def check_fewer_rows_than_ranks(rank, ws, group):
+    """Decode-sized row counts (M = 1, 3 with two ranks; M < ws in general): some rank's share of a chunk is EMPTY.  That
+    rank must still raise its "share ready" flag (csrc/peer_comm.hip `mojo_hip_peer_reduce`, rows == 0) or its peers'
+    gather step waits until the timeout and poisons every later call.  Checked on the direct exchange and, for the same
+    shapes, on the collective-library pipeline; the other side is the golden's definition in fp32 torch on the device."""
+    import time
+
+    from hip_utils import hip_cls
+    from mojo_opset_amd.comm import peer
+
+    k, n = 1024, 2048
+    for direct in ("1", "0"):
+        os.environ["MOJO_HIP_COMM_DIRECT"] = direct
+        for m in (1, 3, 2 * ws, 5):
+            for dtype in (torch.bfloat16, torch.float32):
+                want = _device_closed_form(ws, rank, m, k, n, dtype, "MojoGemmAllReduce")
+                torch.manual_seed(42 + rank)
+                x = torch.randn(m, k // ws, dtype=dtype).to(DEV)
+                w = torch.randn(k // ws, n, dtype=dtype).to(DEV)
+                t0 = time.time()
+                got = hip_cls("MojoGemmAllReduce")(weight=w, bias=None, trans_weight=True, process_group=group)(x)
+                torch.cuda.synchronize()
+                assert time.time() - t0 < 10, "an empty share stalled the exchange"
+                _compare(rank, f"fp32ref:MojoGemmAllReduce:tiny{'_direct' if direct == '1' else ''}:{m}x{k}x{n}:{str(dtype)[6:]}",
+                         got, want, 5e-3 if dtype != torch.float32 else 2e-4)
+        if direct == "1":
+            assert peer._CACHE, "MOJO_HIP_COMM_DIRECT=1 but no peer exchange was built"
+            for ex in peer._CACHE.values():
+                ex.check()                           # no wait timed out
+    os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+
+
+def check_config4_shapes(rank, ws, group):
+    """BASELINE configs[3] at TP = ws: Llama-3-70B row-parallel GemmAllReduce (down-proj K 28672, o-proj K 8192, N 8192) and
+    column-parallel AllGatherGemm (QKV N 10240, gate|up N 57344), M in {1024, 4096}, bf16, per-rank seed 42 + rank
+    (tests/accuracy/operators/test_compute_with_comm.py:151).  The oracle (golden classes over the same gloo group on CPU)
+    is the other side at a quarter of every dimension; at full size it is the golden's definition in fp32 torch on the device."""
+    from hip_utils import hip_cls, torch_cls
+
+    dtype = torch.bfloat16
+    for scale in (4, 1):
+        for m0 in (1024, 4096):
+            for k0, n0 in ((28672, 8192), (8192, 8192)):
+                m, k, n = m0 // scale, k0 // scale, n0 // scale
+                tag = f"cfg4:{m}x{k}x{n}:tp{ws}"
+                torch.manual_seed(42 + rank)
+                x = torch.randn(m, k // ws, dtype=dtype)
+                w = torch.randn(k // ws, n, dtype=dtype)
+                if scale == 1:
+                    want, side = _device_closed_form(ws, rank, m, k, n, dtype, "MojoGemmAllReduce"), "fp32ref"
+                else:
+                    want = torch.as_tensor(torch_cls("MojoGemmAllReduce")(weight=w, bias=None, trans_weight=True,
+                                                                          process_group=group)(x)).clone()
+                    side = "oracle"
+                got = hip_cls("MojoGemmAllReduce")(weight=w.to(DEV), bias=None, trans_weight=True, process_group=group)(x.to(DEV))
+                torch.cuda.synchronize()
+                _compare(rank, f"{side}:MojoGemmAllReduce:{tag}", got, want, 5e-3)
+                del got, want
+            for n_total in (10240, 57344):
+                m, k, n = m0 // scale, 8192 // scale, n_total // scale // ws
+                tag = f"cfg4:{m}x{k}x{n}:tp{ws}"
+                torch.manual_seed(42)
+                x_full = torch.randn(m, k, dtype=dtype)
+                torch.manual_seed(142 + rank)                   # this rank's column shard of the weight
+                w = torch.randn(n, k, dtype=dtype)
+                ml = m // ws
+                x = x_full[rank * ml:(rank + 1) * ml].contiguous()
+                if scale == 1:
+                    want, side = (x_full.to(DEV).float() @ w.to(DEV).float().t()).to(dtype).cpu(), "fp32ref"
+                else:
+                    want = torch.as_tensor(torch_cls("MojoAllGatherGemm")(weight=w, bias=None, trans_weight=False, gather_dim=0,
+                                                                          process_group=group)(x)).clone()
+                    side = "oracle"
+                got = hip_cls("MojoAllGatherGemm")(weight=w.to(DEV), bias=None, trans_weight=False, gather_dim=0,
+                                                   process_group=group)(x.to(DEV))
+                torch.cuda.synchronize()
+                _compare(rank, f"{side}:MojoAllGatherGemm:{tag}", got, want, 5e-3)
+                del got, want
+        torch.cuda.empty_cache()
+
+
 def check_timeout_path(rank, ws, group):
     """Liveness of the peer exchange: a rank whose peer never shows up must not spin for ever.  Both ranks make one
     normal call (that builds the exchange); then only rank 0 calls again.  Its waits expire (MOJO_HIP_PEER_TIMEOUT_MS), the
@@ -239,6 +320,18 @@ def main():
             if mode == "timeout":
                 _report(rank, mode=mode)
                 check_timeout_path(rank, ws, group)
+                continue
+            if mode == "tiny":
+                _report(rank, mode=mode)
+                os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+                check_fewer_rows_than_ranks(rank, ws, group)
+                continue
+            if mode.startswith("config4"):
+                _report(rank, mode=mode)
+                os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+                if mode.endswith("direct"):
+                    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+                check_config4_shapes(rank, ws, group)
                 continue
             if mode.startswith("chunks"):
                 os.environ["MOJO_HIP_COMM_CHUNKS"] = mode[6:]

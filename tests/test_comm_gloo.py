@@ -154,6 +154,82 @@ def _check_against_oracle(rank, ws, chunks):
     torch.testing.assert_close(got, torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
 
 
+def _check_chunks_in_flight(rank, ws):
+    """The wait ordering of the asynchronous pipelines (comm/pipelines.py gemm_all_reduce / gemm_reduce_scatter /
+    all_gather_gemm): every chunk's collective is ISSUED (async_op=True) before the first one is waited for, the GEMM of
+    chunk c + 1 is enqueued while chunk c's collective is in flight, and the handles are waited for in issue order."""
+    from mojo_opset_amd import comm
+    from mojo_opset_amd.comm import pipelines
+
+    os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+    log = []
+
+    class Spy:
+        def __init__(self, work, tag):
+            self.work, self.tag = work, tag
+
+        def wait(self):
+            log.append(("wait", self.tag))
+            return self.work.wait()
+
+    real = {n: getattr(dist, n) for n in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor")}
+    counter = {"n": 0}
+
+    def wrap(name):
+        def call(*args, **kw):
+            work = real[name](*args, **kw)
+            if kw.get("async_op"):
+                counter["n"] += 1
+                log.append(("issue", counter["n"]))
+                return Spy(work, counter["n"])
+            return work
+        return call
+
+    class LoggingEngine(TorchEngine):
+        def __call__(self, *a, **kw):
+            log.append(("gemm", None))
+            return super().__call__(*a, **kw)
+
+    for name in real:
+        setattr(pipelines.dist, name, wrap(name))
+    try:
+        eng = LoggingEngine()
+        group = dist.group.WORLD
+        torch.manual_seed(3 + rank)
+        m, k, n = 2048 * ws, 64, 48
+        x, w = torch.randn(m, k), torch.randn(k, n) * 0.1
+
+        def run(fn, *extra):
+            log.clear()
+            counter["n"] = 0
+            out = fn(eng, x, w, None, True, group, *extra)
+            issues = [i for i, e in enumerate(log) if e[0] == "issue"]
+            waits = [i for i, e in enumerate(log) if e[0] == "wait"]
+            gemms = [i for i, e in enumerate(log) if e[0] == "gemm"]
+            assert len(issues) == len(waits) >= 3, log
+            assert [log[i][1] for i in waits] == sorted(log[i][1] for i in waits), log      # waited for in issue order
+            return out, issues, waits, gemms
+
+        out, issues, waits, gemms = run(comm.gemm_all_reduce)
+        assert max(issues) < min(waits), "all-reduce: a chunk was waited for before the last one was issued"
+        assert any(issues[0] < g < issues[-1] for g in gemms), "no GEMM was enqueued while a collective was in flight"
+        want = x @ w
+        dist.all_reduce(want)
+        torch.testing.assert_close(out, want, atol=1e-4, rtol=1e-4)
+        out, issues, waits, gemms = run(comm.gemm_reduce_scatter, 0)
+        assert max(issues) < min(waits) and any(issues[0] < g < issues[-1] for g in gemms)
+        out, issues, waits, gemms = run(comm.all_gather_gemm, 0)
+        assert max(issues) < min(waits), "all-gather: every gather is issued up front"
+        assert any(waits[0] < g < waits[-1] for g in gemms), "the GEMM of chunk c must run while later gathers are in flight"
+    finally:
+        for name, fn in real.items():
+            setattr(pipelines.dist, name, fn)
+
+
+def test_pipelines_keep_several_chunks_in_flight():
+    run_dist(_check_chunks_in_flight)
+
+
 def test_pipelines_reproduce_reference_vectors_over_gloo():
     run_dist(_check_vectors, load_golden("compute_with_comm"))
 

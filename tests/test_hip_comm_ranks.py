@@ -78,3 +78,31 @@ def test_hip_peer_exchange_wait_is_bounded(monkeypatch):
     recs = run_ranks("timeout", timeout=120)
     hit = [r for r in recs if r.get("check") == "timeout:MojoGemmAllReduce"]
     assert hit and hit[0]["poisoned"] and hit[0]["reported"] and hit[0]["waited_s"] < 30, recs
+
+
+def test_hip_all_reduce_with_fewer_rows_than_ranks(monkeypatch):
+    """a chunk with fewer rows than ranks leaves some rank an empty share; it must still signal (no stall, no
+    poisoned output).  M = 1, 3, 4, 5 at two ranks, direct exchange and collective pipeline."""
+    monkeypatch.setenv("MOJO_HIP_PEER_TIMEOUT_MS", "5000")
+    recs = run_ranks("tiny", timeout=240)
+    checks = [r["check"] for r in recs if "check" in r]
+    assert len(checks) == 2 * 4 * 2, checks
+    assert sum("tiny_direct" in c for c in checks) == 8
+
+
+def test_hip_compute_comm_config4_shapes_two_ranks():
+    """BASELINE configs[3] (Llama-3-70B, hidden 8192) at TP 2 on the GPU: GemmAllReduce K 28672 / 8192, N 8192 and AllGatherGemm
+    N 10240 / 57344 at M 1024 and 4096 — oracle at a quarter of every dimension, fp32 device reference at full size; both the
+    collective pipeline and the direct exchange."""
+    recs = run_ranks("config4,config4direct", timeout=900)
+    per_mode, mode = {}, None
+    for r in recs:
+        if "mode" in r:
+            mode = r["mode"]
+            per_mode[mode] = []
+        elif "check" in r:
+            per_mode[mode].append(r["check"])
+    assert set(per_mode) == {"config4", "config4direct"}
+    for mode, checks in per_mode.items():
+        assert len(checks) == 2 * 2 * 4, (mode, checks)
+        assert sum(c.startswith("oracle:") for c in checks) == 8 and sum(c.startswith("fp32ref:") for c in checks) == 8

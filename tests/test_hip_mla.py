@@ -343,6 +343,87 @@ def test_mla_decode_on_the_references_own_inputs(cfg):
     assert rec["hip_vs_fp64"] <= 1e-2 * (1.0 + rec["max_abs_exact"])
 
 
+@pytest.mark.parametrize("cfg", [(4, 16, 96, 32, 128, 64, 256, 64), (2, 8, 64, 32, 64, 32, 128, 32), (3, 8, 64, 32, 64, 32, 0, 32)],
+                         ids=["REF0", "REF1", "REF_PADSEQ"])
+def test_mla_decode_golden_route_holds_the_references_bound(cfg, monkeypatch):
+    """The reference's `test_paged_decode_mla` (test_attention.py:1164-1187) AS WRITTEN: its generator, `w = randn_like(
+    kv_b_proj)`, and its bound atol = rtol = 1e-2 AGAINST THE GOLDEN — on the golden-rounding decode route
+    (`MOJO_HIP_MLA_DECODE=golden`: un-page, decompression GEMM rounded to bf16, scores rounded to bf16, scaled and rounded
+    again, probabilities rounded to bf16: experimental/operators/attention.py:196-220).  Also through `decode_route` on the
+    instance, several seeds, and the fp64 triple is logged as for the absorbed route."""
+    b, h, nope, rope, vd, r, s, page = cfg
+    monkeypatch.setenv("MOJO_HIP_MLA_DECODE", "golden")
+    for seed in (0, 1, 2):
+        torch.manual_seed(seed)
+        q, ckv, kpe, lens, table = _ref_decode_data(b, h, nope, rope, r, s, page)
+        ref = torch_cls("MojoPagedDecodeMLA")(h, nope, rope, vd, r).to(torch.bfloat16)
+        w = torch.randn_like(ref.kv_b_proj)
+        op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w, None, DEV)
+        with torch.no_grad():
+            ref.kv_b_proj.copy_(w)
+        golden = ref(q, ckv, kpe, lens, table)
+        got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens.to(DEV), table.to(DEV)))
+        exact = exact_mla(q, ckv, kpe, table, w, None, h, nope, rope, vd, r, lens.tolist())
+        _report_triple(f"decode_mla_golden_route{cfg}_seed{seed}", got, golden, exact)
+        assert got.shape == golden.shape and got.dtype == golden.dtype
+        torch.testing.assert_close(got.float(), golden.float(), atol=1e-2, rtol=1e-2)     # the reference's own assertion
+    # the switch on the instance selects the same route without the environment variable
+    monkeypatch.delenv("MOJO_HIP_MLA_DECODE")
+    absorbed = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens.to(DEV), table.to(DEV)))
+    op.decode_route = "golden"
+    again = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens.to(DEV), table.to(DEV)))
+    assert torch.equal(again, got)
+    if s > 0:
+        assert not torch.equal(absorbed, got)                # (the default route is the absorbed kernel: other rounding points)
+
+
+def test_mla_decode_golden_route_fixtures_sink_and_empty_rows(monkeypatch):
+    """The golden-rounding decode route on the committed fixtures (with and without sink, zero-length rows, ragged
+    lengths) at the reference's bound against the reference's outputs; sequences walked in slices when the decompressed
+    image exceeds the budget; a length above the caller's bound is truncated at the capacity, never written past it."""
+    monkeypatch.setenv("MOJO_HIP_MLA_DECODE", "golden")
+    ran = 0
+    for case in load_golden("paged_mla"):
+        if case["op"] != "MojoPagedDecodeMLA":
+            continue
+        kw = case["ctor"]["kwargs"]
+        h, nope, rope, vd, r = (kw[k] for k in ("num_heads", "qk_nope_head_dim", "qk_rope_head_dim", "v_head_dim", "kv_lora_rank"))
+        from mojo_opset_amd.backends.hip import lib as L
+        if not L.load().mojo_hip_mla_prefill_supported(nope, rope, vd, L.dtype_code(torch.bfloat16)):
+            continue
+        got = run_hip_case(case)
+        torch.testing.assert_close(to_cpu(got).float(), case["out"].float(), atol=1e-2, rtol=1e-2)
+        ran += 1
+    assert ran >= 1
+    # slices: a budget that holds one sequence at a time gives the same bits as one pass
+    h, nope, rope, vd, r, page = 8, 128, 64, 128, 512, 16
+    ckv, kpe, table, w, _ = make_mla([300, 0, 17, 512, 64], h, nope, rope, vd, r, page, seed=5)
+    lens = torch.tensor([300, 0, 17, 512, 64], dtype=torch.int32)
+    torch.manual_seed(6)
+    q = torch.randn(5, h, nope + rope, dtype=torch.bfloat16)
+    op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, False, w, None, DEV)
+    args = (q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens.to(DEV), table.to(DEV))
+    whole = to_cpu(op(*args, max_total_seq_len=512))
+    monkeypatch.setenv("MOJO_HIP_MLA_PREFILL_BYTES", str(512 * h * (nope + vd) * 2))
+    sliced = to_cpu(op(*args, max_total_seq_len=512))
+    assert torch.equal(whole, sliced)
+    assert float(whole[1].abs().max()) == 0.0                 # the empty row reads as zeros (attention.py:184-185)
+    ref = torch_cls("MojoPagedDecodeMLA")(h, nope, rope, vd, r).to(torch.bfloat16)
+    with torch.no_grad():
+        ref.kv_b_proj.copy_(w)
+    torch.testing.assert_close(whole.float(), ref(q, ckv, kpe, lens, table).float(), atol=1e-2, rtol=1e-2)
+    # a bound below the real lengths: the image holds 5 x 128 rows; nothing is written or read at or past its capacity
+    # (sequences that end inside it are complete, the others are cut at it), every output stays finite
+    monkeypatch.delenv("MOJO_HIP_MLA_PREFILL_BYTES")
+    short = to_cpu(op(*args, max_total_seq_len=128))
+    want = ref(q, ckv, kpe, lens, table)
+    torch.testing.assert_close(short[[0, 1, 2]].float(), want[[0, 1, 2]].float(), atol=1e-2, rtol=1e-2)
+    assert torch.isfinite(short.float()).all() and float(short[4].abs().max()) == 0.0
+    monkeypatch.setenv("MOJO_HIP_VALIDATE", "1")
+    with pytest.raises(ValueError):
+        op(*args, max_total_seq_len=128)
+
+
 @pytest.mark.parametrize("cfg", [(2, 8, 64, 32, 64, 32, 48, 32), (3, 8, 64, 32, 64, 32, 0, 32)], ids=["REF0", "REF_PADSEQ"])
 def test_mla_prefill_on_the_references_own_inputs(cfg):
     """`test_paged_prefill_mla` (test_attention.py:1235-1257), same statement as the decode case."""
