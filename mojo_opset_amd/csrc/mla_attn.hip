@@ -43,6 +43,9 @@ struct MlaArgs {
   int64_t table_stride, ckv_blk, ckv_tok, kpe_blk, kpe_tok;
   int heads, page, page_shift, max_pages, batch, n_tiles, n_splits, split_keys;
   float scale_log2;
+  int ps_debug;             // mla512_ps ablation bits (MOJO_HIP_MLA_PS_DEBUG; timing only: 1 no DMA after the first slots, 2 no QK^T, 4 no softmax, 8 no PV)
+  int ps_issuers;           // mla512_ps: waves that issue the LDS-DMA: 2 (the loaders; default) or 6 (loaders + consumers; MOJO_HIP_MLA_PS_ISSUERS=6: measured equal)
+  int ps_prefetch;          // mla512_ps: L2 prefetch ahead of the LDS-DMA (MOJO_HIP_MLA_PS_PREFETCH=1: on; measured slower, default off)
 };
 
 template <typename T> struct mla_mfma;
@@ -56,7 +59,7 @@ template <> struct mla_mfma<f16_t> {
 };
 
 constexpr int MLA_KEYS = 64;
-constexpr int MLA512_DEFAULT_KERNEL = 0;       // 0 oct, 1 pair, 2 ping-pong (dispatch_mla)
+constexpr int MLA512_DEFAULT_KERNEL = 3;       // 0 oct, 1 pair, 2 ping-pong, 3 specialised waves (dispatch_mla)
 
 template <int R, int ROPE> struct mla_geom {
   static constexpr int CH = (R + ROPE) / 8;                               // 16-byte chunks per latent row
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
 #include "mla512_pair.h"
 #include "mla512_oct.h"
 #include "mla512_pp.h"
+#include "mla512_ps.h"
 namespace mojo {
 
 // merge the splits of one (token, head): grid = (Tq, H), a workgroup of NL split lanes x 128 threads (4 latent elements each),
@@ -424,17 +428,23 @@ static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
     const int head_blocks = (a.heads + 63) / 64;
     // MOJO_HIP_MLA_KERNEL: "pp" the ping-pong kernel (32-key tiles, the two waves of a SIMD one segment apart), "oct" two
     // waves per SIMD in lock-step on 64-key tiles, "pair" one wave per SIMD with 32 heads
-    const int which = [] {                               // read per call: the tests switch kernels inside one process
+    int which = [] {                                     // read per call: the tests switch kernels inside one process
       const char* e = getenv("MOJO_HIP_MLA_KERNEL");
       if (!e) return MLA512_DEFAULT_KERNEL;
       if (e[0] == 'p' && e[1] == 'a') return 1;
+      if (e[0] == 'p' && e[1] == 's') return 3;
       if (e[0] == 'p') return 2;
       return 0;
     }();
+    if (which == 3 && a.page_shift < 4) which = 0;       // a loader's 16 rows must share one page id: pages of >= 16 tokens
     if (which == 1) {
       void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
       hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
+    } else if (which == 3) {
+      void (*fn)(MlaArgs) = mla512_ps_kernel<T>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PS_LDS);
+      hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(512), MLA512_PS_LDS, s, a);
     } else if (which == 2) {
       void (*fn)(MlaArgs) = mla512_pp_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PP_LDS);
@@ -525,6 +535,9 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride,
   a.n_splits = mla_splits(q_tokens * ((kv_lora_rank == 512 && rope_dim == 64) ? (heads + 63) / 64 : 1), max_len);
   a.split_keys = static_cast<int>(ceil_div(ceil_div(max_len > 0 ? max_len : 1, a.n_splits), MLA_KEYS) * MLA_KEYS);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  { const char* e = getenv("MOJO_HIP_MLA_PS_DEBUG"); a.ps_debug = e ? atoi(e) : 0; }
+  { const char* e = getenv("MOJO_HIP_MLA_PS_ISSUERS"); a.ps_issuers = (e && e[0] == '6') ? 6 : 2; }
+  { const char* e = getenv("MOJO_HIP_MLA_PS_PREFETCH"); a.ps_prefetch = (e && e[0] == '1') ? 1 : 0; }
   a.part_o = nullptr; a.part_ml = nullptr;
   if (a.n_splits > 1) {
     const int64_t slots = q_tokens * a.n_splits * heads;

@@ -47,7 +47,7 @@ def test_prefill_gqa_is_bit_stable(q_lens, cached):
     _stable(lambda: op(*args, max_q_len=max(q_lens), max_total_seq_len=max(kv_lens), **kw))
 
 
-@pytest.mark.parametrize("kernel", ["oct", "pp", "pair"])
+@pytest.mark.parametrize("kernel", ["ps", "oct", "pp", "pair"])
 def test_mla_decode_is_bit_stable(kernel, monkeypatch):
     b, h, nope, rope, vd, r, page = 16, 128, 128, 64, 128, 512, 16
     g = torch.Generator().manual_seed(2)
