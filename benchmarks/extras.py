@@ -16,11 +16,29 @@ MFMA_I8_PEAK_TOPS = 5000.0
 MFMA_FP8_PEAK_TFLOPS = 5000.0
 
 
-def _time(fn, iters=10, warmup=2, settle_s=0.03, settle_n=None):
+REPEATS = 5            # every figure is the MEDIAN of this many timed regions (min and max are kept beside it)
+_LAST = {}             # statistics of the most recent _time / _time_graph call, picked up by _mfma / _hbm
+
+
+def _summarise(samples):
+    """Median of the repeats (seconds); min / max / count remembered for the record built from it.  One mean over a single
+    region let a 3x outlier (a neighbour's clock ramp, a stray host stall) into a committed evidence file in round 2."""
+    xs = sorted(samples)
+    med = xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+    _LAST.clear()
+    _LAST.update({"t": med, "us_min": xs[0] * 1e6, "us_max": xs[-1] * 1e6, "repeats": len(xs)})
+    return med
+
+
+def _stats(t):
+    return {k: v for k, v in _LAST.items() if k != "t"} if _LAST.get("t") == t else {}
+
+
+def _time(fn, iters=10, warmup=2, settle_s=0.03, settle_n=None, repeats=REPEATS):
     """Eager launches timed with HIP events, after ``warmup`` calls and ``settle_s`` of back-to-back device work (the
     power-management transient after an idle moment, see _time_graph, lasts 10-30 ms).  ``settle_n`` fixes the number of
     settle calls instead: a case that contains collectives must make the SAME number of calls on every rank, and a count
-    derived from a rank's own clock would not."""
+    derived from a rank's own clock would not.  ``repeats`` back-to-back regions of ``iters`` calls; returns their median."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -32,12 +50,14 @@ def _time(fn, iters=10, warmup=2, settle_s=0.03, settle_n=None):
     one = max(e0.elapsed_time(e1) * 1e-3, 1e-6)
     for _ in range(min(200, int(settle_s / one)) if settle_n is None else settle_n):
         fn()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
+    evs[0].record()
+    for r in range(repeats):
+        for _ in range(iters):
+            fn()
+        evs[r + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    return _summarise([evs[r].elapsed_time(evs[r + 1]) / iters * 1e-3 for r in range(repeats)])
 
 
 def _time_graph(fn, reps=20, replays=5, settle_s=0.03, min_timed_s=0.01):
@@ -71,12 +91,15 @@ def _time_graph(fn, reps=20, replays=5, settle_s=0.03, min_timed_s=0.01):
     replays = min(400, max(replays, int(min_timed_s / one) + 1))
     for _ in range(settle):
         graph.replay()
-    e0.record()
-    for _ in range(replays):
-        graph.replay()
-    e1.record()
+    per = max(1, -(-replays // REPEATS))                                # replays per timed region
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(REPEATS + 1)]
+    evs[0].record()
+    for r in range(REPEATS):
+        for _ in range(per):
+            graph.replay()
+        evs[r + 1].record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / (reps * replays) * 1e-3
+    return _summarise([evs[r].elapsed_time(evs[r + 1]) / (reps * per) * 1e-3 for r in range(REPEATS)])
 
 
 def hip(name):
@@ -92,12 +115,12 @@ def _want(case_name):
 
 def _mfma(t, flops, peak=MFMA_BF16_PEAK_TFLOPS):
     tf = flops / t / 1e12
-    return {"us": t * 1e6, "tflops": tf, "frac_of_mfma_peak": tf / peak}
+    return {"us": t * 1e6, "tflops": tf, "frac_of_mfma_peak": tf / peak, **_stats(t)}
 
 
 def _hbm(t, nbytes):
     gbs = nbytes / t / 1e9
-    return {"us": t * 1e6, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    return {"us": t * 1e6, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, **_stats(t)}
 
 
 def group_gemm_case(device, m, k, n, groups, trans, split="balanced", dtype=torch.bfloat16, data="randn"):
