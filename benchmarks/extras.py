@@ -241,6 +241,38 @@ def bench_decode_variants(device):
     return out
 
 
+def bench_decode_geometries(device):
+    """MojoPagedDecodeGQA away from the headline head geometry: Llama-3-70B (64 q / 8 kv heads: groups of EIGHT query heads
+    per kv head), its per-rank shape under TP 8 (8 / 1), and head_dim 64.  B = 64, ctx 4096, page 16, bf16, graph replay."""
+    out = {}
+    page, bsz, ctx = 16, 64, 4096
+    for name, (hq, hkv, d) in {"G8_llama3_70b_64q_8kv_d128_ctx4096": (64, 8, 128), "G8_tp8_8q_1kv_d128_ctx4096": (8, 1, 128),
+                               "G4_32q_8kv_d64_ctx4096": (32, 8, 64)}.items():
+        if not _want(name):
+            continue
+        op = hip("MojoPagedDecodeGQA")(is_causal=True, gqa_layout="AABB")
+        lens = [ctx] * bsz
+        sets = []
+        for _ in range(2):
+            k, v, table = _paged(device, lens, hkv, d, page)
+            q = torch.randn(bsz, hq, d, device=device, dtype=torch.bfloat16)
+            sets.append((q, k, v, torch.tensor(lens, dtype=torch.int32, device=device), table))
+        it = [0]
+
+        def step():
+            q, k, v, ln, tb = sets[it[0] % len(sets)]
+            it[0] += 1
+            return op(q, k, v, ln, tb, max_total_seq_len=ctx)
+        t = _time_graph(step, reps=10, replays=10)
+        nbytes = sum(lens) * hkv * d * 2 * 2 + 2 * bsz * hq * d * 2 + 4 * bsz * (sets[0][4].shape[1] + 1)
+        res = _hbm(t, nbytes)
+        res["tokens_per_s"] = bsz / t
+        out[name] = res
+        del sets
+        torch.cuda.empty_cache()
+    return out
+
+
 def bench_prefill(device):
     out = {}
     hq, hkv, d, page = 32, 8, 128, 16
@@ -693,7 +725,8 @@ def bench_dense_decode(device):
 
 def run_extras(device, world, rank=0):
     out = {}
-    for name, fn in (("MojoPagedDecodeGQA_bf16_other_contexts", bench_decode_variants), ("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
+    for name, fn in (("MojoPagedDecodeGQA_bf16_other_contexts", bench_decode_variants),
+                     ("MojoPagedDecodeGQA_bf16_other_geometries", bench_decode_geometries), ("MojoGroupGemm_bf16", bench_group_gemm), ("MojoQuantGemm", bench_quant_gemm),
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
                      ("MojoPagedPrefillMLA_bf16", bench_mla_prefill),
                      ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),

@@ -162,14 +162,20 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
   const bool dim_ok = j * 8 < a.dim;
   const int jd = dim_ok ? j * 8 : a.dim - 8;          // lanes past a short head re-read its last slice
 
-  // query slices for the G heads of this kv-head (AABB: h = kvh*G + g, ABAB: h = g*Hkv + kvh)
-  V8 qv[G];
+  // query slices for the G heads of this kv-head (AABB: h = kvh*G + g, ABAB: h = g*Hkv + kvh).  The 8-head instance of the
+  // workgroup forms parks them in LDS (its own 16 lanes x 16 B per head, read back four heads at a time): with them in
+  // registers it needs ~10 more than a wave has at two waves per SIMD.
+  constexpr bool Q_LDS = FUSED && G >= 8;
+  V8 qv[Q_LDS ? 1 : G];
+  extern __shared__ float s_part[];                      // [waves][G][dim + 2] partials (+ [waves][G][16 lanes] query slices)
+  V8* const q_lds = reinterpret_cast<V8*>(s_part + (blockDim.x >> 6) * G * (a.dim + 2)) + (wave_id * G) * DEC_LPT + j;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int h = decode_head(a, kvh, g, G);
     V8 z = {};
     const V8 x = *reinterpret_cast<const V8*>(static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + jd);
-    qv[g] = dim_ok ? x : z;
+    if constexpr (Q_LDS) { if (r == 0) q_lds[g * DEC_LPT] = dim_ok ? x : z; }
+    else qv[g] = dim_ok ? x : z;
   }
 
   float m[G], l[G], acc[G][8];
@@ -244,58 +250,80 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
         if (t.lp[u] >= first_neg) { V8 z = {}; t.k[u] = z; t.v[u] = z; }
     }
     const bool full = t0 + DEC_TILE <= tok_end;          // wave-uniform
-    float s[DEC_LOADS][G];
-#pragma unroll
-    for (int u = 0; u < DEC_LOADS; ++u) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          V2 qa = {qv[g][2 * e], qv[g][2 * e + 1]};
-          V2 ka = {t.k[u][2 * e], t.k[u][2 * e + 1]};
-          d = pack8<T>::dot2(qa, ka, d);
-        }
-        s[u][g] = row16_sum(d) * a.scale_log2;
-      }
-    }
-    if (!full) {                                         // last tile of the chunk: mask the tail
+    if (!full) {                                         // last tile of the chunk: slots past the length may hold NaN/Inf
 #pragma unroll
       for (int u = 0; u < DEC_LOADS; ++u) {
-        const bool valid = (t0 + u * DEC_TPL + r) < tok_end;
         V8 z = {};
-        if (!valid) t.v[u] = z;                          // slots past the length may hold NaN/Inf
-#pragma unroll
-        for (int g = 0; g < G; ++g) s[u][g] = valid ? s[u][g] : -INFINITY;
+        if (!((t0 + u * DEC_TPL + r) < tok_end)) t.v[u] = z;
       }
     }
+    // Heads in blocks of GB = 4: eight heads at once need 32 score registers on top of 64 accumulators, 32 query registers
+    // and the tile ring — more than a wave has at two waves per SIMD (the 8-head instance spilled: B 64, ctx 4096, 64 / 8
+    // heads 876 us).  Scores and probabilities of one block are dead before the next block's are formed.
+    constexpr int GB = G < 4 ? G : 4;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      float mx = m[g];
+    for (int g0 = 0; g0 < G; g0 += GB) {
+      float s[DEC_LOADS][GB];
+      V8 qb[GB];
 #pragma unroll
-      for (int u = 0; u < DEC_LOADS; ++u) mx = fmaxf(mx, s[u][g]);
-      const float ms = mx == -INFINITY ? 0.f : mx;       // row r may not have seen a valid token yet
-      const float alpha = exp2f(m[g] - ms);
-      m[g] = mx;
-      float p[DEC_LOADS];
-      float ps = 0.f;
+      for (int gg = 0; gg < GB; ++gg) {
+        if constexpr (Q_LDS) qb[gg] = q_lds[(g0 + gg) * DEC_LPT];   // (written by this wave's own lanes 0-15: no barrier)
+        else qb[gg] = qv[g0 + gg];
+      }
 #pragma unroll
       for (int u = 0; u < DEC_LOADS; ++u) {
-        p[u] = exp2f(s[u][g] - ms);
-        ps += p[u];
-      }
-      l[g] = l[g] * alpha + ps;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = acc[g][e] * alpha;
+        for (int gg = 0; gg < GB; ++gg) {
+          float d = 0.f;
 #pragma unroll
-        for (int u = 0; u < DEC_LOADS; ++u) x = fmaf(p[u], static_cast<float>(t.v[u][e]), x);
-        acc[g][e] = x;
+          for (int e = 0; e < 4; ++e) {
+            V2 qa = {qb[gg][2 * e], qb[gg][2 * e + 1]};
+            V2 ka = {t.k[u][2 * e], t.k[u][2 * e + 1]};
+            d = pack8<T>::dot2(qa, ka, d);
+          }
+          s[u][gg] = row16_sum(d) * a.scale_log2;
+        }
       }
+      if (!full) {                                       // mask the tail
+#pragma unroll
+        for (int u = 0; u < DEC_LOADS; ++u) {
+          const bool valid = (t0 + u * DEC_TPL + r) < tok_end;
+#pragma unroll
+          for (int gg = 0; gg < GB; ++gg) s[u][gg] = valid ? s[u][gg] : -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int gg = 0; gg < GB; ++gg) {
+        const int g = g0 + gg;
+        float mx = m[g];
+#pragma unroll
+        for (int u = 0; u < DEC_LOADS; ++u) mx = fmaxf(mx, s[u][gg]);
+        const float ms = mx == -INFINITY ? 0.f : mx;     // row r may not have seen a valid token yet
+        const float alpha = exp2f(m[g] - ms);
+        m[g] = mx;
+        float p[DEC_LOADS];
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < DEC_LOADS; ++u) {
+          p[u] = exp2f(s[u][gg] - ms);
+          ps += p[u];
+        }
+        l[g] = l[g] * alpha + ps;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = acc[g][e] * alpha;
+#pragma unroll
+          for (int u = 0; u < DEC_LOADS; ++u) x = fmaf(p[u], static_cast<float>(t.v[u][e]), x);
+          acc[g][e] = x;
+        }
+      }
+      if constexpr (GB < G) asm volatile("" ::: "memory");   // keep the blocks apart (the scheduler would interleave them again)
     }
   };
 
-  // three-tile register ring, prefetch distance two tiles (16 KiB in flight per wave)
+  // register ring of tiles: three (prefetch distance two tiles, 16 KiB in flight per wave) — two for the 8-head instance, whose
+  // accumulators take the third tile's registers
+  constexpr int RING = G >= 8 ? 2 : 3;
   Tile ta, tb, tc;
   if (has_work) {
   load_tile(ta, tok_begin);
@@ -305,15 +333,25 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
     scan_issue(base);
     scan_reduce(base);
   }
-  for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DEC_TILE) {
-    if (t0 + 2 * DEC_TILE < tok_end) load_tile(tc, t0 + 2 * DEC_TILE);
-    process(ta, t0);
-    if (t0 + DEC_TILE >= tok_end) break;
-    if (t0 + 3 * DEC_TILE < tok_end) load_tile(ta, t0 + 3 * DEC_TILE);
-    process(tb, t0 + DEC_TILE);
-    if (t0 + 2 * DEC_TILE >= tok_end) break;
-    if (t0 + 4 * DEC_TILE < tok_end) load_tile(tb, t0 + 4 * DEC_TILE);
-    process(tc, t0 + 2 * DEC_TILE);
+  if constexpr (RING == 3) {
+    for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DEC_TILE) {
+      if (t0 + 2 * DEC_TILE < tok_end) load_tile(tc, t0 + 2 * DEC_TILE);
+      process(ta, t0);
+      if (t0 + DEC_TILE >= tok_end) break;
+      if (t0 + 3 * DEC_TILE < tok_end) load_tile(ta, t0 + 3 * DEC_TILE);
+      process(tb, t0 + DEC_TILE);
+      if (t0 + 2 * DEC_TILE >= tok_end) break;
+      if (t0 + 4 * DEC_TILE < tok_end) load_tile(tb, t0 + 4 * DEC_TILE);
+      process(tc, t0 + 2 * DEC_TILE);
+    }
+  } else {
+    for (int t0 = tok_begin; t0 < tok_end; t0 += 2 * DEC_TILE) {
+      process(ta, t0);
+      if (t0 + DEC_TILE >= tok_end) break;
+      if (t0 + 2 * DEC_TILE < tok_end) load_tile(ta, t0 + 2 * DEC_TILE);
+      process(tb, t0 + DEC_TILE);
+      if (t0 + 3 * DEC_TILE < tok_end) load_tile(tb, t0 + 3 * DEC_TILE);
+    }
   }
   }
 
@@ -340,7 +378,6 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
   }
 
   if constexpr (FUSED) {
-    extern __shared__ float s_part[];                    // [n_chunks][G][dim + 2]
     const int stride = a.dim + 2;
     if (r == 0 && dim_ok) {
 #pragma unroll
@@ -417,6 +454,10 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_split_ker
     }
   }
 }
+
+}  // namespace mojo
+#include "paged_decode_mfma.h"
+namespace mojo {
 
 // Merge the chunk partials: grid = (B*Hkv, G), a workgroup of 8 chunk lanes x 32 threads (4 output elements each); rows with
 // seq_len <= 0 become zeros (golden semantics), single-chunk rows were finished by the split kernel.  Chunk lane j takes
@@ -501,14 +542,57 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
   return (hint > 0 && hint < cap) ? hint : cap;
 }
 
+// The matrix-core kernel (paged_decode_mfma.h): pages of a multiple of 16 tokens, head_dim 64 / 128, groups of <= 16 heads.
+// MOJO_HIP_DECODE_MFMA: unset = where it measured faster — groups of >= 8 heads (Llama-3-70B 64 / 8, B 64, ctx 4096: 355 ->
+// 198 us; 8 / 1: 79 -> 44 us), head_dim 64 (149 -> 116 us) — and the group sizes the vector-unit kernel has no instance for;
+// groups of <= 4 heads at head_dim 128 stay on the vector-unit kernel (headline 179 vs 188 us: its loads cover whole
+// 256-byte rows, this kernel's 64-byte row segments); 1 = wherever it applies, 0 = never (read per call).
+static bool decode_use_mfma(const DecodeArgs& a, int G) {
+  if (a.page_shift < 4 || (a.dim != 64 && a.dim != 128) || G > 16) return false;
+  const char* e = getenv("MOJO_HIP_DECODE_MFMA");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return G >= 8 || a.dim == 64 || (G != 1 && G != 2 && G != 4);
+}
+
+template <typename T, bool NT, int MODE>
+static void launch_decode_mfma(const DecodeArgs& a, dim3 grid, dim3 block, int G, hipStream_t s) {
+  const size_t waves = block.x / 64;
+  const size_t lds = (MODE != DEC_SPLIT ? waves * G * (a.dim + 2) * sizeof(float) : 0) + waves * 16 * a.dim * 2;
+  static std::atomic<uint64_t> attr_set{0};             // (per instantiation: dynamic LDS beyond 64 KiB needs the attribute)
+  if (first_call_on_device(attr_set)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma_kernel<T, 4, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma_kernel<T, 2, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }
+  if (a.dim == 128) hipLaunchKernelGGL((decode_mfma_kernel<T, 4, NT, MODE>), grid, block, lds, s, a, G);
+  else hipLaunchKernelGGL((decode_mfma_kernel<T, 2, NT, MODE>), grid, block, lds, s, a, G);
+}
+
 template <typename T, bool NT>
 static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
   static const bool no_fuse = [] { const char* e = getenv("MOJO_HIP_DECODE_FUSE"); return e && e[0] == '0'; }();
   static const bool no_pair = [] { const char* e = getenv("MOJO_HIP_DECODE_PAIR"); return e && e[0] == '0'; }();
+  if (decode_use_mfma(a, G)) {
+    if (a.n_chunks == 4 && batch >= 2 && batch <= 64 && !no_fuse && !no_pair) {
+      launch_decode_mfma<T, NT, DEC_PAIRED>(a, dim3(1, static_cast<unsigned>(((batch + 1) / 2) * a.hkv)), dim3(512), G, s);
+      MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, paired)");
+      return MOJO_OK;
+    }
+    if (a.n_chunks <= 8 && !no_fuse) {
+      launch_decode_mfma<T, NT, DEC_FUSED>(a, dim3(1, static_cast<unsigned>(batch * a.hkv)), dim3(static_cast<unsigned>(64 * a.n_chunks)), G, s);
+      MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, fused)");
+      return MOJO_OK;
+    }
+    launch_decode_mfma<T, NT, DEC_SPLIT>(a, dim3(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv)), dim3(64), G, s);
+    MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, split)");
+    hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv), G), dim3(256), 0, s, a, G);
+    MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
+    return MOJO_OK;
+  }
   if (a.n_chunks == 4 && batch >= 2 && batch <= 64 && a.dim % 4 == 0 && !no_fuse && !no_pair) {
     // four waves per sequence fill the chip once: pair the sequences by length rank and deal each pair's 8 waves by length
     dim3 grid(1, static_cast<unsigned>(((batch + 1) / 2) * a.hkv));
-    const size_t lds = static_cast<size_t>(8) * G * (a.dim + 2) * sizeof(float);
+    const size_t lds = static_cast<size_t>(8) * G * (a.dim + 2) * sizeof(float) + (G >= 8 ? static_cast<size_t>(8) * G * DEC_LPT * 16 : 0);
     switch (G) {
       case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, DEC_PAIRED>), grid, dim3(512), lds, s, a); break;
       case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, DEC_PAIRED>), grid, dim3(512), lds, s, a); break;
@@ -522,7 +606,8 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
   if (a.n_chunks <= 8 && a.dim % 4 == 0 && !no_fuse) {   // all chunks of a (sequence, kv-head) in one workgroup: merged in LDS
     dim3 grid(1, static_cast<unsigned>(batch * a.hkv));
     const dim3 block(static_cast<unsigned>(64 * a.n_chunks));
-    const size_t lds = static_cast<size_t>(a.n_chunks) * G * (a.dim + 2) * sizeof(float);
+    const size_t lds = static_cast<size_t>(a.n_chunks) * G * (a.dim + 2) * sizeof(float) +
+                       (G >= 8 ? static_cast<size_t>(a.n_chunks) * G * DEC_LPT * 16 : 0);
     switch (G) {
       case 1: hipLaunchKernelGGL((decode_split_kernel<T, 1, NT, DEC_FUSED>), grid, block, lds, s, a); break;
       case 2: hipLaunchKernelGGL((decode_split_kernel<T, 2, NT, DEC_FUSED>), grid, block, lds, s, a); break;
@@ -564,10 +649,15 @@ extern "C" int64_t mojo_hip_paged_decode_gqa_workspace_bytes(int64_t batch, int6
                                                              int64_t max_blocks_per_seq, int64_t max_seq_len_hint) {
   if (batch <= 0 || kv_heads <= 0 || q_heads <= 0) return 0;
   const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
-  const int64_t grid_heads = kv_heads * (q_heads / kv_heads == 8 ? 2 : 1);        // groups of 8 run as two halves (launch)
-  const int chunk = decode_chunk_tokens(batch, grid_heads, max_len);
-  const int64_t n_chunks = ceil_div(max_len > 0 ? max_len : 1, chunk);
-  const int64_t slots = batch * kv_heads * n_chunks * (q_heads / kv_heads);
+  // (groups of 8 query heads can run as two 4-head halves on twice the grid heads — MOJO_HIP_DECODE_G8_HALVES=1 —: size for
+  // whichever form cuts the sequences finer)
+  int64_t slots = 0;
+  for (int64_t mult = 1; mult <= (q_heads / kv_heads == 8 ? 2 : 1); ++mult) {
+    const int chunk = decode_chunk_tokens(batch, kv_heads * mult, max_len);
+    const int64_t n_chunks = ceil_div(max_len > 0 ? max_len : 1, chunk);
+    const int64_t sl = batch * kv_heads * n_chunks * (q_heads / kv_heads);
+    if (sl > slots) slots = sl;
+  }
   return slots * (head_dim + 2) * static_cast<int64_t>(sizeof(float)) + 256;
 }
 
@@ -605,13 +695,16 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
   a.table_stride = block_table_stride; a.c_blk = cache_block_stride; a.c_head = cache_head_stride;
   a.c_tok = cache_token_stride;
   const int64_t max_len = decode_max_len(block_size, max_blocks_per_seq, max_seq_len_hint);
-  // Groups of 8 query heads per kv head (Llama-3-70B: 64 / 8): the 8-head instance of the kernel needs more registers than a
-  // wave has at two waves per SIMD and spilled its accumulators (B = 64, ctx 4096: 876 us = 1.2 TB/s).  Such a launch runs
-  // the 4-head instance on twice as many grid heads — the two halves of a real kv head read its K/V one after / next to the
-  // other (twice the bytes, a good part of them from L2 / MALL) at the 4-head kernel's rate.
+  // Groups of 8 query heads per kv head (Llama-3-70B: 64 / 8).  Round 2 ran them as two 4-head halves on twice as many grid
+  // heads (twice the K/V bytes: 360 us at B 64, ctx 4096) because the 8-head instance spilled; the instance now walks its heads
+  // in blocks of four over a two-tile ring with the query slices parked in LDS (232 registers, no spill) and reads K/V once.
+  // MOJO_HIP_DECODE_G8_HALVES=1 selects the halves again (A/B).
   int G = static_cast<int>(q_heads / kv_heads);
   a.hshift = 0;
-  if (G == 8) { a.hshift = 1; a.hkv *= 2; G = 4; }
+  if (G == 8) {
+    const char* e = getenv("MOJO_HIP_DECODE_G8_HALVES");
+    if (e && e[0] == '1') { a.hshift = 1; a.hkv *= 2; G = 4; }
+  }
   a.chunk_tokens = decode_chunk_tokens(batch, a.hkv, max_len);
   a.n_chunks = static_cast<int>(ceil_div(max_len > 0 ? max_len : 1, a.chunk_tokens));
   a.scale_log2 = softmax_scale * 1.4426950408889634f;

@@ -1,0 +1,342 @@
+// decode_mfma_kernel: MojoPagedDecodeGQA with the two contractions on the matrix cores (round 3).
+// Included by paged_decode_gqa.hip (shares DecodeArgs, the chunking rules, decode_head, the merge kernel and the launch forms).
+//
+// The vector-unit kernel (decode_split_kernel) spends ~600 vector instructions per 16-token tile for four query heads and
+// ~1 070 for eight (dot products, DPP butterflies, exponentials and the P V sums, all of them per head): with two waves per
+// SIMD that is a latency-bound stream — groups of eight query heads (Llama-3-70B: 64 / 8) ran at 3.0 TB/s however the K/V
+// bytes were shared.  Here a tile costs ~60 vector instructions whatever the group size:
+//
+//   S^T[16 tokens x 16 heads] = K Q^T      v_mfma_f32_16x16x32: A = the K registers AS LOADED (lane = (token l & 15, dim chunk
+//                                          l >> 4): 16 B per lane and k-step, 64 contiguous bytes of every token row per
+//                                          instruction), B = the query slices (head = l & 15; lanes past the group repeat its
+//                                          last head and are never stored)
+//   online softmax                         lane = (head, tokens 4 g .. 4 g + 3 of every tile): in-lane maximum, one cross-group
+//                                          maximum (two lane-row swaps), lazy reference (rescale O only when it grows by 2^8)
+//   O^T[D x 16 heads] += V^T P^T           v_mfma_f32_16x16x16: B = the four probabilities of the lane (the accumulator layout of
+//                                          S^T IS the B layout: no lane movement), A = V^T from a wave-private 4 KiB LDS image of
+//                                          the tile read with ds_read_b64_tr_b16 (32-byte pairs XOR-swizzled by the token: the
+//                                          eight row blocks of a half-wave land in eight bank slots)
+//
+// The LDS image belongs to ONE wave (LDS operations of a wave execute in order): no barrier anywhere in the loop.  Pages must
+// hold a multiple of 16 tokens (a tile then lies in one page), head_dim 64 or 128, group size <= 16; everything else takes the
+// vector-unit kernel.  Same chunking, pairing, in-LDS merge, workspace layout and hole / empty-row semantics as that kernel.
+#pragma once
+
+namespace mojo {
+
+template <typename T> struct dec_mma;
+template <> struct dec_mma<bf16_t> {
+  typedef bf16x8 frag8;
+  typedef s16x4 frag4;
+  static __device__ __forceinline__ f32x4 qk(frag8 a, frag8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 pv(frag4 a, frag4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ frag4 pack(float p0, float p1, float p2, float p3) {
+    const bf16x4 v = {static_cast<bf16_t>(p0), static_cast<bf16_t>(p1), static_cast<bf16_t>(p2), static_cast<bf16_t>(p3)};
+    return __builtin_bit_cast(frag4, v);
+  }
+  static __device__ __forceinline__ frag4 from_lds(s16x4 v) { return v; }
+};
+template <> struct dec_mma<f16_t> {
+  typedef f16x8 frag8;
+  typedef f16x4 frag4;
+  static __device__ __forceinline__ f32x4 qk(frag8 a, frag8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 pv(frag4 a, frag4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ frag4 pack(float p0, float p1, float p2, float p3) {
+    const f16x4 v = {static_cast<f16_t>(p0), static_cast<f16_t>(p1), static_cast<f16_t>(p2), static_cast<f16_t>(p3)};
+    return v;
+  }
+  static __device__ __forceinline__ frag4 from_lds(s16x4 v) { return __builtin_bit_cast(f16x4, v); }
+};
+
+constexpr int DECM_TILE = 16;
+
+template <typename T, int DK /* head_dim / 32 */, bool NT, int MODE>
+__global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kernel(DecodeArgs a, int G) {
+  constexpr bool FUSED = MODE != DEC_SPLIT;
+  constexpr bool PAIRED = MODE == DEC_PAIRED;
+  constexpr int D = DK * 32, ND = D / 16;               // head_dim, 16-wide d tiles of O^T
+  constexpr int ROWB = D * 2;                           // bytes of a token row
+  constexpr int NP = D / 16;                            // 32-byte pairs per row
+  constexpr int RPB = 8 / NP;                           // rows per 256-byte bank row (1 at D = 128, 2 at D = 64)
+  typedef typename pack8<T>::vec V8;
+  typedef dec_mma<T> MM;
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & 15, g4 = lane >> 4;             // K / V loads: token tl of the tile, dim chunk g4 of each k-step
+  const int wave_id = FUSED ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) : 0;
+  int chunk = FUSED ? wave_id : static_cast<int>(blockIdx.x);
+  int b = blockIdx.y / a.hkv;
+  const int kvh = blockIdx.y % a.hkv;
+
+  int seq_len, chunk_tokens;
+  int pb[2] = {0, -1}, plen[2] = {0, 0}, pchunk[2] = {DEC_TILE, DEC_TILE}, n_first = 8;
+  if constexpr (PAIRED) {                               // (identical to decode_split_kernel: the two launches must agree)
+    const int cap = a.n_chunks * a.chunk_tokens;
+    int len = -1;
+    if (lane < a.batch) len = a.max_pages > 0 ? max(min(a.seq_lens[lane], cap), 0) : 0;
+    int rank = lane;
+    if (__ballot(lane < a.batch && len != __builtin_amdgcn_readfirstlane(len)) != 0) {
+      rank = 0;
+      for (int o = 0; o < a.batch; ++o) {
+        const int lo = __builtin_amdgcn_readlane(len, o);
+        rank += (lo > len || (lo == len && o < lane)) ? 1 : 0;
+      }
+    }
+    const int p = b;
+    const unsigned long long first = __ballot(lane < a.batch && rank == p);
+    const unsigned long long second = __ballot(lane < a.batch && rank == a.batch - 1 - p && a.batch - 1 - p > p);
+    pb[0] = __builtin_ctzll(first);
+    plen[0] = __builtin_amdgcn_readlane(len, pb[0]);
+    if (second) {
+      pb[1] = __builtin_ctzll(second);
+      plen[1] = __builtin_amdgcn_readlane(len, pb[1]);
+    }
+    const int sum = plen[0] + plen[1];
+    n_first = plen[1] <= 0 ? 8 : min(max((8 * plen[0] + sum / 2) / sum, 1), 7);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n_u = u ? 8 - n_first : n_first;
+      int c = n_u > 0 ? (plen[u] + n_u - 1) / n_u : DEC_TILE;
+      c = max(c, 128);
+      pchunk[u] = ((c + DEC_TILE - 1) / DEC_TILE) * DEC_TILE;
+    }
+    const int u = wave_id < n_first ? 0 : 1;
+    b = pb[u];
+    chunk = u ? wave_id - n_first : wave_id;
+    seq_len = b >= 0 ? plen[u] : 0;
+    chunk_tokens = pchunk[u];
+    if (b < 0) b = pb[0];
+  } else {
+    seq_len = a.max_pages > 0 ? decode_seq_len(a, b) : 0;
+    chunk_tokens = decode_seq_chunk(a, seq_len);
+  }
+  const int tok_begin = chunk * chunk_tokens;
+  const bool has_work = seq_len > 0 && tok_begin < seq_len;
+  if (!FUSED && !has_work) return;
+  const int tok_end = has_work ? min(seq_len, tok_begin + chunk_tokens) : tok_begin + 1;
+
+  // query slices: B operand, lane = (head tl, dims 32 s + 8 g4 .. + 7)
+  const int hq_l = min(tl, G - 1);                      // lanes past the group repeat its last head (computed, never stored)
+  typename MM::frag8 qf[DK];
+  {
+    const int h = decode_head(a, kvh, hq_l, G);
+    const T* qp = static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + g4 * 8;
+#pragma unroll
+    for (int s = 0; s < DK; ++s) qf[s] = *reinterpret_cast<const typename MM::frag8*>(qp + s * 32);
+  }
+
+  f32x4 o[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+
+  const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
+  int p1 = (tok_end + a.page - 1) / a.page;
+  int first_neg = 0x7fffffff;
+  if (p1 > a.max_pages) { first_neg = a.max_pages; p1 = a.max_pages; }
+  constexpr int SCAN = 4;
+  int scan_v[SCAN];
+  auto scan_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < SCAN; ++u) {
+      const int idx = base + u * 64 + lane;
+      scan_v[u] = idx < p1 ? table[idx] : 0;
+    }
+  };
+  auto scan_reduce = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < SCAN; ++u) {
+      const unsigned long long neg = __ballot(scan_v[u] < 0);
+      if (neg && first_neg == 0x7fffffff) first_neg = base + u * 64 + __builtin_ctzll(neg);
+    }
+  };
+  if (has_work) scan_issue(0);
+
+  const T* kbase = static_cast<const T*>(a.kc) + (kvh >> a.hshift) * a.c_head + g4 * 8;
+  const T* vbase = static_cast<const T*>(a.vc) + (kvh >> a.hshift) * a.c_head + g4 * 8;
+  const int last_tile = ((tok_end - 1) / DECM_TILE) * DECM_TILE;      // first token of the last non-empty tile
+  const int last_page = a.max_pages - 1;
+
+  struct Tile { V8 k[DK]; V8 v[DK]; int lp; };
+  auto ld = [&](const T* p) -> V8 {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V8*>(p));
+    else return *reinterpret_cast<const V8*>(p);
+  };
+  auto load_tile = [&](Tile& t, int t0) {
+    const int tu = min(t0, last_tile);                    // wave-uniform; 16 | page: the tile lies in one page
+    const int lp = tu >> a.page_shift;
+    t.lp = lp;
+    const int phys = max(table[min(lp, last_page)], 0);
+    const int64_t off = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - (lp << a.page_shift) + tl) * a.c_tok;
+#pragma unroll
+    for (int s = 0; s < DK; ++s) t.k[s] = ld(kbase + off + s * 32);
+#pragma unroll
+    for (int s = 0; s < DK; ++s) t.v[s] = ld(vbase + off + s * 32);
+  };
+
+  // wave-private V image: [16 tokens][ROWB bytes], 32-byte pair pp of row t at pp ^ ((t / RPB) & (NP - 1))
+  extern __shared__ float s_part[];                      // [waves][G][D + 2] partials, then [waves][16 x ROWB] V images
+  const int n_waves = FUSED ? static_cast<int>(blockDim.x >> 6) : 1;
+  char* const v_img = reinterpret_cast<char*>(s_part + (FUSED ? n_waves * G * (D + 2) : 0)) + wave_id * (16 * ROWB);
+  const unsigned v_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(v_img));
+  const int fw = (tl / RPB) & (NP - 1);
+  unsigned w_off[DK];                                    // write: chunk c = 4 s + g4 of row tl
+#pragma unroll
+  for (int s = 0; s < DK; ++s) {
+    const int c = 4 * s + g4;
+    w_off[s] = tl * ROWB + (((c >> 1) ^ fw) << 5) + (c & 1) * 16;
+  }
+  // transposed read of d tile dt: lane (group g4, i = tl): row = token 4 g4 + (i >> 2), columns 16 dt + 4 (i & 3) .. + 3
+  const int rrow = 4 * g4 + (tl >> 2);
+  const int fr = (rrow / RPB) & (NP - 1);
+  const unsigned r_base = v_u32 + rrow * ROWB + (tl & 3) * 8;      // + ((dt ^ fr) << 5)
+
+  auto process = [&](Tile& t, int t0) {
+    if (t.lp >= first_neg) {                             // rare: pages behind a hole read as zeros
+      V8 z = {};
+#pragma unroll
+      for (int s = 0; s < DK; ++s) { t.k[s] = z; t.v[s] = z; }
+    }
+    const bool full = t0 + DECM_TILE <= tok_end;         // wave-uniform
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DK; ++s) sc = MM::qk(__builtin_bit_cast(typename MM::frag8, t.k[s]), qf[s], sc);
+    // stage V while the scores come out of the matrix pipe (rows past the length may hold NaN / Inf: zeros)
+    {
+      const bool vrow_ok = full || (t0 + tl) < tok_end;
+#pragma unroll
+      for (int s = 0; s < DK; ++s) {
+        V8 z = {};
+        *reinterpret_cast<V8*>(v_img + w_off[s]) = vrow_ok ? t.v[s] : z;
+      }
+    }
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = sc[i] * a.scale_log2;
+    if (!full) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (t0 + 4 * g4 + i >= tok_end) x[i] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+    mx = xor_max_16_32(mx);                              // the head's maximum over the tile (all four token groups)
+    float ref = m;
+    if (mx - m > 8.0f) ref = mx;                         // m = -inf: any finite score; NaN (-inf - -inf): keep
+    if (!__all(ref == m)) {
+      const float alpha = m == ref ? 1.f : fast_exp2(m - ref);        // m = -inf: 0 (O and the sum are 0)
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) o[dt] *= alpha;
+      m = ref;
+    }
+    const float ms = m == -INFINITY ? 0.f : m;
+    float p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = fast_exp2(x[i] - ms);
+    l += (p[0] + p[1]) + (p[2] + p[3]);
+    const typename MM::frag4 pf = MM::pack(p[0], p[1], p[2], p[3]);
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const s16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          reinterpret_cast<__attribute__((address_space(3))) s16x4*>(static_cast<uintptr_t>(r_base + ((dt ^ fr) << 5))));
+      o[dt] = MM::pv(MM::from_lds(vt), pf, o[dt]);
+    }
+  };
+
+  Tile ta, tb, tc;
+  if (has_work) {
+    load_tile(ta, tok_begin);
+    if (tok_begin + DECM_TILE < tok_end) load_tile(tb, tok_begin + DECM_TILE);
+    scan_reduce(0);
+    for (int base = 64 * SCAN; base < p1 && first_neg == 0x7fffffff; base += 64 * SCAN) {
+      scan_issue(base);
+      scan_reduce(base);
+    }
+    for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DECM_TILE) {
+      if (t0 + 2 * DECM_TILE < tok_end) load_tile(tc, t0 + 2 * DECM_TILE);
+      process(ta, t0);
+      if (t0 + DECM_TILE >= tok_end) break;
+      if (t0 + 3 * DECM_TILE < tok_end) load_tile(ta, t0 + 3 * DECM_TILE);
+      process(tb, t0 + DECM_TILE);
+      if (t0 + 2 * DECM_TILE >= tok_end) break;
+      if (t0 + 4 * DECM_TILE < tok_end) load_tile(tb, t0 + 4 * DECM_TILE);
+      process(tc, t0 + 2 * DECM_TILE);
+    }
+  }
+
+  // the row sums of the four token groups of a head meet (the reference maximum is already common to them)
+  l = xor_sum_16_32(l);
+  // lane holds head tl, dims 16 dt + 4 g4 + i
+  const bool head_ok = tl < G;
+  if constexpr (FUSED) {
+    const int stride = D + 2;
+    if (head_ok) {
+      float* dst = s_part + (wave_id * G + tl) * stride;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16 + 4 * g4) = o[dt];
+      if (g4 == 0) { dst[D] = m; dst[D + 1] = l; }
+    }
+    __syncthreads();
+    const int per_head = D / 4;
+    typedef typename vec_of<T, 4>::type V4;
+    constexpr int UNITS = PAIRED ? 2 : 1;
+    for (int item = threadIdx.x; item < UNITS * G * per_head; item += blockDim.x) {
+      const int u = item / (G * per_head);
+      const int rest = item - u * (G * per_head);
+      const int g = rest / per_head, d0 = (rest - g * per_head) * 4;
+      int ub, ulen, uchunk, slot0, uwaves;
+      if constexpr (PAIRED) {
+        ub = pb[u]; ulen = plen[u]; uchunk = pchunk[u];
+        slot0 = u ? n_first : 0;
+        uwaves = u ? 8 - n_first : n_first;
+        if (ub < 0) continue;
+      } else {
+        ub = b; ulen = seq_len; uchunk = chunk_tokens; slot0 = 0; uwaves = static_cast<int>(blockDim.x >> 6);
+      }
+      const int n_chunks_seq = ulen <= 0 ? 0 : min((ulen + uchunk - 1) / uchunk, uwaves);
+      if (n_chunks_seq == 0 && a.leave_empty) continue;
+      const int h = decode_head(a, kvh, g, G);
+      float mx = -INFINITY;
+      for (int c = 0; c < n_chunks_seq; ++c) mx = fmaxf(mx, s_part[((slot0 + c) * G + g) * stride + D]);
+      f32x4 num = {0.f, 0.f, 0.f, 0.f};
+      float den = 0.f;
+      for (int c = 0; c < n_chunks_seq; ++c) {
+        const float* src = s_part + ((slot0 + c) * G + g) * stride;
+        const float w = exp2f(src[D] - mx);
+        den = fmaf(w, src[D + 1], den);
+        num += f32x4{src[d0], src[d0 + 1], src[d0 + 2], src[d0 + 3]} * w;
+      }
+      const float inv = n_chunks_seq > 0 ? 1.0f / den : 0.f;
+      V4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = static_cast<T>(num[e] * inv);
+      *reinterpret_cast<V4*>(static_cast<T*>(a.out) + (static_cast<int64_t>(ub) * a.hq + h) * D + d0) = ov;
+    }
+    return;
+  }
+  if (!head_ok) return;
+  const int n_chunks_seq = (seq_len + chunk_tokens - 1) / chunk_tokens;
+  if (n_chunks_seq == 1) {                               // single chunk: finish here, the merge kernel skips this row
+    const int h = decode_head(a, kvh, tl, G);
+    const float inv = 1.0f / l;
+    typedef typename vec_of<T, 4>::type V4;
+    T* dst = static_cast<T*>(a.out) + (static_cast<int64_t>(b) * a.hq + h) * D + 4 * g4;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      V4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = static_cast<T>(o[dt][e] * inv);
+      *reinterpret_cast<V4*>(dst + dt * 16) = ov;
+    }
+    return;
+  }
+  const int64_t slot = (static_cast<int64_t>(blockIdx.y) * a.n_chunks + chunk) * G + tl;
+  float* dst = a.ws_acc + slot * D + 4 * g4;
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt) *reinterpret_cast<f32x4*>(dst + dt * 16) = o[dt];
+  if (g4 == 0) {
+    a.ws_ml[slot * 2 + 0] = m;
+    a.ws_ml[slot * 2 + 1] = l;
+  }
+}
+
+}  // namespace mojo

@@ -247,10 +247,13 @@ def test_decode_paired_workgroups_on_ragged_batches(batch, layout, monkeypatch):
 @pytest.mark.parametrize("layout", ["AABB", "ABAB"])
 @pytest.mark.parametrize("batch,hq,hkv,d,lens", [(5, 64, 8, 128, [1, 700, 64, 333, 2049]), (3, 8, 1, 128, [4096, 17, 900]),
                                                   (2, 32, 4, 96, [150, 1000]), (9, 16, 2, 64, [33] * 9)])
-def test_decode_groups_of_eight_query_heads_run_as_two_halves(batch, hq, hkv, d, lens, layout):
-    """Hq / Hkv = 8 (Llama-3-70B's 64 / 8, or its per-rank 8 / 1 under TP 8): the launch runs the 4-head kernel on the two
-    halves of every kv head (paged_decode_gqa.hip, hshift).  Against the oracle in both head layouts, ragged lengths, the
-    fused, paired and split + merge forms (short and long rows)."""
+@pytest.mark.parametrize("halves", ["0", "1"], ids=["g8", "halves"])
+def test_decode_groups_of_eight_query_heads(batch, hq, hkv, d, lens, layout, halves, monkeypatch):
+    """Hq / Hkv = 8 (Llama-3-70B's 64 / 8, or its per-rank 8 / 1 under TP 8): the 8-head instance of the kernel (heads in
+    blocks of four over a two-tile ring, query slices in LDS: K/V read once; the default) and the round-2 form that runs the
+    4-head kernel on the two halves of every kv head (MOJO_HIP_DECODE_G8_HALVES=1, `hshift`).  Against the oracle in both
+    head layouts, ragged lengths, the fused, paired and split + merge forms (short and long rows)."""
+    monkeypatch.setenv("MOJO_HIP_DECODE_G8_HALVES", halves)
     torch.manual_seed(hq + d)
     page = 16
     need = [(n + page - 1) // page for n in lens]
@@ -266,5 +269,66 @@ def test_decode_groups_of_eight_query_heads_run_as_two_halves(batch, hq, hkv, d,
     q = torch.randn(batch, hq, d).to(torch.bfloat16)
     sl = torch.tensor(lens, dtype=torch.int32)
     want = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)(q, k, v, sl, table)
-    got = to_cpu(hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)(q.to(DEV), k.to(DEV), v.to(DEV), sl.to(DEV), table.to(DEV)))
+    op = hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    dev = (q.to(DEV), k.to(DEV), v.to(DEV), sl.to(DEV), table.to(DEV))
+    got = to_cpu(op(*dev))
     assert (got.float() - want.float()).abs().max().item() <= 2e-2
+    assert torch.equal(to_cpu(op(*dev)), got)                        # launch-to-launch determinism
+
+
+# ---- the matrix-core kernel (csrc/paged_decode_mfma.h) ----------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    # batch, hq, hkv, d, page, lens, dtype
+    (5, 64, 8, 128, 16, [1, 700, 64, 333, 2049], torch.bfloat16),          # G 8: fused form, ragged, a one-token row
+    (64, 32, 8, 128, 16, None, torch.bfloat16),                             # the headline geometry: paired form (G 4)
+    (6, 16, 1, 128, 32, [0, 5, 0, 300, 4097, 31], torch.float16),          # G 16, empty rows, fp16, page 32, split + merge
+    (3, 8, 1, 128, 64, [4096, 17, 900], torch.bfloat16),                    # Llama-3-70B per-rank shape under TP 8
+    (7, 12, 4, 64, 16, [33, 64, 65, 1, 15, 16, 17], torch.bfloat16),        # G 3 (no vector-unit instance), head_dim 64
+    (9, 10, 2, 128, 128, [500] * 9, torch.bfloat16),                         # G 5, large pages
+    (2, 8, 8, 64, 16, [129, 1000], torch.float16),                           # G 1 (MHA), head_dim 64
+], ids=["G8_ragged", "G4_paired", "G16_fp16_split", "G8_tp8", "G3_d64", "G5_page128", "G1_d64"])
+@pytest.mark.parametrize("layout", ["AABB", "ABAB"])
+def test_decode_matrix_core_kernel(cfg, layout, monkeypatch):
+    """MOJO_HIP_DECODE_MFMA=1: QK^T and PV on the matrix cores wherever the kernel applies (pages of a multiple of 16 tokens,
+    head_dim 64 / 128, groups of <= 16 query heads) — against the oracle, bit-stable from launch to launch, equal to the
+    vector-unit kernel within accumulation-order noise where both exist, page relabelling changes no bit."""
+    batch, hq, hkv, d, page, lens, dtype = cfg
+    monkeypatch.setenv("MOJO_HIP_DECODE_MFMA", "1")
+    q, k, v, lens_t, table = make_decode_inputs(batch, hq, hkv, d, 1024, page, dtype=dtype, seed=hq * 7 + d, lens=lens)
+    op = hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
+    want = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)(q, k, v, lens_t, table)
+    dev = [t.to(DEV) for t in (q, k, v, lens_t, table)]
+    got = op(*dev)
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    assert torch.equal(op(*dev), got)
+    if (lens_t <= 0).any():
+        assert torch.count_nonzero(got[(lens_t <= 0).to(DEV)]) == 0
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(k.shape[0], generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel())
+    table2 = torch.where(table >= 0, inv[table.clamp(min=0).long()].to(torch.int32), table)
+    assert torch.equal(op(q.to(DEV), k[perm].to(DEV), v[perm].to(DEV), dev[3], table2.to(DEV)), got)
+    if hq // hkv in (1, 2, 4, 8):
+        monkeypatch.setenv("MOJO_HIP_DECODE_MFMA", "0")
+        plain = op(*dev)
+        torch.testing.assert_close(got.float(), plain.float(), atol=8e-3, rtol=8e-3)
+
+
+def test_decode_matrix_core_kernel_holes_and_replay(monkeypatch):
+    """Pages behind the first negative id read as zero K/V (the golden's `break`), padded rows stay untouched under
+    `leave_empty_rows`, lengths beyond the caller's bound are truncated — on the matrix-core kernel."""
+    monkeypatch.setenv("MOJO_HIP_DECODE_MFMA", "1")
+    q, k, v, lens, table = make_decode_inputs(4, 16, 2, 128, 0, 16, lens=[700, 0, 130, 48], seed=11)
+    table[0, 9] = -1                                                        # a hole inside row 0: tokens 144.. read as zeros
+    ref = torch_cls("MojoPagedDecodeGQA")()
+    want = ref(q, k, v, lens, table)
+    op = hip_cls("MojoPagedDecodeGQA")()
+    dev = [t.to(DEV) for t in (q, k, v, lens, table)]
+    got = op(*dev)
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    again = op(*dev, leave_empty_rows=True)
+    assert torch.equal(again[[0, 2, 3]], got[[0, 2, 3]])
+    short = op(*dev, max_total_seq_len=128)
+    want_short = ref(q, k, v, lens.clamp(max=128), table)
+    assert_close_tree(to_cpu(short), want_short, ATOL, RTOL)
