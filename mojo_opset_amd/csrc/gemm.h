@@ -39,6 +39,7 @@ struct GemmArgs {
   int splitk = 1;
   void* slab = nullptr;
   int slab_rows = 0;
+  int sk_slot = -1;          // decode-sized kernel: >= 0 = combine the K slices inside the launch (splitk_combine.h), ticket slot
 };
 
 // number of M tiles of height bm over all groups

@@ -11,6 +11,7 @@
 //
 // Algorithmic bytes: G*K*N*elt (weights) + M*K*elt * (N/64) (activations, from L2) + M*N*elt.
 #include "gemm.h"
+#include "splitk_combine.h"
 
 namespace mojo {
 
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   constexpr int KB = 128;                                    // elements of K per block
   __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
   __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
   int grp, t0, R, row_base;                                  // group; first row of this block inside the group; rows of the group; the group's first row
@@ -147,22 +149,46 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   T* C = static_cast<T*>(a.C);
   const T* bias = static_cast<const T*>(a.bias);
   typedef typename vec_of<T, 4>::type V4;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int t = t0 + mt * 16 + l15;
-    if (t >= R) continue;
-    if (a.splitk > 1) {                                  // raw fp32 partials of this K slice (dense GEMMs only: G == 1)
-      *reinterpret_cast<f32x4*>(static_cast<float*>(a.slab) + (static_cast<int64_t>(slice) * a.slab_rows + t) * a.N + n) = acc[mt];
-      continue;
-    }
+  auto emit = [&](int t, f32x4 v) {
     V4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[mt][e]);
+    for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(v[e]);
     if (bias) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
     }
     *reinterpret_cast<V4*>(C + static_cast<int64_t>(RAGGED ? row_base + t : map_row(row_base + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
+  };
+  if (a.splitk > 1 && a.sk_slot >= 0) {
+    // raw fp32 partials of this K slice, write-through; the last slice of the tile to arrive sums all of them (splitk_combine.h)
+    const long long slice_bytes = static_cast<long long>(a.slab_rows) * a.N * 4;
+    const sk_rsrc_t rs = splitk_rsrc(a.slab, slice_bytes * a.splitk);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int t = t0 + mt * 16 + l15;
+      if (t < R) splitk_store16(rs, slice * slice_bytes + (static_cast<long long>(t) * a.N + n) * 4, __builtin_bit_cast(u32x4, acc[mt]));
+    }
+    if (!splitk_arrive(a.sk_slot, static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x), a.splitk, &s_last)) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int t = t0 + mt * 16 + l15;
+      if (t >= R) continue;
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int sx = 0; sx < a.splitk; ++sx)               // slice order: the same bits whoever is last
+        sum += __builtin_bit_cast(f32x4, splitk_load16(rs, sx * slice_bytes + (static_cast<long long>(t) * a.N + n) * 4));
+      emit(t, sum);
+    }
+    return;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = t0 + mt * 16 + l15;
+    if (t >= R) continue;
+    if (a.splitk > 1) {                                  // raw fp32 partials of this K slice for the finalize kernel (dense GEMMs only: G == 1)
+      *reinterpret_cast<f32x4*>(static_cast<float*>(a.slab) + (static_cast<int64_t>(slice) * a.slab_rows + t) * a.N + n) = acc[mt];
+      continue;
+    }
+    emit(t, acc[mt]);
   }
 }
 
@@ -240,9 +266,12 @@ int launch_gemm_skinny_ragged(const GemmArgs& a, int dtype, int64_t m_total, hip
   return MOJO_OK;
 }
 
-int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
-  MOJO_REQUIRE(gemm_skinny_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_skinny: preconditions not met");
+int launch_gemm_skinny(const GemmArgs& a_in, int dtype, hipStream_t s) {
+  MOJO_REQUIRE(gemm_skinny_ok(a_in, dtype), MOJO_EUNSUPPORTED, "gemm_skinny: preconditions not met");
+  GemmArgs a = a_in;
   const int mt = (a.uniform_rows + 15) / 16;
+  if (a.splitk > 1)                                      // K slices combined by the last one to arrive, inside this launch
+    a.sk_slot = splitk_take_slot(static_cast<int64_t>(a.N / 64) * a.G * (mt > 4 ? 2 : 1));
   const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G * (mt > 4 ? 2 : 1)), static_cast<unsigned>(a.splitk));
 #define SKINNY(TY, MT_, RB_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_, RB_>), grid, dim3(256), 0, s, a)
 #define SKINNY_MT(TY)                                                                          \
@@ -253,7 +282,7 @@ int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s) {
 #undef SKINNY_MT
 #undef SKINNY
   MOJO_CHECK_LAUNCH("gemm_skinny");
-  if (a.splitk > 1) return launch_gemm_splitk_finalize(a, dtype, a.uniform_rows, s);
+  if (a.splitk > 1 && a.sk_slot < 0) return launch_gemm_splitk_finalize(a, dtype, a.uniform_rows, s);
   return MOJO_OK;
 }
 

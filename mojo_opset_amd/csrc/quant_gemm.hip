@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "gemm256_core.h"
+#include "splitk_combine.h"
 
 namespace mojo {
 
@@ -81,11 +82,12 @@ template <typename TO, bool FP8, int MT, bool NT /* weights read once: non-tempo
 __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                            const float* __restrict__ rs, const bf16_t* __restrict__ cs,
                                                            TO* __restrict__ C, void* __restrict__ slab, int M, int K, int N,
-                                                           int splitk) {
+                                                           int splitk, int sk_slot) {
   typedef typename std::conditional<FP8, f32x4, i32x4>::type acc_t;
   constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
   __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
   __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];        // per wave: its 16 weight rows of a K block
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64 + wave * 16;
@@ -196,6 +198,40 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
     });
   // lane holds rows m = mt*16 + l15, columns n0 + 4g .. +3
   const int n = n0 + 4 * g;
+  auto emit = [&](int m, acc_t v) {
+    const float r = rs[m];
+    typedef typename vec_of<TO, 4>::type V4;
+    V4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x = __fmul_rn(__fmul_rn(static_cast<float>(v[q]), r), static_cast<float>(cs[n + q]));
+      asm volatile("" : "+v"(x));
+      o[q] = elt<TO>::from_f(x);
+    }
+    *reinterpret_cast<V4*>(C + static_cast<int64_t>(m) * N + n) = o;
+  };
+  if (splitk > 1 && sk_slot >= 0) {
+    // raw accumulators of this K slice, write-through; the last slice of the tile to arrive sums all of them in slice order
+    // (splitk_combine.h) and applies the scales: one launch instead of two
+    const long long slice_bytes = static_cast<long long>(M) * N * 4;
+    const sk_rsrc_t rsrc = splitk_rsrc(slab, slice_bytes * splitk);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + l15;
+      if (m < M) splitk_store16(rsrc, slice * slice_bytes + (static_cast<long long>(m) * N + n) * 4, __builtin_bit_cast(u32x4, acc[mt]));
+    }
+    if (!splitk_arrive(sk_slot, static_cast<int>(blockIdx.z * gridDim.x + blockIdx.x), splitk, &s_last)) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + l15;
+      if (m >= M) continue;
+      acc_t sum = acc_t{0, 0, 0, 0};
+      for (int sx = 0; sx < splitk; ++sx)
+        sum += __builtin_bit_cast(acc_t, splitk_load16(rsrc, sx * slice_bytes + (static_cast<long long>(m) * N + n) * 4));
+      emit(m, sum);
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + mt * 16 + l15;
@@ -204,16 +240,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
       acc_t* dst = reinterpret_cast<acc_t*>(static_cast<char*>(slab) + ((static_cast<int64_t>(slice) * M + m) * N + n) * 4);
       *dst = acc[mt];
     } else {
-      const float r = rs[m];
-      typedef typename vec_of<TO, 4>::type V4;
-      V4 o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[mt][q]), r), static_cast<float>(cs[n + q]));
-        asm volatile("" : "+v"(v));
-        o[q] = elt<TO>::from_f(v);
-      }
-      *reinterpret_cast<V4*>(C + static_cast<int64_t>(m) * N + n) = o;
+      emit(m, acc[mt]);
     }
   }
 }
@@ -378,11 +405,12 @@ static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t*
   const uint8_t* W = static_cast<const uint8_t*>(a.W);
   TO* C = static_cast<TO*>(a.C);
   const int M = static_cast<int>(m);
-#define SKINNY(MT_, NT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_, NT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk)
+  const int slot = sk > 1 ? splitk_take_slot(static_cast<int64_t>(grid.x) * grid.z) : -1;   // K slices combined inside the launch
+#define SKINNY(MT_, NT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_, NT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk, slot)
   if (m <= 16) SKINNY(1, true); else if (m <= 32) SKINNY(2, true); else if (m <= 64) SKINNY(4, true); else SKINNY(4, false);
 #undef SKINNY
   MOJO_CHECK_LAUNCH("quant_gemm(skinny)");
-  if (sk > 1) {
+  if (sk > 1 && slot < 0) {
     int64_t blocks = ceil_div(m * a.N, 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
     if (FP8)

@@ -110,3 +110,41 @@ def test_dense_gemm_split_over_k_for_few_output_tiles_is_exact(m, k, n, bias, dt
     out = dense_gemm(xr, wr, None, False).float()
     assert (out - ref).abs().max() <= 1e-2 * ref.abs().max()
     assert torch.equal(out, dense_gemm(xr, wr, None, False).float())          # same bits on a second launch
+
+
+def test_split_k_combined_inside_the_launch_gives_the_finalize_kernels_bits(monkeypatch):
+    """csrc/splitk_combine.h: the last K slice to arrive sums all slices in index order.  Same bits as the two-launch form
+    (the default; MOJO_HIP_SPLITK_INLAUNCH=1 selects the combine), the same bits launch after launch while OTHER products keep the chip unevenly busy (the
+    hand-off must not depend on placement or timing), across more calls than there are ticket slots (64), for bf16, int8
+    and fp8."""
+    from hip_utils import hip_cls
+    torch.manual_seed(3)
+    cases = []
+    for m, k, n in ((64, 8192, 1024), (17, 14336, 512), (128, 8192, 512), (1, 28672, 64)):
+        x = torch.randn(m, k, dtype=torch.bfloat16).to(DEV)
+        w = (torch.randn(n, k, dtype=torch.bfloat16) * 0.05).to(DEV)
+        cases.append(lambda x=x, w=w: dense_gemm(x, w, None, False))
+    for qd in (torch.int8, torch.float8_e4m3fn):
+        for m, k, n in ((128, 7168, 4096), (32, 7168, 4096), (48, 18432, 1024)):
+            op = hip_cls("MojoQuantGemm")(k, n, trans_weight=True, quant_dtype=qd, weight_dtype=qd, device=DEV)
+            if qd == torch.int8:
+                op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8).to(DEV))
+                xq = torch.randint(-127, 128, (m, k), dtype=torch.int8).to(DEV)
+            else:
+                op.weight.copy_(torch.randn(n, k).to(DEV).to(qd))
+                xq = torch.randn(m, k).to(DEV).to(qd)
+            op.weight_scale.fill_(0.01)
+            sc = torch.rand(m).to(DEV)
+            cases.append(lambda op=op, xq=xq, sc=sc: op(xq, sc))
+    monkeypatch.setenv("MOJO_HIP_SPLITK_INLAUNCH", "0")
+    two_launch = [c().clone() for c in cases]
+    monkeypatch.setenv("MOJO_HIP_SPLITK_INLAUNCH", "1")
+    noise_x = torch.randn(4096, 4096, dtype=torch.bfloat16, device=DEV)
+    side = torch.cuda.Stream()
+    for rnd in range(12):                                              # 12 x 10 calls: every ticket slot is used twice
+        with torch.cuda.stream(side):                                  # uneven load next to the products
+            for _ in range(1 + rnd % 3):
+                noise_x @ noise_x
+        for c, want in zip(cases, two_launch):
+            assert torch.equal(c(), want)
+    torch.cuda.synchronize()
