@@ -13,6 +13,9 @@ Given the same initial free list the block tables come out identical to the refe
 of the free list, sequence by sequence — see csrc/page_pool.hip).  Exhaustion cannot raise from a kernel: the launch then
 changes nothing and latches an error word, and `check()` (one device->host copy; call it outside captured regions)
 raises the reference's `ValueError("PagedDummyCache: Out of memory!")`.
+
+Capture note: `max_total_seq_len_hint()` is host state and does not advance under graph replay — captured steps pass a
+static upper bound to the paged ops (see the method's docstring).
 """
 from typing import Optional
 
@@ -50,6 +53,7 @@ class PagedDummyCache:
         self._store_ctx = torch.zeros(batch_size, dtype=torch.int32, device=self.device)   # written by the extend kernel
         self._cu_cache = {}
         self._len_bound = [0] * self.num_layers        # host-side UPPER bound of max(seq_lens[layer]): the kernels' grid hint
+        self._pool_init = self.pool_state.clone()      # device-resident initial state: `reset` copies it without a host sync
         self.store_paged_kv = MojoStorePagedKVCache.get_backend_impl("hip", strict=True)()
 
     # ---- allocator state --------------------------------------------------------------------------------------
@@ -67,10 +71,10 @@ class PagedDummyCache:
             raise ValueError("PagedDummyCache: a sequence outgrew max_position_embeddings (block table too narrow)")
 
     def reset(self) -> None:
-        """Return every block to the pool and forget all sequences (no sync)."""
+        """Return every block to the pool and forget all sequences (no sync: the initial cursor is a device tensor)."""
         self.block_tables.fill_(-1)
         self.seq_lens.zero_()
-        self.pool_state.copy_(torch.tensor([self.total_blocks, 0, 0, 0], dtype=torch.int32), non_blocking=False)
+        self.pool_state.copy_(self._pool_init)
         self._len_bound = [0] * self.num_layers
 
     def _cu_q(self, new_len: int) -> torch.Tensor:
@@ -97,6 +101,9 @@ class PagedDummyCache:
         nl = None
         if new_lens is not None:
             assert new_lens.dtype == torch.int32 and new_lens.shape == (batch,) and new_lens.is_cuda
+            if new_len != 1:                             # (checked BEFORE anything is enqueued: a raise behind the extend launch
+                # would leave blocks popped and written into the table while the lengths never advance)
+                raise NotImplementedError("PagedDummyCache.update: per-row new_lens is supported for decode steps (S = 1)")
             nl = new_lens.contiguous()
         L.check(lib.mojo_hip_page_pool_extend(L.ptr(table), table.stride(0), table.shape[1], L.ptr(lens), L.ptr(nl),
                                               new_len, L.ptr(self.free_blocks), L.ptr(self.pool_state),
@@ -107,8 +114,6 @@ class PagedDummyCache:
         if new_len == 1:
             self.store_paged_kv(k, v, self.k_cache, self.v_cache, table, None, self._store_ctx)
         else:
-            if nl is not None:
-                raise NotImplementedError("PagedDummyCache.update: per-row new_lens is supported for decode steps (S = 1)")
             self.store_paged_kv(k, v, self.k_cache, self.v_cache, table, self._cu_q(new_len), self._store_ctx)
         L.check(lib.mojo_hip_page_pool_advance(L.ptr(lens), L.ptr(nl), new_len, L.ptr(self.pool_state), batch, stream),
                 "PagedDummyCache.update")
@@ -124,7 +129,11 @@ class PagedDummyCache:
         return self.k_cache, self.v_cache, self.block_tables[layer_idx]
 
     def max_total_seq_len_hint(self, layer_idx: int = 0) -> int:
-        """Host-known upper bound of ``max(seq_lens[layer])`` — the `max_total_seq_len=` argument of the paged ops."""
+        """Host-known upper bound of ``max(seq_lens[layer])`` — the `max_total_seq_len=` argument of the paged ops.
+
+        It advances with every EAGER ``update`` call only: a captured step replays the kernels, not this Python counter, and
+        the paged ops clamp lengths to the hint they were captured with.  A captured decode loop must therefore pass a
+        static bound (``max_position_embeddings``, or the length the loop will reach) instead of this value."""
         return min(self._len_bound[layer_idx], self.max_blocks_per_seq * self.block_size)
 
     def get_seq_length(self, layer_idx: int = 0):

@@ -155,3 +155,20 @@ def test_decode_step_with_the_cache_replays_in_a_graph():
         assert torch.equal(cache.k_cache.cpu(), ref.k_cache)
         want = feed() if i < 4 else None
     cache.check()
+
+
+def test_update_rejects_per_row_lengths_on_multi_token_steps_before_touching_the_pool():
+    """the unsupported combination (per-row new_lens with S > 1) must raise BEFORE the extend kernel is
+    enqueued — no block popped, no table entry written, lengths unchanged; `reset()` restores the cursor from a device
+    tensor (no host copy)."""
+    cache = mo.PagedDummyCache(_cfg(1, 2, 64, 128), 3, DEV, block_size=16)
+    k = torch.randn(3, 2, 4, 64, dtype=torch.bfloat16, device=DEV)
+    before = (cache.pool_state.clone(), cache.block_tables.clone(), cache.seq_lens.clone())
+    with pytest.raises(NotImplementedError):
+        cache.update(k, k, 0, new_lens=torch.tensor([4, 0, 2], dtype=torch.int32, device=DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(cache.pool_state, before[0]) and torch.equal(cache.block_tables, before[1]) and torch.equal(cache.seq_lens, before[2])
+    cache.update(k, k, 0)
+    assert cache.num_free_blocks == cache.total_blocks - 3
+    cache.reset()
+    assert cache.num_free_blocks == cache.total_blocks and int(cache.seq_lens.sum()) == 0
