@@ -281,7 +281,8 @@ def bench_prefill(device):
     ragged = torch.randint(512, 1025, (16,), generator=g).tolist()
     for name, (q_lens, cached) in {"4x2048_nocache": ([2048] * 4, [0] * 4), "4x2048_cached2048": ([2048] * 4, [2048] * 4),
                                    "16_ragged_512_1024_nocache": (ragged, [0] * 16),
-                                   "1x16384_nocache": ([16384], [0])}.items():
+                                   "1x16384_nocache": ([16384], [0]),
+                                   "chunked_1x512_cached16384": ([512], [16384])}.items():
         if not _want(name):
             continue
         kv = [a + b for a, b in zip(q_lens, cached)]

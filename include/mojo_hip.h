@@ -245,7 +245,15 @@ int mojo_hip_quant_gemm(const void* input, const void* weight, const float* inpu
 /* ---- MojoPagedPrefillGQA (core/operators/attention.py:315-451; replaces paged_attention_prefill,
  *      backends/ttx/operators/attention.py).  Packed var-len queries [T,Hq,D], causal with offset
  *      kv_len - q_len; cu_total_seq_lens may be NULL (kv_len = q_len).  `out` is fully written: rows of
- *      empty sequences / padding tokens are zeroed.  max_q_len_hint <= 0: use total_tokens as the bound.  */
+ *      empty sequences / padding tokens are zeroed.  max_q_len_hint <= 0: use total_tokens as the bound.
+ *      Launches of few, long blocks (a chunked prefill against a long cache) are cut along the keys: every (query block,
+ *      kv head, sequence) workgroup becomes several that walk a slice of its key tiles and leave fp32 partials in the
+ *      workspace, combined by a merge kernel in slice order.  workspace_bytes() == 0: the launch is not split (workspace may
+ *      be NULL); a workspace that is too small runs the launch unsplit.  max_kv_len_hint <= 0: block_size * max_blocks.   */
+int64_t mojo_hip_paged_prefill_gqa_workspace_bytes(int64_t total_tokens, int64_t batch, int64_t q_heads,
+                                                   int64_t kv_heads, int64_t head_dim, int64_t block_size,
+                                                   int64_t max_blocks_per_seq, int64_t max_q_len_hint,
+                                                   int64_t max_kv_len_hint);
 int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const void* value_cache,
                                const int32_t* cu_q_lens, const int32_t* cu_total_seq_lens,
                                const int32_t* block_tables, void* out, int64_t total_tokens,
@@ -253,8 +261,9 @@ int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const v
                                int64_t block_size, int64_t max_blocks_per_seq,
                                int64_t block_table_stride, int64_t cache_block_stride,
                                int64_t cache_head_stride, int64_t cache_token_stride,
-                               int64_t max_q_len_hint, float softmax_scale, int layout_abab,
-                               int dtype, mojo_stream_t stream);
+                               int64_t max_q_len_hint, int64_t max_kv_len_hint, float softmax_scale,
+                               int layout_abab, int dtype, void* workspace, int64_t workspace_bytes,
+                               mojo_stream_t stream);
 
 /* ---- MoE routing either side of the grouped GEMM (core/operators/moe.py).
  *      gating (:299-316): softmax(hidden.float() @ gate_weight [hidden, E] fp32) over all experts, top-k in descending

@@ -54,8 +54,9 @@ SIGNATURES = {
     "mojo_hip_paged_decode_gqa_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I, _I, _I]),
     "mojo_hip_paged_decode_gqa": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                           c_float, c_int, c_int, c_int, _P]),
-    "mojo_hip_paged_prefill_gqa": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
-                                           c_float, c_int, c_int, _P]),
+    "mojo_hip_paged_prefill_gqa_workspace_bytes": (c_int64, [_I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "mojo_hip_paged_prefill_gqa": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I,
+                                           c_float, c_int, c_int, _P, _I, _P]),
     "mojo_hip_group_gemm_workspace_bytes": (c_int64, [_I]),
     "mojo_hip_group_gemm": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),
     "mojo_hip_group_gemm_swiglu": (c_int, [_P, _P, _P, _P, c_int, _I, _I, _I, _I, c_int, c_int, _P, _I, _P]),

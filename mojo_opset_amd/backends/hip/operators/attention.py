@@ -97,9 +97,15 @@ class HIPPagedPrefillGQA(MojoPagedPrefillGQA):
         cu_kv = None if cu_total_seq_lens is None else cu_total_seq_lens.contiguous()
         scale = 1.0 / math.sqrt(dim) if softmax_scale is None else float(softmax_scale)
         out = torch.empty_like(q)
-        L.check(L.load().mojo_hip_paged_prefill_gqa(
+        lib = L.load()
+        hint_q = int(max_q_len) if max_q_len else 0
+        hint_kv = int(max_total_seq_len) if max_total_seq_len else 0
+        # few, long blocks (a chunked prefill against a long cache) are cut along the keys: fp32 partials + a merge launch
+        ws_bytes = lib.mojo_hip_paged_prefill_gqa_workspace_bytes(tokens, batch, hq, hkv, dim, page, tables.shape[1], hint_q, hint_kv)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device) if ws_bytes > 0 else None
+        L.check(lib.mojo_hip_paged_prefill_gqa(
             L.ptr(q), L.ptr(key_cache), L.ptr(value_cache), L.ptr(cu_q), L.ptr(cu_kv), L.ptr(tables), L.ptr(out),
             tokens, batch, hq, hkv, dim, page, tables.shape[1], tables.stride(0), key_cache.stride(0),
-            key_cache.stride(1), key_cache.stride(2), int(max_q_len) if max_q_len else 0, scale,
-            1 if self.gqa_layout == "ABAB" else 0, L.dtype_code(q.dtype), L.stream_of(q)), "HIPPagedPrefillGQA")
+            key_cache.stride(1), key_cache.stride(2), hint_q, hint_kv, scale,
+            1 if self.gqa_layout == "ABAB" else 0, L.dtype_code(q.dtype), L.ptr(ws), ws_bytes, L.stream_of(q)), "HIPPagedPrefillGQA")
         return out

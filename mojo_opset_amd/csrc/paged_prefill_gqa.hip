@@ -50,6 +50,12 @@ struct PrefillArgs {
   int abab;
   int fast_stage;            // pages are a power of two >= 16 keys and the per-lane offsets fit 32 bits
   int skew;                  // rotate the sequence coordinate by this much per query-block level (0 or 1)
+  // key split (few, long blocks: a chunked prefill against a long cache): every (query block, kv head, sequence) workgroup
+  // becomes `ksplit` workgroups that each walk a slice of the block's key tiles and leave un-normalised fp32 partials;
+  // prefill_merge_kernel combines them.  ksplit == 1: no workspace, the workgroup writes `out` itself.
+  int ksplit;
+  float* ws_o;               // [blocks * ksplit][128 rows][dim]
+  float* ws_ml;              // [blocks * ksplit][128 rows][2]   reference maximum (log2 units), row sum
 };
 
 template <typename T> struct pf_mfma;
@@ -102,7 +108,7 @@ constexpr int PF_TILE_BYTES = PF_KEYS * 256; // 16 KiB per K or V tile
 constexpr int PF_TABLE = 1024;                // block-table entries cached in LDS
 constexpr int PF_LDS = 4 * PF_TILE_BYTES + PF_TABLE * 4 + 16;    // K0 V0 K1 V1 | table slice | first negative page
 
-template <typename T, int G /* q heads per kv head */, int DK /* head_dim / 32 */>
+template <typename T, int G /* q heads per kv head */, int DK /* head_dim / 32 */, bool SPLIT = false /* key split, see PrefillArgs */>
 __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   typedef typename pf_mfma<T>::frag frag;
   constexpr int QPB = 128 / G;               // query positions per workgroup
@@ -116,11 +122,15 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   // blocks of the last ramp.  Consecutive ids also land on consecutive XCDs, so with 8 kv-heads each XCD's L2 holds
   // the K/V of one head.
   const int inner = a.hkv * a.batch;
-  if (static_cast<int>(blockIdx.x) >= a.n_qb * inner) {
+  // (key split: the slices of a block are consecutive workgroups; `wg` is the block's index in the unsplit order)
+  const int ks = SPLIT ? static_cast<int>(blockIdx.x % a.ksplit) : 0;
+  const int wg = SPLIT ? static_cast<int>(blockIdx.x / a.ksplit) : static_cast<int>(blockIdx.x);
+  if (wg >= a.n_qb * inner) {
+    if (SPLIT && ks != 0) return;
     // Trailing workgroups zero the padding tokens behind the last sequence (rows no sequence owns must read as zeros);
     // they sit at the end of the grid, i.e. in the tail of the launch, and replace a memset of the whole output.
-    const int64_t t0 = max(static_cast<int64_t>(a.cu_q[a.batch]), (static_cast<int64_t>(blockIdx.x) - a.n_qb * inner) * PF_ZERO_TOKENS);
-    const int64_t t1 = min(a.total_tokens, (static_cast<int64_t>(blockIdx.x) - a.n_qb * inner + 1) * PF_ZERO_TOKENS);
+    const int64_t t0 = max(static_cast<int64_t>(a.cu_q[a.batch]), (static_cast<int64_t>(wg) - a.n_qb * inner) * PF_ZERO_TOKENS);
+    const int64_t t1 = min(a.total_tokens, (static_cast<int64_t>(wg) - a.n_qb * inner + 1) * PF_ZERO_TOKENS);
     const int64_t row_elems = static_cast<int64_t>(a.hq) * a.dim;            // dim % 8 == 0: 16-byte pieces
     typedef typename vec_of<T, 8>::type V8;
     V8 z;
@@ -130,14 +140,14 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
       *reinterpret_cast<V8*>(static_cast<T*>(a.out) + i) = z;
     return;
   }
-  const int qb = a.n_qb - 1 - static_cast<int>(blockIdx.x / inner);
-  const int rem = static_cast<int>(blockIdx.x % inner);
+  const int qb = a.n_qb - 1 - wg / inner;
+  const int rem = wg % inner;
   // Blocks are dealt to XCDs, and inside an XCD to its shader engines, in strict rotation and in order: with the
   // sequence as a fixed coordinate every block of a long sequence lands on ONE engine, and while its two slots per CU are
   // full the blocks behind it wait although other engines are empty (measured on 16 ragged sequences: 272 workgroups
   // resident for the first 25 us of a 150 us launch, 91 CUs idle).  The sequence coordinate is therefore rotated by
   // one per query-block level, so a sequence's blocks walk over the engines.
-  const int kvh = rem % a.hkv, b = (rem / a.hkv + a.skew * static_cast<int>(blockIdx.x / inner)) % a.batch;
+  const int kvh = rem % a.hkv, b = (rem / a.hkv + a.skew * (wg / inner)) % a.batch;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
@@ -156,10 +166,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   };
   // A sequence longer than the caller's max_q_len hint has rows no query block of this launch covers: they are written
   // as zeros (never left uninitialised) by the workgroup of the sequence's last covered block.
-  if (qb == a.n_qb - 1 && q_len > a.n_qb * QPB) zero_rows(a.n_qb * QPB, q_len);
+  if (qb == a.n_qb - 1 && q_len > a.n_qb * QPB && ks == 0) zero_rows(a.n_qb * QPB, q_len);
   if (qb * QPB >= q_len) return;
   if (kv_len <= 0) {                                     // a sequence without keys: its rows read as zeros
-    zero_rows(qb * QPB, min(q_len, (qb + 1) * QPB));
+    if (ks == 0) zero_rows(qb * QPB, min(q_len, (qb + 1) * QPB));
     return;
   }
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
@@ -180,7 +190,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int pos_hi = min(q_len, (qb + 1) * QPB) - 1;    // last query position of this block
   int kv_hi = min(kv_len, offset + pos_hi + 1);          // keys [0, kv_hi) are visible to some row
   if (kv_hi < 1) kv_hi = 1;
-  const int n_kb = (kv_hi + PF_KEYS - 1) / PF_KEYS;
+  const int n_kb_all = (kv_hi + PF_KEYS - 1) / PF_KEYS;
+  // key tiles [kb_lo, n_kb) of the block belong to this workgroup (unsplit: all of them)
+  const int kb_lo = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * ks / a.ksplit) : 0;
+  const int n_kb = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * (ks + 1) / a.ksplit) : n_kb_all;
 
   // The prologue is a chain of dependent memory round trips (1.5-2 us each on a busy chip) in front of a workgroup that
   // may own only a handful of tiles, so it is kept to two: {Q fragments, page-id window} together, then the first tile.
@@ -348,11 +361,11 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 
   // leading key blocks that every row of this workgroup sees completely need no masking at all; the diagonal /
   // tail / hole blocks run the masked variant.  Two loops, so neither carries the other's state.
-  const int n_full = min(min(kv_len, offset + qb * QPB + 1), first_neg_key) / PF_KEYS;
+  const int n_full = min(min(min(kv_len, offset + qb * QPB + 1), first_neg_key) / PF_KEYS, n_kb);
   const int n_fast = a.fast_stage ? n_full : 0;          // tiles [0, n_fast) may be staged the fast way
 
-  stage(0, 0);
-  int phys_next = a.fast_stage ? page_of_tile(1) : 0;    // page id for the NEXT stage, loaded a tile ahead
+  if (kb_lo < n_kb) stage(kb_lo, kb_lo & 1);
+  int phys_next = a.fast_stage ? page_of_tile(kb_lo + 1) : 0;    // page id for the NEXT stage, loaded a tile ahead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   PF_WG_MARK(0);
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     __builtin_amdgcn_s_barrier();                         // ... and everyone is done reading this one
     if constexpr (FAST) { PF_STAMP(9); }
   };
-  int kb_i = 0;
+  int kb_i = kb_lo;
   for (; kb_i + 1 < n_fast; ++kb_i) key_block(std::false_type{}, std::true_type{}, kb_i);     // the hot loop
   if (a.fast_stage) page_ready(phys_next);               // retire the last request before its register is reused
 #ifdef PF_STAMPS
@@ -590,6 +603,23 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   // O^T leaves the accumulators as 8-byte pieces at a row stride (a store instruction would touch 64 separate lines), so
   // each wave transposes its 32 rows through a private LDS region (the tile buffers are free now; rows padded to 288 B:
   // the 8-byte writes of 16 rows then spread over all banks) and stores whole 2 * dim-byte rows, 16 bytes per lane.
+  if constexpr (SPLIT) {
+    // un-normalised partials of this key slice: row r of the block (= wave * 32 + qt * 16 + l15), dims 16 dt + 4 grp .. + 3
+    const int64_t item = static_cast<int64_t>(blockIdx.x);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int r = wave * 32 + qt * 16 + l15;
+      const float ls = xor_sum_16_32(lsum[qt]);
+      float* po = a.ws_o + (item * 128 + r) * a.dim + grp * 4;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16) = o[qt][dt];
+      if (grp == 0) {
+        a.ws_ml[(item * 128 + r) * 2 + 0] = m[qt] * a.scale_log2;      // (-inf for a slice that saw no visible key)
+        a.ws_ml[(item * 128 + r) * 2 + 1] = ls;
+      }
+    }
+    return;
+  }
   constexpr int OROW = 288;
   lds_c* stage_o = smem + wave * (32 * OROW);
   typedef typename vec_of<T, 4>::type V4;
@@ -628,12 +658,61 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #endif
 }
 
+// Combine the key slices of a block (PrefillArgs::ksplit): one workgroup per (query block, kv head, sequence), thread =
+// (row, 4 dims); slices in index order (fixed association: the same bits from run to run).
+template <typename T, int G>
+__global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
+  constexpr int QPB = 128 / G;
+  const int inner = a.hkv * a.batch;
+  const int wg = blockIdx.x;
+  const int qb = a.n_qb - 1 - wg / inner;
+  const int rem = wg % inner;
+  const int kvh = rem % a.hkv, b = (rem / a.hkv + a.skew * (wg / inner)) % a.batch;
+  const int q_start = a.cu_q[b];
+  const int q_len = a.cu_q[b + 1] - q_start;
+  const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
+  if (qb * QPB >= q_len || kv_len <= 0) return;          // (rows the attention launch zeroed or never owned)
+  const int per_row = a.dim / 4;
+  typedef typename vec_of<T, 4>::type V4;
+  for (int i = threadIdx.x; i < 128 * per_row; i += 256) {
+    const int r = i / per_row, d0 = (i - r * per_row) * 4;
+    const int pos = qb * QPB + (r % QPB);
+    if (pos >= q_len) continue;
+    const int g = r / QPB;
+    const int head = a.abab ? g * a.hkv + kvh : kvh * G + g;
+    float mx = -INFINITY;
+    for (int sl = 0; sl < a.ksplit; ++sl) mx = fmaxf(mx, a.ws_ml[((static_cast<int64_t>(wg) * a.ksplit + sl) * 128 + r) * 2]);
+    f32x4 num = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
+    for (int sl = 0; sl < a.ksplit; ++sl) {
+      const int64_t row = (static_cast<int64_t>(wg) * a.ksplit + sl) * 128 + r;
+      const float ms = a.ws_ml[row * 2];
+      if (ms == -INFINITY) continue;
+      const float w = exp2f(ms - mx);
+      den = fmaf(w, a.ws_ml[row * 2 + 1], den);
+      num += *reinterpret_cast<const f32x4*>(a.ws_o + row * a.dim + d0) * w;
+    }
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+    V4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = static_cast<T>(num[e] * inv);
+    *reinterpret_cast<V4*>(static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + pos) * a.hq + head) * a.dim + d0) = ov;
+  }
+}
+
 template <typename T, int G, int DK>
 static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
-  auto* fn = prefill_kernel<T, G, DK>;
   static std::atomic<uint64_t> attr_set{0};
-  if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
-  hipLaunchKernelGGL(fn, grid, dim3(256), PF_LDS, s, a);
+  if (first_call_on_device(attr_set)) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_kernel<T, G, DK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_kernel<T, G, DK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
+  }
+  if (a.ksplit > 1) {
+    hipLaunchKernelGGL((prefill_kernel<T, G, DK, true>), grid, dim3(256), PF_LDS, s, a);
+    hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch)), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((prefill_kernel<T, G, DK, false>), grid, dim3(256), PF_LDS, s, a);
+  }
 }
 
 template <typename T, int G>
@@ -653,11 +732,11 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
   const int qpb = 128 / G;
   const int64_t n_qb = ceil_div(max_q, qpb);
   const int64_t n_zero = ceil_div(a.total_tokens, static_cast<int64_t>(PF_ZERO_TOKENS));
-  MOJO_REQUIRE(n_qb * a.hkv * batch + n_zero < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
+  MOJO_REQUIRE((n_qb * a.hkv * batch + n_zero) * a.ksplit < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
   a.batch = static_cast<int>(batch);
   a.n_qb = static_cast<int>(n_qb);
   { const char* e = getenv("MOJO_HIP_PREFILL_SKEW"); a.skew = (e && e[0] == '0') ? 0 : 1; }
-  dim3 grid(static_cast<unsigned>(n_qb * a.hkv * batch + n_zero));
+  dim3 grid(static_cast<unsigned>((n_qb * a.hkv * batch + n_zero) * a.ksplit));
   switch (G) {
     case 1: return dispatch_dk<T, 1>(a, grid, s);
     case 2: return dispatch_dk<T, 2>(a, grid, s);
@@ -667,9 +746,46 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
   }
 }
 
+// Key split: a launch of few, long blocks (a chunked prefill of one or two sequences against a long cache: 128 workgroups of
+// ~260 key tiles each) leaves half of the chip's 512 workgroup slots empty and ends on its longest block.  Cut every block's
+// key range into as many slices as fill the slots ONCE (512 new tokens + 16 384 cached, 32 q / 8 kv heads: 128 blocks; slices
+// 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 339 / 197 / 199 / 185 / 223 / 210 / 229 us: a second round of workgroups only adds partials to
+// write and merge) and still leave >= 8 tiles (512 keys) per slice.  MOJO_HIP_PREFILL_KSPLIT=<n> forces (1 = off).
+static int prefill_ksplit(int64_t blocks, int64_t kv_cap) {
+  if (const char* e = getenv("MOJO_HIP_PREFILL_KSPLIT")) { const int v = atoi(e); if (v >= 1) return v > 16 ? 16 : v; }
+  if (blocks <= 0 || blocks > 256) return 1;
+  int64_t ks = 512 / blocks;
+  const int64_t by_keys = kv_cap / 512;
+  if (ks > by_keys) ks = by_keys;
+  if (ks > 16) ks = 16;
+  return ks < 2 ? 1 : static_cast<int>(ks);
+}
+
+static void prefill_plan(int64_t total_tokens, int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t block_size,
+                         int64_t max_blocks_per_seq, int64_t max_q_len_hint, int64_t max_kv_len_hint, int64_t& n_qb, int& ksplit) {
+  const int G = static_cast<int>(q_heads / kv_heads);
+  const int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
+  n_qb = ceil_div(max_q, 128 / (G > 0 ? G : 1));
+  int64_t kv_cap = block_size * max_blocks_per_seq;
+  if (max_kv_len_hint > 0 && max_kv_len_hint < kv_cap) kv_cap = max_kv_len_hint;
+  ksplit = prefill_ksplit(n_qb * kv_heads * batch, kv_cap);
+}
+
 }  // namespace mojo
 
 using namespace mojo;
+
+extern "C" int64_t mojo_hip_paged_prefill_gqa_workspace_bytes(int64_t total_tokens, int64_t batch, int64_t q_heads,
+                                                              int64_t kv_heads, int64_t head_dim, int64_t block_size,
+                                                              int64_t max_blocks_per_seq, int64_t max_q_len_hint,
+                                                              int64_t max_kv_len_hint) {
+  if (total_tokens <= 0 || batch <= 0 || q_heads <= 0 || kv_heads <= 0 || q_heads % kv_heads) return 0;
+  int64_t n_qb;
+  int ks;
+  prefill_plan(total_tokens, batch, q_heads, kv_heads, block_size, max_blocks_per_seq, max_q_len_hint, max_kv_len_hint, n_qb, ks);
+  if (ks <= 1) return 0;
+  return n_qb * kv_heads * batch * ks * 128 * (head_dim + 2) * static_cast<int64_t>(sizeof(float)) + 64;
+}
 
 extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cache, const void* value_cache,
                                           const int32_t* cu_q_lens, const int32_t* cu_total_seq_lens,
@@ -677,8 +793,9 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
                                           int64_t q_heads, int64_t kv_heads, int64_t head_dim, int64_t block_size,
                                           int64_t max_blocks_per_seq, int64_t block_table_stride,
                                           int64_t cache_block_stride, int64_t cache_head_stride,
-                                          int64_t cache_token_stride, int64_t max_q_len_hint, float softmax_scale,
-                                          int layout_abab, int dtype, mojo_stream_t stream) {
+                                          int64_t cache_token_stride, int64_t max_q_len_hint, int64_t max_kv_len_hint,
+                                          float softmax_scale, int layout_abab, int dtype, void* workspace,
+                                          int64_t workspace_bytes, mojo_stream_t stream) {
   if (total_tokens == 0) return MOJO_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
   MOJO_REQUIRE(query && key_cache && value_cache && cu_q_lens && block_tables && out, MOJO_EINVAL,
@@ -713,6 +830,17 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   a.fast_stage = (a.page_shift >= 4 && cache_token_stride * 16 * 2 + 256 < (int64_t{1} << 31) && !(fs && fs[0] == '0')) ? 1 : 0;
   int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
   const int G = static_cast<int>(q_heads / kv_heads);
+  {
+    int64_t n_qb;
+    int ks;
+    prefill_plan(total_tokens, batch, q_heads, kv_heads, block_size, max_blocks_per_seq, max_q_len_hint, max_kv_len_hint, n_qb, ks);
+    const int64_t rows = n_qb * kv_heads * batch * ks * 128;
+    const int64_t need = rows * (head_dim + 2) * static_cast<int64_t>(sizeof(float));
+    if (ks > 1 && !(workspace && workspace_bytes >= need && aligned_to(workspace, 16))) ks = 1;   // no workspace: run unsplit
+    a.ksplit = ks;
+    a.ws_o = ks > 1 ? static_cast<float*>(workspace) : nullptr;
+    a.ws_ml = ks > 1 ? a.ws_o + rows * head_dim : nullptr;
+  }
   return dtype == MOJO_BF16 ? dispatch_g<bf16_t>(a, G, batch, max_q, s) : dispatch_g<f16_t>(a, G, batch, max_q, s);
 }
 
