@@ -36,6 +36,10 @@ struct GemmArgs {
   int glu = 0;
   int stage_rows = 0;        // 256x256 kernel, 16-bit C, ldc % 8 == 0, 16-byte aligned C: store whole 64-byte row pieces via LDS
   int ablate = 0;            // timing-only: 1 = skip the C stores (MOJO_HIP_GEMM_ABLATE)
+  int tile_order = 0;        // 256x256 kernel (MOJO_HIP_GEMM_ORDER, read per call; measurement): 0 = every XCD walks its own run of
+                             // panels (8 m x 4 n tiles per XCD at a time); 1 = the eight XCDs walk the SAME panel at the same time
+                             // (64 m x 4 n tiles in flight chip-wide, an XCD takes every eighth tile); 2 = 0 with panels of 2 n-tiles
+                             // (16 m x 2 n per XCD)
   int splitk = 1;
   void* slab = nullptr;
   int slab_rows = 0;

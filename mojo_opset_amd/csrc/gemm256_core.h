@@ -210,7 +210,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   int w2_off[2] = {64, 64};                           // byte offset of the wave's second glds
   auto locate = [&](int bid_) {
     int tile;
-    {  // bijective XCD remap: blocks b, b+8, ... share an XCD; give each XCD one contiguous run of tiles
+    if (a.tile_order == 1) {
+      tile = bid_;                                     // measurement: no XCD remap — the eight XCDs share every panel
+    } else {  // bijective XCD remap: blocks b, b+8, ... share an XCD; give each XCD one contiguous run of tiles
       const int q = total >> 3, r = total & 7, x = bid_ & 7, i = bid_ >> 3;
       tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     tile -= kslice * tiles_mn;
     int mi, ni;
     {  // panel-major order: panels of PANEL n-tiles; inside a panel m-tile by m-tile
+      const int PANEL = a.tile_order == 2 ? 2 : mojo::g256::PANEL;
       const int full_panels = n_tiles / PANEL, rem = n_tiles - full_panels * PANEL;
       const int in_full = full_panels * m_tiles * PANEL;
       if (tile < in_full) {

@@ -8,6 +8,7 @@ namespace mojo {
 static int run_gemm(GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
   static const int abl = [] { const char* e = getenv("MOJO_HIP_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = abl;
+  { const char* e = getenv("MOJO_HIP_GEMM_ORDER"); a.tile_order = e ? atoi(e) : 0; }
   if (gemm_skinny_ok(a, dtype)) return launch_gemm_skinny(a, dtype, s);      // <= 128 rows per (equal-sized) group, [N,K] weights
   if (gemm_skinny_ragged_ok(a, dtype, m_total)) return launch_gemm_skinny_ragged(a, dtype, m_total, s);   // ragged, <= 64 rows per group on average
   if (gemm_mfma256_ok(a, dtype)) return launch_gemm_mfma256(a, dtype, m_total, s);
