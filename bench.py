@@ -363,6 +363,17 @@ def main():
                                 if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" else
                                 "mojo::decode_split_kernel<bf16,4,nt> + mojo::decode_merge_kernel (MOJO_HIP_DECODE_FUSE=0)")},
     }
+    if dist_on:                     # what the collective library itself reports: a SCALE line must describe its own fabric
+        try:
+            names = [None] * world
+            dist.all_gather_object(names, f"{torch.cuda.get_device_name(device)} (device {device.index})")
+            line["comm"] = {"backend": dist.get_backend(), "world_observed": dist.get_world_size(), "ranks": names,
+                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                            "xgmi_link_peak_GBps": 153.0,
+                            "per_case": "extras.compute_comm_bf16: payload_MB_per_rank, link_MB, link_GBps_over_exposed_time, "
+                                        "bare_collective_us, overlap_frac (1 - exposed exchange / bare collective), speedup_vs_tp1"}
+        except Exception as e:
+            line["comm"] = {"error": repr(e)}
     hung = False
     if not ns.no_extras:            # every rank takes part: the GEMM + collective cases contain collectives
         # Extras run under a deadline in a worker thread: a collective that one rank never enters (an exception on a

@@ -494,6 +494,14 @@ def bench_compute_comm(device, world, rank):
                 t1 = timed(lambda: _ENGINE(xf, wf, None, True))
                 del xf
             payload = m * n * 2
+            bare = {}
+            import torch.distributed as dist
+            if world > 1 and dist.get_backend() == "nccl":  # the collective alone on the same payload: what overlap is measured against
+                buf = torch.randn(m, n, device=device, dtype=dt)
+                shard = torch.empty(m // world, n, device=device, dtype=dt)
+                bare["gemm_allreduce"] = timed(lambda: dist.all_reduce(buf))
+                bare["gemm_reducescatter"] = timed(lambda: dist.reduce_scatter_tensor(shard, buf))
+                del buf, shard
             for name, cls, kw in (("gemm_allreduce", "MojoGemmAllReduce", {}), ("gemm_reducescatter", "MojoGemmReduceScatter", {"scatter_dim": 0})):
                 op = hip(cls)(w, None, True, **kw)
                 phases = 2 if name == "gemm_allreduce" else 1
@@ -512,6 +520,10 @@ def bench_compute_comm(device, world, rank):
                         # bytes one rank moves over ONE link: ring = phases*(ws-1)/ws of the payload over its single ring link;
                         # direct = phases * payload/ws from each of its ws-1 peers
                         per_link = phases * payload * ((world - 1) / world if variant == "rccl" else 1.0 / world)
+                        exposed = max(t - t_local, 0.0)
+                        if name in bare:
+                            rec.update({"bare_collective_us": bare[name] * 1e6,
+                                        "overlap_frac": max(0.0, min(1.0, 1.0 - exposed / max(bare[name], 1e-9)))})
                         rec.update({"tp1_full_gemm_us": t1 * 1e6, "speedup_vs_tp1": t1 / t,
                                     "link_MB": per_link / 1e6, "link_GBps_over_whole_op": per_link / t / 1e9,
                                     "link_GBps_over_exposed_time": per_link / max(t - t_local, 1e-6) / 1e9,
