@@ -6,10 +6,15 @@
 // SIMD that is a latency-bound stream — groups of eight query heads (Llama-3-70B: 64 / 8) ran at 3.0 TB/s however the K/V
 // bytes were shared.  Here a tile costs ~60 vector instructions whatever the group size:
 //
-//   S^T[16 tokens x 16 heads] = K Q^T      v_mfma_f32_16x16x32: A = the K registers AS LOADED (lane = (token l & 15, dim chunk
-//                                          l >> 4): 16 B per lane and k-step, 64 contiguous bytes of every token row per
-//                                          instruction), B = the query slices (head = l & 15; lanes past the group repeat its
-//                                          last head and are never stored)
+//   S^T[16 tokens x 16 heads] = K Q^T      v_mfma_f32_16x16x32: A = the K registers AS LOADED, and loaded in WHOLE 128-byte lines (a
+//                                          load instruction = 8 tokens x one line; 64-byte runs stream at about half the rate):
+//                                          lane l holds chunk (l >> 3) of token (l & 7), which the MFMA sees as row
+//                                          (token, parity p = chunk & 1) with k-group g = chunk >> 1.  Row (token, p) meets the
+//                                          right query dims only in the product whose B operand holds the chunks 2 g + p: every
+//                                          register feeds TWO products (p = 0, 1), each valid in 8 of its 16 rows, and
+//                                          S[token] = C0[row token] + C1[row token + 8] — one v_permlane32_swap per score
+//                                          register puts two 8-token halves side by side in exactly the layout of the 16-row form.
+//                                          B = the query slices (head = l & 15; lanes past the group repeat its last head)
 //   online softmax                         lane = (head, tokens 4 g .. 4 g + 3 of every tile): in-lane maximum, one cross-group
 //                                          maximum (two lane-row swaps), lazy reference (rescale O only when it grows by 2^8)
 //   O^T[D x 16 heads] += V^T P^T           v_mfma_f32_16x16x16: B = the four probabilities of the lane (the accumulator layout of
@@ -116,12 +121,16 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
 
   // query slices: B operand, lane = (head tl, dims 32 s + 8 g4 .. + 7)
   const int hq_l = min(tl, G - 1);                      // lanes past the group repeat its last head (computed, never stored)
-  typename MM::frag8 qf[DK];
+  // B operands: line L (128 bytes = 8 chunks) of the row, parity p: lane k-group g4 holds the dims of chunk 8 L + 2 g4 + p
+  constexpr int NL = D / 64;                            // 128-byte lines per token row
+  typename MM::frag8 qf[NL][2];
   {
     const int h = decode_head(a, kvh, hq_l, G);
-    const T* qp = static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim + g4 * 8;
+    const T* qp = static_cast<const T*>(a.q) + (static_cast<int64_t>(b) * a.hq + h) * a.dim;
 #pragma unroll
-    for (int s = 0; s < DK; ++s) qf[s] = *reinterpret_cast<const typename MM::frag8*>(qp + s * 32);
+    for (int L = 0; L < NL; ++L)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) qf[L][p] = *reinterpret_cast<const typename MM::frag8*>(qp + (8 * L + 2 * g4 + p) * 8);
   }
 
   f32x4 o[ND];
@@ -151,12 +160,18 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
   };
   if (has_work) scan_issue(0);
 
-  const T* kbase = static_cast<const T*>(a.kc) + (kvh >> a.hshift) * a.c_head + g4 * 8;
-  const T* vbase = static_cast<const T*>(a.vc) + (kvh >> a.hshift) * a.c_head + g4 * 8;
+  // K: instruction (token group j, line L) = tokens 8 j + (l & 7), chunk 8 L + (l >> 3);  V: whole rows, RPI rows per instruction
+  constexpr int CPR = D / 8;                            // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;                         // V rows per load instruction (4 at D = 128, 8 at D = 64)
+  constexpr int NV = 16 / RPI;                          // V load instructions per tile
+  const int kt8 = lane & 7, kc8 = lane >> 3;
+  const int vr = lane / CPR, vc = lane % CPR;
+  const T* kbase = static_cast<const T*>(a.kc) + (kvh >> a.hshift) * a.c_head + kc8 * 8;
+  const T* vbase = static_cast<const T*>(a.vc) + (kvh >> a.hshift) * a.c_head + vc * 8;
   const int last_tile = ((tok_end - 1) / DECM_TILE) * DECM_TILE;      // first token of the last non-empty tile
   const int last_page = a.max_pages - 1;
 
-  struct Tile { V8 k[DK]; V8 v[DK]; int lp; };
+  struct Tile { V8 k[2][NL]; V8 v[NV]; int lp; };
   auto ld = [&](const T* p) -> V8 {
     if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V8*>(p));
     else return *reinterpret_cast<const V8*>(p);
@@ -166,11 +181,13 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
     const int lp = tu >> a.page_shift;
     t.lp = lp;
     const int phys = max(table[min(lp, last_page)], 0);
-    const int64_t off = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - (lp << a.page_shift) + tl) * a.c_tok;
+    const int64_t pg = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - (lp << a.page_shift)) * a.c_tok;
 #pragma unroll
-    for (int s = 0; s < DK; ++s) t.k[s] = ld(kbase + off + s * 32);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int s = 0; s < DK; ++s) t.v[s] = ld(vbase + off + s * 32);
+      for (int L = 0; L < NL; ++L) t.k[j][L] = ld(kbase + pg + static_cast<int64_t>(8 * j + kt8) * a.c_tok + L * 64);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) t.v[u] = ld(vbase + pg + static_cast<int64_t>(RPI * u + vr) * a.c_tok);
   };
 
   // wave-private V image: [16 tokens][ROWB bytes], 32-byte pair pp of row t at pp ^ ((t / RPB) & (NP - 1))
@@ -178,12 +195,12 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
   const int n_waves = FUSED ? static_cast<int>(blockDim.x >> 6) : 1;
   char* const v_img = reinterpret_cast<char*>(s_part + (FUSED ? n_waves * G * (D + 2) : 0)) + wave_id * (16 * ROWB);
   const unsigned v_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(v_img));
-  const int fw = (tl / RPB) & (NP - 1);
-  unsigned w_off[DK];                                    // write: chunk c = 4 s + g4 of row tl
+  unsigned w_off[NV];                                    // write of load instruction u: chunk vc of row RPI u + vr
 #pragma unroll
-  for (int s = 0; s < DK; ++s) {
-    const int c = 4 * s + g4;
-    w_off[s] = tl * ROWB + (((c >> 1) ^ fw) << 5) + (c & 1) * 16;
+  for (int u = 0; u < NV; ++u) {
+    const int row = RPI * u + vr;
+    const int fw = (row / RPB) & (NP - 1);
+    w_off[u] = row * ROWB + (((vc >> 1) ^ fw) << 5) + (vc & 1) * 16;
   }
   // transposed read of d tile dt: lane (group g4, i = tl): row = token 4 g4 + (i >> 2), columns 16 dt + 4 (i & 3) .. + 3
   const int rrow = 4 * g4 + (tl >> 2);
@@ -194,24 +211,45 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
     if (t.lp >= first_neg) {                             // rare: pages behind a hole read as zeros
       V8 z = {};
 #pragma unroll
-      for (int s = 0; s < DK; ++s) { t.k[s] = z; t.v[s] = z; }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int L = 0; L < NL; ++L) t.k[j][L] = z;
+#pragma unroll
+      for (int u = 0; u < NV; ++u) t.v[u] = z;
     }
     const bool full = t0 + DECM_TILE <= tok_end;         // wave-uniform
-    f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+    // c[j][p]: token group j (8 tokens), parity p; valid rows: (token, p)
+    f32x4 c[2][2];
 #pragma unroll
-    for (int s = 0; s < DK; ++s) sc = MM::qk(__builtin_bit_cast(typename MM::frag8, t.k[s]), qf[s], sc);
-    // stage V while the scores come out of the matrix pipe (rows past the length may hold NaN / Inf: zeros)
-    {
-      const bool vrow_ok = full || (t0 + tl) < tok_end;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s = 0; s < DK; ++s) {
-        V8 z = {};
-        *reinterpret_cast<V8*>(v_img + w_off[s]) = vrow_ok ? t.v[s] : z;
+      for (int p = 0; p < 2; ++p) {
+        c[j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int L = 0; L < NL; ++L) c[j][p] = MM::qk(__builtin_bit_cast(typename MM::frag8, t.k[j][L]), qf[L][p], c[j][p]);
       }
+    // stage V while the scores come out of the matrix pipe (rows past the length may hold NaN / Inf: zeros)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const bool vrow_ok = full || (t0 + RPI * u + vr) < tok_end;
+      V8 z = {};
+      *reinterpret_cast<V8*>(v_img + w_off[u]) = vrow_ok ? t.v[u] : z;
     }
+    // S[token] = C0[row token] + C1[row token + 8]; rows 0-7 live in lanes 0-31, rows 8-15 in lanes 32-63 (row = 4 (l >> 4) + i).
+    // Tokens 0-7 (group 0) end up in lanes 0-31, tokens 8-15 (group 1) in lanes 32-63: token 4 (l >> 4) + i, as in the 16-row form.
     float x[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = sc[i] * a.scale_log2;
+    for (int i = 0; i < 4; ++i) {
+      // X = C1 of group 0 (its upper half is needed below), Y = C0 of group 1;  X' = [X.lo, Y.lo], Y' = [X.hi, Y.hi].
+      // The builtin, not inline asm: the operands come straight out of the matrix pipe, and only the compiler's hazard
+      // recogniser knows how many wait states an MFMA result needs before a lane swap may read it.
+      // (floats first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the index)
+      const float xa = c[0][1][i], ya = c[1][0][i];
+      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, ya), false, false);
+      const float own = lane < 32 ? c[0][0][i] : c[1][1][i];
+      const float oth = __builtin_bit_cast(float, lane < 32 ? sw[1] : sw[0]);
+      x[i] = (own + oth) * a.scale_log2;
+    }
     if (!full) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
