@@ -543,16 +543,18 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
 }
 
 // The matrix-core kernel (paged_decode_mfma.h): pages of a multiple of 16 tokens, head_dim 64 / 128, groups of <= 16 heads.
-// MOJO_HIP_DECODE_MFMA: unset = where it measured faster — groups of >= 8 heads (Llama-3-70B 64 / 8, B 64, ctx 4096: 355 ->
-// 198 us; 8 / 1: 79 -> 44 us), head_dim 64 (149 -> 116 us) — and the group sizes the vector-unit kernel has no instance for;
-// groups of <= 4 heads at head_dim 128 stay on the vector-unit kernel (headline 179 vs 188 us: its loads cover whole
-// 256-byte rows, this kernel's 64-byte row segments); 1 = wherever it applies, 0 = never (read per call).
+// MOJO_HIP_DECODE_MFMA: unset = where it measured faster (B 64, ctx 4096, page 16, graph replay, vector-unit -> matrix-core):
+// groups of 8 heads (Llama-3-70B 64 / 8: 356 -> 170 us; 8 / 1: 79 -> 39 us), head_dim 64 (149 -> 99 us), groups of 4 at
+// head_dim 128 once the grid fills the chip (headline 179 -> 169 us, ctx 1024 51 -> 47 us, ragged 150 -> 139 us; B 8: 34 vs 37 us
+// the other way), and the group sizes the vector-unit kernel has no instance for.  Groups of 1 and 2 heads at head_dim 128
+// stay on the vector-unit kernel (163 vs 168 us, 167 vs 169 us).  1 = wherever it applies, 0 = never (read per call).
 static bool decode_use_mfma(const DecodeArgs& a, int G) {
   if (a.page_shift < 4 || (a.dim != 64 && a.dim != 128) || G > 16) return false;
   const char* e = getenv("MOJO_HIP_DECODE_MFMA");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
-  return G >= 8 || a.dim == 64 || (G != 1 && G != 2 && G != 4);
+  if (G == 4 && a.dim == 128) return static_cast<int64_t>(a.batch) * a.hkv >= 128;
+  return G >= 8 || a.dim == 64 || (G != 1 && G != 2);
 }
 
 template <typename T, bool NT, int MODE>
