@@ -95,6 +95,18 @@ def decode_algorithmic_bytes(lens, max_blocks):
     return kv + qo + idx
 
 
+def _headline_kernel():
+    """Name of the kernel the headline op call launches (the switches are the library's, read per call)."""
+    env = os.environ.get
+    form = ("paired> (one launch per op call: 8-wave workgroups own a length-ranked pair of sequences, their chunk partials "
+            "are merged in LDS)" if env("MOJO_HIP_DECODE_FUSE", "1") != "0" and env("MOJO_HIP_DECODE_PAIR", "1") != "0" else
+            "fused> (MOJO_HIP_DECODE_PAIR=0)" if env("MOJO_HIP_DECODE_FUSE", "1") != "0" else
+            "split> + mojo::decode_merge_kernel (MOJO_HIP_DECODE_FUSE=0)")
+    if env("MOJO_HIP_DECODE_MFMA", "") == "0":
+        return "mojo::decode_split_kernel<bf16,4,nt," + form + " [vector-unit kernel: MOJO_HIP_DECODE_MFMA=0]"
+    return "mojo::decode_mfma_kernel<bf16,head_dim 128,nt," + form
+
+
 def _profiled(name, key):
     """A value from a committed rocprofv3 summary under profiles/ (None when absent)."""
     try:
@@ -325,7 +337,7 @@ def main():
     kernel_s = dev_ms / 1e3 / ns.steps
     achieved = alg_bytes / kernel_s / 1e9
     # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 owns the counters and
-    # must wrap the program): they come from the committed summary of scripts/profile_r2.sh + scripts/summarize_r2.py
+    # must wrap the program): they come from the committed summary of scripts/profile_r3.sh + scripts/summarize_r3.py
     # (separate --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command line; date and box are in the file)
     traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "decode_gqa_traffic.json")
@@ -356,12 +368,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "device_us_per_launch": kernel_s * 1e6,
-                     "kernel": ("mojo::decode_split_kernel<bf16,4,nt,paired> (one launch per op call: 8-wave workgroups own a length-ranked pair "
-                                "of sequences, their chunk partials are merged in LDS)"
-                                if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" and os.environ.get("MOJO_HIP_DECODE_PAIR", "1") != "0" else
-                                "mojo::decode_split_kernel<bf16,4,nt,fused> (MOJO_HIP_DECODE_PAIR=0)"
-                                if os.environ.get("MOJO_HIP_DECODE_FUSE", "1") != "0" else
-                                "mojo::decode_split_kernel<bf16,4,nt> + mojo::decode_merge_kernel (MOJO_HIP_DECODE_FUSE=0)")},
+                     "kernel": _headline_kernel()},
     }
     if dist_on:                     # what the collective library itself reports: a SCALE line must describe its own fabric
         try:
@@ -461,7 +468,7 @@ def main():
             "us_min": rec.get("us_min"), "us_max": rec.get("us_max"),
             "workload": "MojoQuantGemm fp8 e4m3 (v_mfma_f32_16x16x128_f8f6f4), DeepSeek-V3 shape M=4096, K=7168, N=36864, weight [N,K] "
                         "(BASELINE configs[4]; fp8 parity is unpinned: the reference implements int8 only)",
-            "kernel": "mojo::quant_gemm256_kernel<fp8>"}
+            "kernel": "mojo::g256::gemm256_kernel<PolF8, EpilogueDequant>"}
     if isinstance(line.get("roofline_group_gemm"), dict):
         gg = line["roofline_group_gemm"]
         clk = gg.get("sustained_clock_mhz")
