@@ -560,7 +560,7 @@ static bool decode_use_mfma(const DecodeArgs& a, int G) {
 template <typename T, bool NT, int MODE>
 static void launch_decode_mfma(const DecodeArgs& a, dim3 grid, dim3 block, int G, hipStream_t s) {
   const size_t waves = block.x / 64;
-  const size_t lds = (MODE != DEC_SPLIT ? waves * G * (a.dim + 2) * sizeof(float) : 0) + waves * 16 * a.dim * 2;
+  const size_t lds = (MODE != DEC_SPLIT ? waves * G * (a.dim + 2) * sizeof(float) : 0) + waves * 4096;   // + one 4 KiB V image (set) per wave
   static std::atomic<uint64_t> attr_set{0};             // (per instantiation: dynamic LDS beyond 64 KiB needs the attribute)
   if (first_call_on_device(attr_set)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma_kernel<T, 4, NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -53,7 +53,7 @@ template <> struct dec_mma<f16_t> {
   static __device__ __forceinline__ frag4 from_lds(s16x4 v) { return __builtin_bit_cast(f16x4, v); }
 };
 
-constexpr int DECM_TILE = 16;
+constexpr int DECM_TILE = 16;                 // tokens of a sub-tile (one S^T product set, one V image)
 
 template <typename T, int DK /* head_dim / 32 */, bool NT, int MODE>
 __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kernel(DecodeArgs a, int G) {
@@ -63,6 +63,10 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
   constexpr int ROWB = D * 2;                           // bytes of a token row
   constexpr int NP = D / 16;                            // 32-byte pairs per row
   constexpr int RPB = 8 / NP;                           // rows per 256-byte bank row (1 at D = 128, 2 at D = 64)
+  constexpr int NS = DK == 2 ? 2 : 1;                   // sub-tiles per loop step: a step moves 8 KiB of K/V whatever the head_dim (at
+                                                        // head_dim 64 one sub-tile per step left the loop's fixed part — maximum, reference,
+                                                        // rescale test, branches — on half the bytes: 0.68 of HBM against 0.80 at 128)
+  constexpr int STEP = DECM_TILE * NS;
   typedef typename pack8<T>::vec V8;
   typedef dec_mma<T> MM;
   const int lane = threadIdx.x & 63;
@@ -171,29 +175,32 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
   const int last_tile = ((tok_end - 1) / DECM_TILE) * DECM_TILE;      // first token of the last non-empty tile
   const int last_page = a.max_pages - 1;
 
-  struct Tile { V8 k[2][NL]; V8 v[NV]; int lp; };
+  struct Tile { V8 k[NS][2][NL]; V8 v[NS][NV]; int lp[NS]; };
   auto ld = [&](const T* p) -> V8 {
     if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const V8*>(p));
     else return *reinterpret_cast<const V8*>(p);
   };
   auto load_tile = [&](Tile& t, int t0) {
-    const int tu = min(t0, last_tile);                    // wave-uniform; 16 | page: the tile lies in one page
-    const int lp = tu >> a.page_shift;
-    t.lp = lp;
-    const int phys = max(table[min(lp, last_page)], 0);
-    const int64_t pg = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - (lp << a.page_shift)) * a.c_tok;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int ss = 0; ss < NS; ++ss) {
+      const int tu = min(t0 + DECM_TILE * ss, last_tile);   // wave-uniform; 16 | page: the sub-tile lies in one page
+      const int lp = tu >> a.page_shift;
+      t.lp[ss] = lp;
+      const int phys = max(table[min(lp, last_page)], 0);
+      const int64_t pg = static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(tu - (lp << a.page_shift)) * a.c_tok;
 #pragma unroll
-      for (int L = 0; L < NL; ++L) t.k[j][L] = ld(kbase + pg + static_cast<int64_t>(8 * j + kt8) * a.c_tok + L * 64);
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int u = 0; u < NV; ++u) t.v[u] = ld(vbase + pg + static_cast<int64_t>(RPI * u + vr) * a.c_tok);
+        for (int L = 0; L < NL; ++L) t.k[ss][j][L] = ld(kbase + pg + static_cast<int64_t>(8 * j + kt8) * a.c_tok + L * 64);
+#pragma unroll
+      for (int u = 0; u < NV; ++u) t.v[ss][u] = ld(vbase + pg + static_cast<int64_t>(RPI * u + vr) * a.c_tok);
+    }
   };
 
-  // wave-private V image: [16 tokens][ROWB bytes], 32-byte pair pp of row t at pp ^ ((t / RPB) & (NP - 1))
+  // wave-private V images, one per sub-tile: [16 tokens][ROWB bytes], 32-byte pair pp of row t at pp ^ ((t / RPB) & (NP - 1))
   extern __shared__ float s_part[];                      // [waves][G][D + 2] partials, then [waves][16 x ROWB] V images
   const int n_waves = FUSED ? static_cast<int>(blockDim.x >> 6) : 1;
-  char* const v_img = reinterpret_cast<char*>(s_part + (FUSED ? n_waves * G * (D + 2) : 0)) + wave_id * (16 * ROWB);
+  char* const v_img = reinterpret_cast<char*>(s_part + (FUSED ? n_waves * G * (D + 2) : 0)) + wave_id * (NS * 16 * ROWB);
   const unsigned v_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(v_img));
   unsigned w_off[NV];                                    // write of load instruction u: chunk vc of row RPI u + vr
 #pragma unroll
@@ -208,55 +215,64 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
   const unsigned r_base = v_u32 + rrow * ROWB + (tl & 3) * 8;      // + ((dt ^ fr) << 5)
 
   auto process = [&](Tile& t, int t0) {
-    if (t.lp >= first_neg) {                             // rare: pages behind a hole read as zeros
-      V8 z = {};
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss)
+      if (t.lp[ss] >= first_neg) {                       // rare: pages behind a hole read as zeros
+        V8 z = {};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int L = 0; L < NL; ++L) t.k[ss][j][L] = z;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) t.v[ss][u] = z;
+      }
+    const bool full = t0 + STEP <= tok_end;              // wave-uniform
+    float x[NS][4];
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+      // c[j][p]: token group j (8 tokens), parity p; valid rows: (token, p)
+      f32x4 c[2][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int L = 0; L < NL; ++L) t.k[j][L] = z;
+        for (int p = 0; p < 2; ++p) {
+          c[j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < NV; ++u) t.v[u] = z;
-    }
-    const bool full = t0 + DECM_TILE <= tok_end;         // wave-uniform
-    // c[j][p]: token group j (8 tokens), parity p; valid rows: (token, p)
-    f32x4 c[2][2];
+          for (int L = 0; L < NL; ++L) c[j][p] = MM::qk(__builtin_bit_cast(typename MM::frag8, t.k[ss][j][L]), qf[L][p], c[j][p]);
+        }
+      // stage V while the scores come out of the matrix pipe (rows past the length may hold NaN / Inf: zeros)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        c[j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int L = 0; L < NL; ++L) c[j][p] = MM::qk(__builtin_bit_cast(typename MM::frag8, t.k[j][L]), qf[L][p], c[j][p]);
+      for (int u = 0; u < NV; ++u) {
+        const bool vrow_ok = full || (t0 + DECM_TILE * ss + RPI * u + vr) < tok_end;
+        V8 z = {};
+        *reinterpret_cast<V8*>(v_img + ss * (16 * ROWB) + w_off[u]) = vrow_ok ? t.v[ss][u] : z;
       }
-    // stage V while the scores come out of the matrix pipe (rows past the length may hold NaN / Inf: zeros)
+      // S[token] = C0[row token] + C1[row token + 8]; rows 0-7 live in lanes 0-31, rows 8-15 in lanes 32-63 (row = 4 (l >> 4) + i).
+      // Tokens 0-7 (group 0) end up in lanes 0-31, tokens 8-15 (group 1) in lanes 32-63: token 4 (l >> 4) + i, as in the 16-row form.
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const bool vrow_ok = full || (t0 + RPI * u + vr) < tok_end;
-      V8 z = {};
-      *reinterpret_cast<V8*>(v_img + w_off[u]) = vrow_ok ? t.v[u] : z;
-    }
-    // S[token] = C0[row token] + C1[row token + 8]; rows 0-7 live in lanes 0-31, rows 8-15 in lanes 32-63 (row = 4 (l >> 4) + i).
-    // Tokens 0-7 (group 0) end up in lanes 0-31, tokens 8-15 (group 1) in lanes 32-63: token 4 (l >> 4) + i, as in the 16-row form.
-    float x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // X = C1 of group 0 (its upper half is needed below), Y = C0 of group 1;  X' = [X.lo, Y.lo], Y' = [X.hi, Y.hi].
-      // The builtin, not inline asm: the operands come straight out of the matrix pipe, and only the compiler's hazard
-      // recogniser knows how many wait states an MFMA result needs before a lane swap may read it.
-      // (floats first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the index)
-      const float xa = c[0][1][i], ya = c[1][0][i];
-      const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, ya), false, false);
-      const float own = lane < 32 ? c[0][0][i] : c[1][1][i];
-      const float oth = __builtin_bit_cast(float, lane < 32 ? sw[1] : sw[0]);
-      x[i] = (own + oth) * a.scale_log2;
+      for (int i = 0; i < 4; ++i) {
+        // X = C1 of group 0 (its upper half is needed below), Y = C0 of group 1;  X' = [X.lo, Y.lo], Y' = [X.hi, Y.hi].
+        // The builtin, not inline asm: the operands come straight out of the matrix pipe, and only the compiler's hazard
+        // recogniser knows how many wait states an MFMA result needs before a lane swap may read it.
+        // (floats first: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the index)
+        const float xa = c[0][1][i], ya = c[1][0][i];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, xa), __builtin_bit_cast(unsigned, ya), false, false);
+        const float own = lane < 32 ? c[0][0][i] : c[1][1][i];
+        const float oth = __builtin_bit_cast(float, lane < 32 ? sw[1] : sw[0]);
+        x[ss][i] = (own + oth) * a.scale_log2;
+      }
     }
     if (!full) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (t0 + 4 * g4 + i >= tok_end) x[i] = -INFINITY;
+      for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (t0 + DECM_TILE * ss + 4 * g4 + i >= tok_end) x[ss][i] = -INFINITY;
     }
-    float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
-    mx = xor_max_16_32(mx);                              // the head's maximum over the tile (all four token groups)
+    float mx = fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3]));
+#pragma unroll
+    for (int ss = 1; ss < NS; ++ss) mx = fmaxf(mx, fmaxf(fmaxf(x[ss][0], x[ss][1]), fmaxf(x[ss][2], x[ss][3])));
+    mx = xor_max_16_32(mx);                              // the head's maximum over the step (all four token groups)
     float ref = m;
     if (mx - m > 8.0f) ref = mx;                         // m = -inf: any finite score; NaN (-inf - -inf): keep
     if (!__all(ref == m)) {
@@ -267,37 +283,43 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
       m = ref;
     }
     const float ms = m == -INFINITY ? 0.f : m;
-    float p[4];
+    typename MM::frag4 pf[NS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = fast_exp2(x[i] - ms);
-    l += (p[0] + p[1]) + (p[2] + p[3]);
-    const typename MM::frag4 pf = MM::pack(p[0], p[1], p[2], p[3]);
+    for (int ss = 0; ss < NS; ++ss) {
+      float p[4];
 #pragma unroll
-    for (int dt = 0; dt < ND; ++dt) {
-      const s16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          reinterpret_cast<__attribute__((address_space(3))) s16x4*>(static_cast<uintptr_t>(r_base + ((dt ^ fr) << 5))));
-      o[dt] = MM::pv(MM::from_lds(vt), pf, o[dt]);
+      for (int i = 0; i < 4; ++i) p[i] = fast_exp2(x[ss][i] - ms);
+      l += (p[0] + p[1]) + (p[2] + p[3]);
+      pf[ss] = MM::pack(p[0], p[1], p[2], p[3]);
     }
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+      for (int ss = 0; ss < NS; ++ss) {
+        const s16x4 vt = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            reinterpret_cast<__attribute__((address_space(3))) s16x4*>(static_cast<uintptr_t>(r_base + ss * (16 * ROWB) + ((dt ^ fr) << 5))));
+        o[dt] = MM::pv(MM::from_lds(vt), pf[ss], o[dt]);
+      }
   };
 
   Tile ta, tb, tc;
   if (has_work) {
     load_tile(ta, tok_begin);
-    if (tok_begin + DECM_TILE < tok_end) load_tile(tb, tok_begin + DECM_TILE);
+    if (tok_begin + STEP < tok_end) load_tile(tb, tok_begin + STEP);
     scan_reduce(0);
     for (int base = 64 * SCAN; base < p1 && first_neg == 0x7fffffff; base += 64 * SCAN) {
       scan_issue(base);
       scan_reduce(base);
     }
-    for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * DECM_TILE) {
-      if (t0 + 2 * DECM_TILE < tok_end) load_tile(tc, t0 + 2 * DECM_TILE);
+    for (int t0 = tok_begin; t0 < tok_end; t0 += 3 * STEP) {
+      if (t0 + 2 * STEP < tok_end) load_tile(tc, t0 + 2 * STEP);
       process(ta, t0);
-      if (t0 + DECM_TILE >= tok_end) break;
-      if (t0 + 3 * DECM_TILE < tok_end) load_tile(ta, t0 + 3 * DECM_TILE);
-      process(tb, t0 + DECM_TILE);
-      if (t0 + 2 * DECM_TILE >= tok_end) break;
-      if (t0 + 4 * DECM_TILE < tok_end) load_tile(tb, t0 + 4 * DECM_TILE);
-      process(tc, t0 + 2 * DECM_TILE);
+      if (t0 + STEP >= tok_end) break;
+      if (t0 + 3 * STEP < tok_end) load_tile(ta, t0 + 3 * STEP);
+      process(tb, t0 + STEP);
+      if (t0 + 2 * STEP >= tok_end) break;
+      if (t0 + 4 * STEP < tok_end) load_tile(tb, t0 + 4 * STEP);
+      process(tc, t0 + 2 * STEP);
     }
   }
 

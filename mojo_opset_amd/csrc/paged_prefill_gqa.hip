@@ -658,13 +658,18 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #endif
 }
 
-// Combine the key slices of a block (PrefillArgs::ksplit): one workgroup per (query block, kv head, sequence), thread =
-// (row, 4 dims); slices in index order (fixed association: the same bits from run to run).
+// Combine the key slices of a block (PrefillArgs::ksplit): PF_MERGE_SPLIT workgroups per (query block, kv head, sequence), each
+// 128 / PF_MERGE_SPLIT rows, thread = (row, 4 dims); slices in index order (fixed association: the same bits from run to run).
+// (Round 3: it was one workgroup per block — 128 workgroups on the chunked-prefill case, each thread walking 16 items of
+// dependent loads: 43 us beside a 145 us attention launch.  Sixteen times the workgroups and the slices of an item loaded four
+// at a time before they are used.)
+constexpr int PF_MERGE_SPLIT = 16;
 template <typename T, int G>
 __global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
   constexpr int QPB = 128 / G;
+  constexpr int ROWS = 128 / PF_MERGE_SPLIT;
   const int inner = a.hkv * a.batch;
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x / PF_MERGE_SPLIT, part = blockIdx.x % PF_MERGE_SPLIT;
   const int qb = a.n_qb - 1 - wg / inner;
   const int rem = wg % inner;
   const int kvh = rem % a.hkv, b = (rem / a.hkv + a.skew * (wg / inner)) % a.batch;
@@ -674,23 +679,34 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
   if (qb * QPB >= q_len || kv_len <= 0) return;          // (rows the attention launch zeroed or never owned)
   const int per_row = a.dim / 4;
   typedef typename vec_of<T, 4>::type V4;
-  for (int i = threadIdx.x; i < 128 * per_row; i += 256) {
-    const int r = i / per_row, d0 = (i - r * per_row) * 4;
+  const int64_t slice0 = static_cast<int64_t>(wg) * a.ksplit;
+  for (int i = threadIdx.x; i < ROWS * per_row; i += 256) {
+    const int r = part * ROWS + i / per_row, d0 = (i % per_row) * 4;
     const int pos = qb * QPB + (r % QPB);
     if (pos >= q_len) continue;
     const int g = r / QPB;
     const int head = a.abab ? g * a.hkv + kvh : kvh * G + g;
     float mx = -INFINITY;
-    for (int sl = 0; sl < a.ksplit; ++sl) mx = fmaxf(mx, a.ws_ml[((static_cast<int64_t>(wg) * a.ksplit + sl) * 128 + r) * 2]);
+    for (int sl = 0; sl < a.ksplit; ++sl) mx = fmaxf(mx, a.ws_ml[((slice0 + sl) * 128 + r) * 2]);
     f32x4 num = {0.f, 0.f, 0.f, 0.f};
     float den = 0.f;
-    for (int sl = 0; sl < a.ksplit; ++sl) {
-      const int64_t row = (static_cast<int64_t>(wg) * a.ksplit + sl) * 128 + r;
-      const float ms = a.ws_ml[row * 2];
-      if (ms == -INFINITY) continue;
-      const float w = exp2f(ms - mx);
-      den = fmaf(w, a.ws_ml[row * 2 + 1], den);
-      num += *reinterpret_cast<const f32x4*>(a.ws_o + row * a.dim + d0) * w;
+    for (int sl0 = 0; sl0 < a.ksplit; sl0 += 4) {
+      f32x4 v[4];
+      float ms[4], ls[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                      // all loads of the four slices first (a slice past the end repeats the last one, weight 0)
+        const int64_t row = (slice0 + min(sl0 + u, a.ksplit - 1)) * 128 + r;
+        ms[u] = sl0 + u < a.ksplit ? a.ws_ml[row * 2] : -INFINITY;
+        ls[u] = a.ws_ml[row * 2 + 1];
+        v[u] = *reinterpret_cast<const f32x4*>(a.ws_o + row * a.dim + d0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ms[u] == -INFINITY) continue;
+        const float w = exp2f(ms[u] - mx);
+        den = fmaf(w, ls[u], den);
+        num += v[u] * w;
+      }
     }
     const float inv = den > 0.f ? 1.0f / den : 0.f;
     V4 ov;
@@ -709,7 +725,7 @@ static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
   }
   if (a.ksplit > 1) {
     hipLaunchKernelGGL((prefill_kernel<T, G, DK, true>), grid, dim3(256), PF_LDS, s, a);
-    hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch * PF_MERGE_SPLIT)), dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL((prefill_kernel<T, G, DK, false>), grid, dim3(256), PF_LDS, s, a);
   }
