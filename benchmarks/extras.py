@@ -315,7 +315,16 @@ def bench_mla_decode(device):
     res = _hbm(t, nbytes)
     flops = 2.0 * b * h * ctx * (2 * r + rope) + 2.0 * b * h * r * (nope + vd) * 2
     res.update({"tflops": flops / t / 1e12, "tokens_per_s": b / t})
-    return {"B64_H128_ctx4096_page16": res}
+    out = {"B64_H128_ctx4096_page16": res}
+    if _want("golden_route"):
+        # the PARITY route (the golden's own arithmetic: decompressed K / V for every cached token, sequences walked in slices
+        # of the decompression budget) timed once beside the default: it is not a fast path and is not meant to be
+        op.decode_route = "golden"
+        tg = _time(lambda: op(q, ckv, kpe, lens, table, max_total_seq_len=ctx), iters=2, warmup=1, repeats=3)
+        op.decode_route = None
+        out["B64_H128_ctx4096_page16_golden_route"] = {"us": tg * 1e6, "tokens_per_s": b / tg, **_stats(tg),
+                                                       "note": "parity route (MOJO_HIP_MLA_DECODE=golden), not the default"}
+    return out
 
 
 def bench_mla_prefill(device):

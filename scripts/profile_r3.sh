@@ -13,7 +13,7 @@ one() {  # tag, bench function, case substring
   MOJO_BENCH_ONLY="$3" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/$1_fetch -- python3 benchmarks/one.py $2 > $P/$1_fetch.log 2>&1; echo $1 fetch rc=$?
   MOJO_BENCH_ONLY="$3" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/$1_write -- python3 benchmarks/one.py $2 > $P/$1_write.log 2>&1; echo $1 write rc=$?
 }
-one mla_decode bench_mla_decode ""
+one mla_decode bench_mla_decode B64_H128
 one prefill_gqa_4x2048 bench_prefill 4x2048_nocache
 one quant_gemm_fp8_4096x7168x36864 bench_quant_gemm fp8_e4m3_4096x7168x36864
 # the other cases: durations only
