@@ -91,3 +91,19 @@ def test_integration_md_stub_passes_what_the_header_declares():
             assert passed == declared, f"INTEGRATION.md passes {passed} arguments to {name}; the header declares {declared}"
             calls += 1
     assert calls >= 3
+
+
+def test_every_environment_switch_of_the_package_is_documented():
+    """INTEGRATION.md §5 lists every MOJO_HIP_* switch the library or the host side reads (a switch a maintainer cannot find
+    is a behaviour they cannot reproduce)."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for pat in ("mojo_opset_amd/csrc/*.hip", "mojo_opset_amd/csrc/*.h", "mojo_opset_amd/**/*.py"):
+        for path in glob.glob(os.path.join(root, pat), recursive=True):
+            names.update(re.findall(r"MOJO_HIP_[A-Z0-9_]+", open(path).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 30 and not missing, missing
