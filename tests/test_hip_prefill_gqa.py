@@ -217,3 +217,33 @@ def test_prefill_key_split(cfg, layout, monkeypatch):
         want2 = ref(q, k, v, cu_q, table2, **kw)
         got2 = op(dev[0], dev[1], dev[2], dev[3], table2.to(DEV), **dkw)
         assert_close_tree(to_cpu(got2), want2, ATOL, RTOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (q_lens, cached, Hq, Hkv, D, page): ragged batch with a cached prefix and a hole; groups of 1 / 8 heads; head_dim 64 / 96
+    ([700, 1, 333, 1024], [900, 515, 0, 77], 16, 4, 128, 16),
+    ([513, 64], [0, 2000], 8, 8, 128, 64),
+    ([300, 129], [31, 0], 16, 2, 64, 16),
+    ([257], [100], 8, 2, 96, 32),
+], ids=["ragged_hole", "g1_cached", "g8_d64", "d96"])
+def test_prefill_phase_alternating_kernel(cfg, monkeypatch):
+    """prefill_pp_kernel (MOJO_HIP_PREFILL_PP=1; opt-in, see DESIGN Appendix A): 8-wave workgroups whose two wave groups
+    alternate matrix and softmax phases over rings of four K / V tiles — against the oracle and against the default kernel."""
+    q_lens, cached, hq, hkv, d, page = cfg
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hq, hkv, d, page, seed=41)
+    if len(q_lens) == 4:
+        table[0, 5] = -1                                        # a hole: rows behind it read as zero K / V
+    op = hip_cls("MojoPagedPrefillGQA")()
+    ref = torch_cls("MojoPagedPrefillGQA")()
+    kw = dict(softmax_scale=1.0 / math.sqrt(d), max_q_len=max(q_lens), max_total_seq_len=max(kv_lens), cu_total_seq_lens=cu_kv)
+    want = ref(q, k, v, cu_q, table, **kw)
+    dkw = {k_: (v_.to(DEV) if isinstance(v_, torch.Tensor) else v_) for k_, v_ in kw.items()}
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV))
+    monkeypatch.setenv("MOJO_HIP_PREFILL_PP", "0")
+    base = op(*args, **dkw)
+    monkeypatch.setenv("MOJO_HIP_PREFILL_PP", "1")
+    got = op(*args, **dkw)
+    again = op(*args, **dkw)
+    assert torch.equal(got, again)                              # same bits from run to run
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    torch.testing.assert_close(got.float(), base.float(), atol=8e-3, rtol=8e-3)
