@@ -531,9 +531,21 @@ static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len)
   const int64_t units = batch * kv_heads > 0 ? batch * kv_heads : 1;
   int64_t splits = (256 * 8) / units;
   if (splits < 1) splits = 1;
-  int64_t chunk = ceil_div(max_len > 0 ? max_len : 1, splits);
+  const int64_t len = max_len > 0 ? max_len : 1;
+  int64_t chunk = ceil_div(len, splits);
   if (chunk < 128) chunk = 128;
   chunk = ceil_div(chunk, DEC_TILE) * DEC_TILE;
+  // More than 8 chunks per (sequence, kv-head) take the split + merge form: single-wave workgroups and a merge launch whose
+  // cost grows with the chunk count.  There 1 024 waves measured best, not 2 048 (round 3, scripts/probes/decode_tp8_chunk_ab.py,
+  // matrix-core kernel: 8 q / 1 kv heads B 64 ctx 4096 39.8 -> 34.3 us, B 16 ctx 16384 52.1 -> 38.9 us, 64 / 8 heads B 8 ctx 8192
+  // 64.2 -> 57.4 us, 32 / 8 heads B 8 ctx 4096 36.8 -> 32.6 us; 512 waves: 1.5-2 x slower) - but never fewer than 8 chunks.
+  if (ceil_div(len, chunk) > 8) {
+    int64_t s2 = 1024 / units;
+    if (s2 < 8) s2 = 8;
+    chunk = ceil_div(len, s2);
+    if (chunk < 128) chunk = 128;
+    chunk = ceil_div(chunk, DEC_TILE) * DEC_TILE;
+  }
   return static_cast<int>(chunk);
 }
 
@@ -545,16 +557,15 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
 // The matrix-core kernel (paged_decode_mfma.h): pages of a multiple of 16 tokens, head_dim 64 / 128, groups of <= 16 heads.
 // MOJO_HIP_DECODE_MFMA: unset = where it measured faster (B 64, ctx 4096, page 16, graph replay, vector-unit -> matrix-core):
 // groups of 8 heads (Llama-3-70B 64 / 8: 356 -> 170 us; 8 / 1: 79 -> 39 us), head_dim 64 (149 -> 99 us), groups of 4 at
-// head_dim 128 once the grid fills the chip (headline 179 -> 169 us, ctx 1024 51 -> 47 us, ragged 150 -> 139 us; B 8: 34 vs 37 us
-// the other way), and the group sizes the vector-unit kernel has no instance for.  Groups of 1 and 2 heads at head_dim 128
+// head_dim 128 (headline 179 -> 169 us, ctx 1024 51 -> 47 us, ragged 150 -> 139 us; B 8: 34.5 -> 32.6 us with the chunk rule
+// of decode_chunk_tokens), and the group sizes the vector-unit kernel has no instance for.  Groups of 1 and 2 heads at head_dim 128
 // stay on the vector-unit kernel (163 vs 168 us, 167 vs 169 us).  1 = wherever it applies, 0 = never (read per call).
 static bool decode_use_mfma(const DecodeArgs& a, int G) {
   if (a.page_shift < 4 || (a.dim != 64 && a.dim != 128) || G > 16) return false;
   const char* e = getenv("MOJO_HIP_DECODE_MFMA");
   if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
-  if (G == 4 && a.dim == 128) return static_cast<int64_t>(a.batch) * a.hkv >= 128;
-  return G >= 8 || a.dim == 64 || (G != 1 && G != 2);
+  return G >= 4 || a.dim == 64 || (G != 1 && G != 2);
 }
 
 template <typename T, bool NT, int MODE>
