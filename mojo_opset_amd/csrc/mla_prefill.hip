@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, kb_i);
 
   // ---- finish: row sums over the 4 lane groups (+ the sink's share of the denominator), normalise, store whole rows ----
-  constexpr int OROW = 288;
+  constexpr int OROW = 272;                       // (68 dwords: the 16 rows of a write land 4 banks apart; 288 left rows l and l + 8 on one bank pair)
   lds_m* stage_o = smem + wave * (32 * OROW);
   typedef typename vec_of<T, 4>::type V4;
   const float sink_l2 = a.sink ? a.sink[head] * 1.4426950408889634f : 0.f;

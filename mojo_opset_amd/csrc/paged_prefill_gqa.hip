@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 
   // ---- finish: reduce the row sums over the 4 lane groups, normalise, store ----------------------------------
   // O^T leaves the accumulators as 8-byte pieces at a row stride (a store instruction would touch 64 separate lines), so
-  // each wave transposes its 32 rows through a private LDS region (the tile buffers are free now; rows padded to 288 B:
+  // each wave transposes its 32 rows through a private LDS region (the tile buffers are free now; rows padded to 272 B:
   // the 8-byte writes of 16 rows then spread over all banks) and stores whole 2 * dim-byte rows, 16 bytes per lane.
   if constexpr (SPLIT) {
     // un-normalised partials of this key slice: row r of the block (= wave * 32 + qt * 16 + l15), dims 16 dt + 4 grp .. + 3
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     }
     return;
   }
-  constexpr int OROW = 288;
+  constexpr int OROW = 272;                       // (68 dwords: the 16 rows of a write land 4 banks apart; 288 left rows l and l + 8 on one bank pair)
   lds_c* stage_o = smem + wave * (32 * OROW);
   typedef typename vec_of<T, 4>::type V4;
 #pragma unroll

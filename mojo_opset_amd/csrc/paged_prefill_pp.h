@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) void prefill_pp_kernel(PrefillArgs a) {
   if (pg == 0) __builtin_amdgcn_s_barrier();             // (group B's M(n)); behind it the rings become the output staging
 
   // ---- finish: reduce the row sums over the 4 lane groups, normalise, transpose through LDS, store whole rows --------------
-  constexpr int OROW = 288;
+  constexpr int OROW = 272;                       // (68 dwords: the 16 rows of a write land 4 banks apart; 288 left rows l and l + 8 on one bank pair)
   lds_c* stage_o = smem + wave * (32 * OROW);
   typedef typename vec_of<T, 4>::type V4;
 #pragma unroll
