@@ -227,7 +227,7 @@ def _decode_decompressed(op, query, ckv_cache, kpe_cache, total_seq_lens, block_
     form cannot where the golden's own rounding error exceeds that bound.  Returns None when the route does not apply."""
     batch = query.shape[0]
     dev = query.device
-    lens = total_seq_lens.to(torch.int32).clamp_(min=0)
+    lens = total_seq_lens.to(torch.int32).clamp(min=0)          # (out of place: `.to` returns the caller's tensor when it is int32 already)
     cu_kv = torch.zeros(batch + 1, dtype=torch.int32, device=dev)
     torch.cumsum(lens, 0, out=cu_kv[1:])
     cu_q = torch.arange(batch + 1, dtype=torch.int32, device=dev)
