@@ -169,6 +169,29 @@ __global__ __launch_bounds__(512, 2) void mla512_ps_kernel(MlaArgs a) {
   // each costs its issuing wave but by what one CU's fill path delivers (~36 GB/s for a stream that is half L2 hits).
   const bool six = a.ps_issuers == 6;
   using ic0 = std::integral_constant<int, 0>;
+  // L2 prefetch issued by a CONSUMER wave (ps_prefetch == 2; round 3, second attempt).  Issued by the loaders (ps_prefetch == 1)
+  // the prefetch loads are older than the DMA pieces in the same wave's in-order vmcnt, so the loader's counted wait for a slot
+  // also waited for prefetch loads that miss to HBM: slower.  A consumer has no vector-memory instruction in its loop and never
+  // waits for these (their destination is an LDS scratch nobody reads).
+  constexpr int PF2 = 3;
+  auto prefetch_group = [&](int kt, int li) {
+    const int key_c = min(k_begin + kt * KEYS + 16 * li, k_end - 1) & ~15;
+    int phys;
+    {
+      const int32_t* pt = table + (key_c >> a.page_shift);
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(phys) : "s"(pt) : "memory");
+    }
+    phys = max(phys, 0);
+    const char* pc = ckv_b + 2 * (static_cast<int64_t>(phys) * a.ckv_blk + static_cast<int64_t>(key_c & pmask) * a.ckv_tok);
+    const char* pp = kpe_b + 2 * (static_cast<int64_t>(phys) * a.kpe_blk + static_cast<int64_t>(key_c & pmask) * a.kpe_tok);
+    lds_m* sink = smem + MLAPS_PF_OFF + li * 256;
+    const unsigned c0 = (lane >> 3) * static_cast<unsigned>(2 * a.ckv_tok) + (lane & 7) * 128;     // rows 0-7, one dword per 128-byte line
+    const unsigned c1 = c0 + 8u * static_cast<unsigned>(2 * a.ckv_tok);                           // rows 8-15
+    const unsigned pe = (lane & 15) * static_cast<unsigned>(2 * a.kpe_tok);                        // 16 rows of 128 B
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc + c0), (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pc + c1), (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pp + pe), (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+  };
 
   if (is_loader) {
     // ---------------------------------------------------------------------------------------------------------------------
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void mla512_ps_kernel(MlaArgs a) {
     const unsigned pf_c0 = (lane >> 3) * static_cast<unsigned>(2 * a.ckv_tok) + (lane & 7) * 128;   // rows 0-7 of the page slice
     const unsigned pf_c1 = pf_c0 + 8u * static_cast<unsigned>(2 * a.ckv_tok);                       // rows 8-15
     const unsigned pf_p = (lane & 15) * static_cast<unsigned>(2 * a.kpe_tok);                        // 16 rows of 128 B (lanes 16+ repeat)
-    const bool pf_on = a.ps_prefetch != 0;       // default OFF: measured 126 -> 136 us per op (stream alone 102 -> 125 us, compute ablated)
+    const bool pf_on = a.ps_prefetch == 1;       // default OFF: measured 126 -> 136 us per op (stream alone 102 -> 125 us, compute ablated)
     auto prefetch_slot = [&](int kt) {
       const int key_g = k_begin + kt * KEYS + 16 * li;
       const int key_c = min(key_g, k_end - 1) & ~15;
@@ -402,7 +425,8 @@ __global__ __launch_bounds__(512, 2) void mla512_ps_kernel(MlaArgs a) {
   }
   for (int kt = -1; kt < n_kt && n_kt > 0; ++kt) {                                   // step kt: slot kt (step -1: the producers' first slot)
     const bool more = six && kt + 3 < n_kt && !((a.ps_debug & 1) && kt > 4);
-    if (more) issue_mine(kt + 3);                                                    // (its ring position was freed by the barrier of step kt - 1)
+    if (more) issue_mine(kt + 3);
+    if (a.ps_prefetch == 2 && dhalf == 0 && kt + 3 + PF2 < n_kt) prefetch_group(kt + 3 + PF2, grp);                                                    // (its ring position was freed by the barrier of step kt - 1)
     if (kt >= 0 && active && !(a.ps_debug & 8)) {
       const unsigned vt = smem_u32 + (kt & (MLAPS_SLOTS - 1)) * SLOT;
       u32x4 pw0, pw1;
@@ -455,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void mla512_ps_kernel(MlaArgs a) {
     }
     __builtin_amdgcn_s_barrier();
   }
+  if (a.ps_prefetch == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no prefetch load may land in LDS behind this workgroup
   // ---- epilogue: lane holds head r31, dims 256 dhalf + 32 dt + 8 (i >> 2) + 4 h + (i & 3) -----------------------------------
   const bool store = active && head0 + r31 < a.heads;
   if (a.n_splits == 1) {

@@ -45,7 +45,7 @@ struct MlaArgs {
   float scale_log2;
   int ps_debug;             // mla512_ps ablation bits (MOJO_HIP_MLA_PS_DEBUG; timing only: 1 no DMA after the first slots, 2 no QK^T, 4 no softmax, 8 no PV)
   int ps_issuers;           // mla512_ps: waves that issue the LDS-DMA: 2 (the loaders; default) or 6 (loaders + consumers; MOJO_HIP_MLA_PS_ISSUERS=6: measured equal)
-  int ps_prefetch;          // mla512_ps: L2 prefetch ahead of the LDS-DMA (MOJO_HIP_MLA_PS_PREFETCH=1: on; measured slower, default off)
+  int ps_prefetch;          // mla512_ps: L2 prefetch ahead of the LDS-DMA (MOJO_HIP_MLA_PS_PREFETCH=1: by the loaders, 2: by a consumer wave per group; default off)
 };
 
 template <typename T> struct mla_mfma;
@@ -537,7 +537,7 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride,
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   { const char* e = getenv("MOJO_HIP_MLA_PS_DEBUG"); a.ps_debug = e ? atoi(e) : 0; }
   { const char* e = getenv("MOJO_HIP_MLA_PS_ISSUERS"); a.ps_issuers = (e && e[0] == '6') ? 6 : 2; }
-  { const char* e = getenv("MOJO_HIP_MLA_PS_PREFETCH"); a.ps_prefetch = (e && e[0] == '1') ? 1 : 0; }
+  { const char* e = getenv("MOJO_HIP_MLA_PS_PREFETCH"); a.ps_prefetch = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0; }
   a.part_o = nullptr; a.part_ml = nullptr;
   if (a.n_splits > 1) {
     const int64_t slots = q_tokens * a.n_splits * heads;
