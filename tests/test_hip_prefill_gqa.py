@@ -247,3 +247,30 @@ def test_prefill_phase_alternating_kernel(cfg, monkeypatch):
     assert torch.equal(got, again)                              # same bits from run to run
     assert_close_tree(to_cpu(got), want, ATOL, RTOL)
     torch.testing.assert_close(got.float(), base.float(), atol=8e-3, rtol=8e-3)
+
+
+def test_prefill_key_split_at_the_bench_size(monkeypatch):
+    """The chunked-prefill bench case at full size (512 new tokens against 16 384 cached, 32 q / 8 kv heads, page 16): the
+    launch's own rule cuts the keys into slices; the result equals the unsplit launch within accumulation noise, is
+    bit-stable, and three sampled query rows match the oracle."""
+    q_lens, cached, hq, hkv, d, page = [512], [16384], 32, 8, 128, 16
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hq, hkv, d, page, seed=77)
+    op = hip_cls("MojoPagedPrefillGQA")()
+    dkw = dict(max_q_len=512, max_total_seq_len=kv_lens[0], cu_total_seq_lens=cu_kv.to(DEV))
+    dev = [t.to(DEV) for t in (q, k, v, cu_q, table)]
+    from mojo_opset_amd.backends.hip import lib as L
+    assert L.load().mojo_hip_paged_prefill_gqa_workspace_bytes(512, 1, hq, hkv, d, page, table.shape[1], 512, kv_lens[0]) > 0
+    got = op(*dev, **dkw)
+    assert torch.equal(op(*dev, **dkw), got)
+    monkeypatch.setenv("MOJO_HIP_PREFILL_KSPLIT", "1")
+    plain = op(*dev, **dkw)
+    torch.testing.assert_close(got.float(), plain.float(), atol=8e-3, rtol=8e-3)
+    # oracle on three query rows (first, middle, last): row i sees keys 0 .. 16384 + i
+    keys = torch.cat([k[int(p)] for p in table[0]], dim=1)[:, : kv_lens[0]].float()        # [hkv, T, d]
+    vals = torch.cat([v[int(p)] for p in table[0]], dim=1)[:, : kv_lens[0]].float()
+    for i in (0, 255, 511):
+        n = 16384 + i + 1
+        qi = q[i].float().view(hkv, hq // hkv, d)
+        sc = torch.einsum("kgd,ktd->kgt", qi, keys[:, :n]) / math.sqrt(d)
+        want = torch.einsum("kgt,ktd->kgd", torch.softmax(sc, -1).to(torch.bfloat16).float(), vals[:, :n]).reshape(hq, d)
+        torch.testing.assert_close(got[i].float().cpu(), want, atol=ATOL, rtol=RTOL)
