@@ -67,10 +67,15 @@ def test_fuzz_prefill_gqa(seed):
     assert_close_tree(got, want, 2e-2, 2e-2)
     if pad:
         assert torch.count_nonzero(got[sum(q_lens):]) == 0
-    if rnd.random() < 0.5:                                              # with the host hints: same bits
+    if rnd.random() < 0.5:                                              # with the host hints: same bits unless the hints change the key split
         got2 = to_cpu(op(q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV), max_q_len=max(q_lens + [0]),
                          max_total_seq_len=max(kv_lens + [0]), **dkw))
-        assert torch.equal(got, got2)
+        from mojo_opset_amd.backends.hip import lib as L
+        ws = lambda hq_, hk_: L.load().mojo_hip_paged_prefill_gqa_workspace_bytes(q.shape[0], batch, hkv * g, hkv, d, page, table.shape[1], hq_, hk_)  # noqa: E731
+        if ws(0, 0) == 0 and ws(max(q_lens + [0]), max(kv_lens + [0])) == 0:
+            assert torch.equal(got, got2)
+        else:
+            torch.testing.assert_close(got.float(), got2.float(), atol=8e-3, rtol=8e-3)
 
 
 @pytest.mark.parametrize("seed", range(16))
