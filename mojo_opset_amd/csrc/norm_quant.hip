@@ -61,7 +61,7 @@ __device__ __forceinline__ float round_quotient(float y, float scale, float inv_
   return r;
 }
 
-template <typename T, int VEC, int CACHE>
+template <typename T, int VEC, int CACHE, bool NT = false /* stream_nt(): activations by-pass the caches */>
 __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
   typedef typename vec_of<T, VEC>::type V;
   __shared__ float red[4];
@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     float y[CACHE][VEC];
     float ss = 0.f;
     auto load_sum = [&](int v, float (&f)[VEC]) {
-      V x = load_vec<T, VEC>(hidden + base + v * VEC);
+      V x = NT ? load_vec_nt<T, VEC>(hidden + base + v * VEC) : load_vec<T, VEC>(hidden + base + v * VEC);
       if (residual) {
-        const V r = load_vec<T, VEC>(residual + base + v * VEC);
+        const V r = NT ? load_vec_nt<T, VEC>(residual + base + v * VEC) : load_vec<T, VEC>(residual + base + v * VEC);
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
           vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(r, j))));
@@ -96,11 +96,11 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     {
       V xr[CACHE];
 #pragma unroll
-      for (int c = 0; c < CACHE; ++c) xr[c] = load_vec<T, VEC>(hidden + base + min(tid + c * 256, n_vec - 1) * VEC);
+      for (int c = 0; c < CACHE; ++c) xr[c] = NT ? load_vec_nt<T, VEC>(hidden + base + min(tid + c * 256, n_vec - 1) * VEC) : load_vec<T, VEC>(hidden + base + min(tid + c * 256, n_vec - 1) * VEC);
       if (residual) {
         V rr[CACHE];
 #pragma unroll
-        for (int c = 0; c < CACHE; ++c) rr[c] = load_vec<T, VEC>(residual + base + min(tid + c * 256, n_vec - 1) * VEC);
+        for (int c = 0; c < CACHE; ++c) rr[c] = NT ? load_vec_nt<T, VEC>(residual + base + min(tid + c * 256, n_vec - 1) * VEC) : load_vec<T, VEC>(residual + base + min(tid + c * 256, n_vec - 1) * VEC);
 #pragma unroll
         for (int c = 0; c < CACHE; ++c)
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
       if (out_sum) {
 #pragma unroll
         for (int c = 0; c < CACHE; ++c)
-          if (tid + c * 256 < n_vec) store_vec<T, VEC>(out_sum + base + (tid + c * 256) * VEC, xr[c]);
+          if (tid + c * 256 < n_vec) { if (NT) store_vec_nt<T, VEC>(out_sum + base + (tid + c * 256) * VEC, xr[c]); else store_vec<T, VEC>(out_sum + base + (tid + c * 256) * VEC, xr[c]); }
       }
 #pragma unroll
       for (int c = 0; c < CACHE; ++c) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
       float f[VEC];
       const V x = load_sum(v, f);
-      if (out_sum) store_vec<T, VEC>(out_sum + base + v * VEC, x);
+      if (out_sum) { if (NT) store_vec_nt<T, VEC>(out_sum + base + v * VEC, x); else store_vec<T, VEC>(out_sum + base + v * VEC, x); }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) ss = fmaf(f[j], f[j], ss);
     }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
         u32x2 w;
         w[0] = q[0] | (q[1] << 8) | (q[2] << 16) | (static_cast<unsigned>(q[3]) << 24);
         w[1] = q[4] | (q[5] << 8) | (q[6] << 16) | (static_cast<unsigned>(q[7]) << 24);
-        *reinterpret_cast<u32x2*>(dst) = w;
+        if (NT) __builtin_nontemporal_store(w, reinterpret_cast<u32x2*>(dst)); else *reinterpret_cast<u32x2*>(dst) = w;
       } else if constexpr (VEC == 4) {
         *reinterpret_cast<unsigned*>(dst) = q[0] | (q[1] << 8) | (q[2] << 16) | (static_cast<unsigned>(q[3]) << 24);
       } else {
@@ -283,7 +283,9 @@ static int launch_norm_quant(const NormQuantArgs& a, hipStream_t s) {
                     (!a.out_sum || aligned_to(a.out_sum, al)) && aligned_to(a.out_q, WIDE) &&
                     (!a.weight || aligned_to(a.weight, 16)) && (!a.smooth || aligned_to(a.smooth, 16));
   int64_t blocks = a.rows > 256 * 32 ? 256 * 32 : a.rows;
-  if (wide) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  const long long moved = a.rows * static_cast<long long>(a.dim) * (static_cast<long long>(sizeof(T)) * (1 + (a.residual ? 1 : 0) + (a.out_sum ? 1 : 0)) + 1);
+  if (wide && stream_nt(moved)) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+  else if (wide) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((norm_quant_kernel<T, 1, 8>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
   MOJO_CHECK_LAUNCH("norm_quant");
   return MOJO_OK;

@@ -12,7 +12,7 @@
 
 namespace mojo {
 
-template <typename T, int VEC, int TPR, int CACHE /* vectors cached per thread */>
+template <typename T, int VEC, int TPR, int CACHE /* vectors cached per thread */, bool NT /* stream_nt(): activations by-pass the caches */>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* hidden /* may alias normed (in-place norm) */,
                                                       const T* __restrict__ residual,
                                                       const T* __restrict__ weight, T* normed,
@@ -39,13 +39,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* hidden /* may ali
     // pass 1: sum (rounded to T), square-accumulate; keep the first CACHE vectors in registers
     int c = 0;
     for (int v = tid; v < n_vec; v += TPR, ++c) {
-      V x = load_vec<T, VEC>(h + v * VEC);
+      V x = NT ? load_vec_nt<T, VEC>(h + v * VEC) : load_vec<T, VEC>(h + v * VEC);
       if (r) {
-        const V y = load_vec<T, VEC>(r + v * VEC);
+        const V y = NT ? load_vec_nt<T, VEC>(r + v * VEC) : load_vec<T, VEC>(r + v * VEC);
 #pragma unroll
         for (int j = 0; j < VEC; ++j)
           vset<T, VEC>(x, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) + elt<T>::to_f(vget<T, VEC>(y, j))));
-        if (summed && live) store_vec<T, VEC>(summed + row * dim + v * VEC, x);
+        if (summed && live) {
+          if (NT) store_vec_nt<T, VEC>(summed + row * dim + v * VEC, x); else store_vec<T, VEC>(summed + row * dim + v * VEC, x);
+        }
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* hidden /* may ali
 #pragma unroll
       for (int j = 0; j < VEC; ++j)
         vset<T, VEC>(o, j, elt<T>::from_f(elt<T>::to_f(vget<T, VEC>(x, j)) * rstd * elt<T>::to_f(vget<T, VEC>(w, j))));
-      if (live) store_vec<T, VEC>(normed + row * dim + v * VEC, o);
+      if (live) {
+        if (NT) store_vec_nt<T, VEC>(normed + row * dim + v * VEC, o); else store_vec<T, VEC>(normed + row * dim + v * VEC, o);
+      }
     }
   }
 }
@@ -102,21 +106,17 @@ static void launch_rms(const void* hidden, const void* residual, const void* wei
   const T* w = static_cast<const T*>(weight);
   T* o = static_cast<T*>(normed);
   T* so = static_cast<T*>(summed);
-  if (n_vec <= 64 * 4) {   // short rows: one wave per row, 4 rows per block
-    int64_t blocks = ceil_div(rows, 4);
+  // (an in-place norm reads what it wrote only through registers: the non-temporal forms are safe for it too)
+  const bool nt = stream_nt(rows * dim * static_cast<long long>(sizeof(T)) * (residual ? (summed ? 4 : 3) : 2));
+  auto go = [&](auto tpr_tag, int64_t blocks) {
+    constexpr int TPR = decltype(tpr_tag)::value;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 64, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
-                       static_cast<int>(dim), eps);
-  } else if (n_vec <= 128 * 4) {   // two waves per row, two rows per block: half the barriers per byte of the 256-thread form
-    int64_t blocks = ceil_div(rows, 2);
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 128, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
-                       static_cast<int>(dim), eps);
-  } else {
-    int64_t blocks = rows > 256 * 32 ? 256 * 32 : rows;
-    hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, 256, 4>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows,
-                       static_cast<int>(dim), eps);
-  }
+    if (nt) hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, TPR, 4, true>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows, static_cast<int>(dim), eps);
+    else hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, TPR, 4, false>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows, static_cast<int>(dim), eps);
+  };
+  if (n_vec <= 64 * 4) go(std::integral_constant<int, 64>{}, ceil_div(rows, 4));          // short rows: one wave per row, 4 rows per block
+  else if (n_vec <= 128 * 4) go(std::integral_constant<int, 128>{}, ceil_div(rows, 2));   // two waves per row, two rows per block
+  else go(std::integral_constant<int, 256>{}, rows);
 }
 
 template <typename T>

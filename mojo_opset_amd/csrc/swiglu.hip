@@ -27,7 +27,7 @@ __device__ __forceinline__ typename vec_of<T, VEC>::type swiglu_vec(const typena
 
 // Each thread takes UNROLL vectors per trip, all 2*UNROLL loads issued before the first use: with one vector per trip
 // a wave has 2 KiB in flight, too little to cover HBM latency at 8 resident waves per SIMD.
-template <typename T, int VEC, int UNROLL>
+template <typename T, int VEC, int UNROLL, bool NT>
 __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gate, const T* __restrict__ up,
                                                      T* __restrict__ out, int64_t n_vec, float limit) {
   typedef typename vec_of<T, VEC>::type V;
@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ gate,
 #pragma unroll
       for (int k = 0; k < UNROLL; ++k) {
         const int64_t i = base + k * 256 + threadIdx.x;
-        g[k] = load_vec<T, VEC>(gate + i * VEC);
-        u[k] = load_vec<T, VEC>(up + i * VEC);
+        g[k] = NT ? load_vec_nt<T, VEC>(gate + i * VEC) : load_vec<T, VEC>(gate + i * VEC);
+        u[k] = NT ? load_vec_nt<T, VEC>(up + i * VEC) : load_vec<T, VEC>(up + i * VEC);
       }
 #pragma unroll
       for (int k = 0; k < UNROLL; ++k) {
         const int64_t i = base + k * 256 + threadIdx.x;
-        store_vec<T, VEC>(out + i * VEC, swiglu_vec<T, VEC>(g[k], u[k], limit));
+        if (NT) store_vec_nt<T, VEC>(out + i * VEC, swiglu_vec<T, VEC>(g[k], u[k], limit));
+        else store_vec<T, VEC>(out + i * VEC, swiglu_vec<T, VEC>(g[k], u[k], limit));
       }
     } else {
       for (int64_t i = base + threadIdx.x; i < n_vec; i += 256)
@@ -100,12 +101,16 @@ static int launch_swiglu(const void* gate, const void* up, void* out, int64_t n,
   constexpr int UNROLL = 4;
   int64_t blocks = ceil_div(n_vec, 256 * UNROLL);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  if (wide)
-    hipLaunchKernelGGL((swiglu_kernel<T, WIDE, UNROLL>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
+  if (wide) {
+    const T* g_ = static_cast<const T*>(gate); const T* u_ = static_cast<const T*>(up); T* o_ = static_cast<T*>(out);
+    if (stream_nt(3 * n * static_cast<long long>(sizeof(T))))
+      hipLaunchKernelGGL((swiglu_kernel<T, WIDE, UNROLL, true>), dim3(blocks), dim3(256), 0, s, g_, u_, o_, n_vec, limit);
+    else
+      hipLaunchKernelGGL((swiglu_kernel<T, WIDE, UNROLL, false>), dim3(blocks), dim3(256), 0, s, g_, u_, o_, n_vec, limit);
+  } else {
+    hipLaunchKernelGGL((swiglu_kernel<T, 1, UNROLL, false>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
                        static_cast<const T*>(up), static_cast<T*>(out), n_vec, limit);
-  else
-    hipLaunchKernelGGL((swiglu_kernel<T, 1, UNROLL>), dim3(blocks), dim3(256), 0, s, static_cast<const T*>(gate),
-                       static_cast<const T*>(up), static_cast<T*>(out), n_vec, limit);
+  }
   MOJO_CHECK_LAUNCH("swiglu");
   return MOJO_OK;
 }
