@@ -8,11 +8,13 @@ A *step* is one pass of the hot path over one batch: paged decode attention for 
 permutation) with all inputs resident in HBM.  ``value`` = tokens/s = B * steps / time, whole job.
 With N > 1 every rank runs its own batch (the op has no exchange step: replicas, weak scaling).
 
-Extra objects on the JSON line:
-  roofline     — HBM roofline of the decode op from HIP-event time of the timed region.
-  cpu_baseline — the torch-native oracle (a port of the reference's golden backend) timed on the
-                 host cores on a bounded sample of the same workload.
-  extras       — other hot-path ops measured in the same run (absolute rate + roofline fraction).
+Output (benchmarks/result_line.py):
+  LAST stdout line — compact JSON (<= 4 KB, asserted): the contract fields + ``roofline`` (HBM roofline of the
+                 decode op from HIP-event time of the timed region), ``cpu_baseline`` (the torch-native oracle, a port
+                 of the reference's golden backend, timed on the host cores on a bounded sample of the same
+                 workload) and a six-key ``roofline_group_gemm``.
+  an EARLIER line ``EXTRAS {...}`` and ``bench_extras.json`` — everything else measured in the same run: the other
+                 hot-path ops (absolute rate + roofline fraction), per-op CPU baselines, GEMM + collective cases.
 """
 import argparse
 import json
@@ -345,7 +347,7 @@ def main():
         try:
             tj = json.load(open(tp))
             traffic = tj.get("hbm_bytes_per_launch")
-            traffic_src = f"profiles/decode_gqa_traffic.json ({tj.get('collected', 'round 1')})"
+            traffic_src = f"profiled: profiles/decode_gqa_traffic.json ({tj.get('collected', 'round 1')})"
         except Exception:
             traffic = None
 
@@ -408,14 +410,15 @@ def main():
             line["roofline_group_gemm"] = {
                 "bound": "mfma", "achieved": head["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": head["tflops"] / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": (lambda r, w: None if r is None or w is None else int(r + w))(
-                    _profiled("r2_group_gemm_traffic.json", "memory_side_read_bytes"),
-                    _profiled("r2_group_gemm_traffic.json", "memory_side_write_bytes")),
-                "traffic_source": "profiles/r2_group_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                "traffic": (lambda o: None if not isinstance(o, dict) else int(
+                    o.get("read_bytes_beyond_L2 (FETCH_SIZE KiB x 1024 x 2)", 0) + o.get("write_bytes", 0)))(
+                    _profiled("r3_group_gemm_order.json", "orders_measured_0")),
+                "traffic_source": "profiled: profiles/r3_group_gemm_order.json orders_measured_0 (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                  "WRITE_SIZE, separate passes)",
                 "algorithmic_bytes_per_launch": 2 * (16384 * 4096 + 8 * 4096 * 28672 + 16384 * 28672),
                 "flops_per_launch": 2.0 * 16384 * 4096 * 28672, "device_us_per_launch": head["us"],
-                "sustained_clock_mhz": _profiled("r2_group_gemm_counters.json", "sustained_clock_mhz"),
-                "mfma_busy_frac_profiled": _profiled("r2_group_gemm_counters.json", "mfma_busy_frac"),
+                "sustained_clock_mhz": (_profiled("r3_group_gemm_order.json", "orders_measured_0") or {}).get("sustained_clock_mhz"),
+                "mfma_busy_frac_profiled": (_profiled("r3_group_gemm_order.json", "orders_measured_0") or {}).get("mfma_busy_frac"),
                 "workload": "MojoGroupGemm bf16, Mixtral up-projection: 16384 rows over 8 experts (balanced), K=4096, N=28672, "
                             "weights [G,K,N], random data (BASELINE configs[2])",
                 "kernel": "mojo::g256::gemm256_kernel<bf16>"}
@@ -433,7 +436,7 @@ def main():
         t = _profiled("r3_traffic.json", tag)
         if not isinstance(t, dict):
             return None, None
-        return t.get("hbm_bytes_per_op"), f"profiles/r3_traffic.json:{tag} ({t.get('collected', '')}; kernels: {', '.join(t.get('kernels', []))})"
+        return t.get("hbm_bytes_per_op"), f"profiled: profiles/r3_traffic.json:{tag} ({t.get('collected', '')}; kernels: {', '.join(t.get('kernels', []))})"
 
     rec = _case("MojoPagedDecodeMLA_bf16", "B64_H128_ctx4096_page16")
     if rec:
@@ -480,7 +483,11 @@ def main():
         if not ns.no_extras:
             line["cpu_baseline_per_op"] = cpu_baselines_per_op()
     if rank == 0:                   # the line goes out before any further collective can get in its way
-        print(json.dumps(line), flush=True)
+        from benchmarks.result_line import emit
+
+        # everything measured -> bench_extras.json + an `EXTRAS ` stdout line; the LAST stdout line is the compact
+        # (<= 4 KB) contract line the driver parses
+        emit(line)
     if dist_on and not hung:
         closer = threading.Thread(target=lambda: (dist.barrier(), dist.destroy_process_group()), daemon=True)
         closer.start()

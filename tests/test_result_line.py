@@ -1,0 +1,84 @@
+"""The driver parses the LAST stdout line of bench.py; round 3's ~24 KB line was not parsed.  These tests
+feed a canned full record — round 3's real line, profiles/r3_bench_line.json, with a multi-rank `comm` block added —
+through the printer and check what the driver will see."""
+import io
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from benchmarks import result_line as rl  # noqa: E402
+
+
+def _canned(world=1):
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_line.json")))
+    assert len(json.dumps(full)) > 8192                  # the record that broke the parser
+    if world > 1:
+        full["n_gpus"] = world
+        full["comm"] = {"backend": "nccl", "world_observed": world, "ranks": [f"AMD Instinct MI355X (device {i})" for i in range(world)],
+                        "rccl_version": "2.26.6", "xgmi_link_peak_GBps": 153.0, "per_case": "x" * 300}
+        full.setdefault("extras", {}).setdefault("compute_comm_bf16", {})[f"gemm_allreduce_M4096_K28672_N8192_tp{world}"] = {
+            "us": 400.123456, "aggregate_tflops": 9621.5, "speedup_vs_tp1": 6.7, "algorithm": "direct", "exposed_exchange_us": 31.0,
+            "payload_MB_per_rank": 67.1}
+    return full
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_last_line_is_compact_parseable_and_complete(tmp_path, world):
+    buf = io.StringIO()
+    rl.emit(_canned(world), out=buf, extras_path=str(tmp_path / "bench_extras.json"))
+    lines = buf.getvalue().splitlines()
+    assert lines[-2].startswith("EXTRAS {")
+    last = lines[-1]
+    assert len(last.encode()) <= rl.MAX_LINE_BYTES
+    rec = json.loads(last)
+    for k in rl.CONTRACT_KEYS:
+        assert k in rec, k
+    assert rec["config"]["workload"].startswith("MojoPagedDecodeGQA")
+    for k in rl.ROOFLINE_KEYS:
+        assert k in rec["roofline"], k
+    assert rec["roofline"]["frac"] == pytest.approx(rec["roofline"]["achieved"] / rec["roofline"]["peak"], rel=1e-4)
+    for k in rl.CPU_KEYS:
+        assert k in rec["cpu_baseline"], k
+    assert set(rec["roofline_group_gemm"]) <= set(rl.GROUP_GEMM_KEYS) and len(rec["roofline_group_gemm"]) <= 6
+    assert "extras" not in rec and "cpu_baseline_per_op" not in rec
+    if world > 1:
+        assert rec["comm"]["world_observed"] == world
+        assert rec["comm"]["gemm_allreduce_M4096_K28672_N8192"]["speedup_vs_tp1"] == 6.7
+        assert "ranks" not in rec["comm"]
+    # everything else is in the file and on the EXTRAS line
+    side = json.load(open(tmp_path / "bench_extras.json"))
+    assert "extras" in side and "cpu_baseline_per_op" in side
+    assert json.loads(lines[-2][len("EXTRAS "):])["extras"].keys() == side["extras"].keys()
+    # the 8 KB tail the driver keeps holds the whole last line
+    assert buf.getvalue()[-8192:].splitlines()[-1] == last
+
+
+def test_oversized_or_incomplete_records_raise_before_printing(tmp_path):
+    full = _canned()
+    full["config"] = {f"k{i}": "v" * 190 for i in range(40)}
+    buf = io.StringIO()
+    with pytest.raises(ValueError, match="bytes"):
+        rl.emit(full, out=buf, extras_path=str(tmp_path / "x.json"))
+    assert buf.getvalue() == ""
+    full = _canned()
+    del full["roofline"]
+    with pytest.raises(ValueError, match="roofline"):
+        rl.compact_line(full)
+
+
+@pytest.mark.gpu
+def test_bench_last_line_parses_on_the_gpu_box():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-extras"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.strip().splitlines()[-1]
+    assert len(last.encode()) <= rl.MAX_LINE_BYTES
+    rec = json.loads(last)
+    assert rec["steps"] == 5 and rec["warmup"] == 2 and rec["n_gpus"] == 1
+    assert rec["value"] > 0 and 0 < rec["roofline"]["frac"] < 1
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
