@@ -26,7 +26,7 @@ REQUIRED = CONTRACT_KEYS + ("roofline",)
 
 
 def _clip(s, n):
-    return s if not isinstance(s, str) or len(s) <= n else s[: n - 1] + "…"
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
 
 
 def _num(v, digits=6):

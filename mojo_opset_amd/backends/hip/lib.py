@@ -123,8 +123,38 @@ def load():
                 raise MojoHipError(f"{path} does not export {name}; rebuild the library") from e
             fn.restype = res
             fn.argtypes = args
+        _check_source_hash(handle, path)
         _lib = handle
     return _lib
+
+
+def built_with_experiments() -> bool:
+    """True when the loaded library was built with MOJO_HIP_BUILD_EXPERIMENTS=1 (csrc/experiments/ kernels present)."""
+    return "+experiments" in load().mojo_hip_version().decode()
+
+
+def _check_source_hash(handle, path):
+    """The prebuilt library travels with the tree (gpurun snapshot): refuse one built from OTHER sources than the
+    ``csrc/`` + ``include/`` beside it.  ``mojo_hip_version()`` ends in ``src=<hash>`` (csrc/build.py::source_hash).
+    Skipped when the sources are not there (a library deployed on its own) or with MOJO_HIP_ALLOW_STALE=1."""
+    if os.environ.get("MOJO_HIP_ALLOW_STALE", "") == "1":
+        return
+    if os.path.abspath(path) != os.path.abspath(DEFAULT_LIB):
+        return
+    try:
+        from mojo_opset_amd.csrc.build import hashed_files, source_hash
+
+        if not hashed_files():
+            return
+        want = source_hash()
+    except (ImportError, OSError):
+        return
+    version = handle.mojo_hip_version().decode()
+    have = version.rsplit("src=", 1)[-1] if "src=" in version else "unstamped"
+    if have != want:
+        raise MojoHipError(
+            f"{path} was built from other sources than this tree (library src={have}, tree src={want}). Rebuild it with "
+            f"`python -m mojo_opset_amd.csrc.build` (or set MOJO_HIP_ALLOW_STALE=1 to load it anyway).")
 
 
 c_void_p = c_void_p  # re-export for callers that build offset pointers

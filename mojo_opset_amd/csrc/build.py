@@ -9,6 +9,7 @@ snapshot to the GPU box.
 import argparse
 import concurrent.futures
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -29,6 +30,27 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
+def hashed_files():
+    """The files whose contents the library is stamped with (sorted, relative to the repository root)."""
+    root = os.path.dirname(PKG)
+    files = (glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(HERE, "*.h")) +
+             glob.glob(os.path.join(HERE, "experiments", "*.h")) + glob.glob(os.path.join(root, "include", "*.h")))
+    return sorted(os.path.relpath(f, root) for f in files)
+
+
+def source_hash() -> str:
+    """sha256 over names and contents of the kernel sources and the C-ABI header: what `mojo_hip_version()` reports after
+    ``src=`` and what ``lib.load()`` checks against the tree it finds the library in."""
+    root = os.path.dirname(PKG)
+    h = hashlib.sha256()
+    for rel in hashed_files():
+        h.update(rel.encode() + b"\0")
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -41,15 +63,26 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     sources = sorted(glob.glob(os.path.join(HERE, "*.hip")))
-    headers = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(os.path.dirname(PKG), "include", "mojo_hip.h")]
+    headers = (sorted(glob.glob(os.path.join(HERE, "*.h"))) + sorted(glob.glob(os.path.join(HERE, "experiments", "*.h"))) +
+               [os.path.join(os.path.dirname(PKG), "include", "mojo_hip.h")])
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
              "-fno-gpu-rdc", "-ffp-contract=on"]
+    if os.environ.get("MOJO_HIP_BUILD_EXPERIMENTS", "") == "1":     # the measured-and-dropped kernels of csrc/experiments/
+        flags.append("-DMOJO_HIP_BUILD_EXPERIMENTS")
     flags += os.environ.get("MOJO_HIP_EXTRA_CXXFLAGS", "").split()   # e.g. -DMLA_DBG_TIMERS for kernel phase timers
+    # a change of flags rebuilds everything (object staleness is otherwise by mtime)
+    flags_file = os.path.join(OBJ_DIR, "flags.txt")
+    if not os.path.exists(flags_file) or open(flags_file).read() != " ".join(flags):
+        force = True
+    src_hash = source_hash()
+    stamp_file = os.path.join(OBJ_DIR, "source_hash.txt")
+    stamp_changed = not os.path.exists(stamp_file) or open(stamp_file).read() != src_hash
 
     def compile_one(src):
         obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + headers):
-            cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        stamped = os.path.basename(src) == "api_common.hip"          # the one file that carries the source hash
+        if force or _stale(obj, [src] + headers) or (stamped and stamp_changed):
+            cmd = [hipcc, *flags, *([f'-DMOJO_SRC_HASH="{src_hash}"'] if stamped else []), "-c", src, "-o", obj]
             if verbose:
                 print("[mojo_hip] hipcc", os.path.basename(src), flush=True)
             res = subprocess.run(cmd, capture_output=True, text=True)
@@ -59,6 +92,10 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> str:
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
         objs = list(pool.map(compile_one, sources))
+    with open(flags_file, "w") as f:
+        f.write(" ".join(flags))
+    with open(stamp_file, "w") as f:
+        f.write(src_hash)
     if force or _stale(LIB_PATH, objs):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -14,6 +14,14 @@
 
 namespace mojo {
 
+// Kernels that were built, measured slower and dropped (DESIGN Appendix A) live in csrc/experiments/ and are compiled
+// only when the library is built with MOJO_HIP_BUILD_EXPERIMENTS=1 (csrc/build.py adds the define).
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+constexpr bool kExperimentsBuild = true;
+#else
+constexpr bool kExperimentsBuild = false;
+#endif
+
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
 

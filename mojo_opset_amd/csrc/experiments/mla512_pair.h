@@ -35,16 +35,7 @@
 
 namespace mojo {
 
-// K-fragment batch B of the paired kernel's QK^T: 4 reads, linear index n = 4B + i -> key tile n / 18, k-step n % 18
-template <int B, int I = 0>
-__device__ __forceinline__ void mlap_k_issue(u32x4 (&dst)[4], const unsigned (&kav)[4], const unsigned (&kbv)[2]) {
-  constexpr int n = 4 * B + I, tt = n / 18, ks = n % 18;
-  if constexpr (ks < 16)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kav[ks & 3]), "i"(tt * 16384 + (ks >> 2) * 256) : "memory");
-  else
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kbv[ks - 16]), "i"(tt * 2048) : "memory");
-  if constexpr (I + 1 < 4) mlap_k_issue<B, I + 1>(dst, kav, kbv);
-}
+// (mlap_k_issue, the K-fragment batch reader, lives in mla512_oct.h, which is included first)
 
 template <typename T>
 __global__ __launch_bounds__(256, 1) void mla512_pair_kernel(MlaArgs a) {

@@ -15,7 +15,7 @@
 #pragma once
 #include <atomic>
 
-#include "common.h"
+#include "../common.h"
 
 namespace mojo {
 

@@ -11,7 +11,9 @@
 //
 // Algorithmic bytes: G*K*N*elt (weights) + M*K*elt * (N/64) (activations, from L2) + M*N*elt.
 #include "gemm.h"
-#include "splitk_combine.h"
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS        // in-launch split-K combine, measured slower (DESIGN Appendix A #9): opt-in build only
+#include "experiments/splitk_combine.h"
+#endif
 
 namespace mojo {
 
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
     }
     *reinterpret_cast<V4*>(C + static_cast<int64_t>(RAGGED ? row_base + t : map_row(row_base + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
   };
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   if (a.splitk > 1 && a.sk_slot >= 0) {
     // raw fp32 partials of this K slice, write-through; the last slice of the tile to arrive sums all of them (splitk_combine.h)
     const long long slice_bytes = static_cast<long long>(a.slab_rows) * a.N * 4;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
     }
     return;
   }
+#endif
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int t = t0 + mt * 16 + l15;
@@ -270,8 +274,11 @@ int launch_gemm_skinny(const GemmArgs& a_in, int dtype, hipStream_t s) {
   MOJO_REQUIRE(gemm_skinny_ok(a_in, dtype), MOJO_EUNSUPPORTED, "gemm_skinny: preconditions not met");
   GemmArgs a = a_in;
   const int mt = (a.uniform_rows + 15) / 16;
+  a.sk_slot = -1;
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   if (a.splitk > 1)                                      // K slices combined by the last one to arrive, inside this launch
     a.sk_slot = splitk_take_slot(static_cast<int64_t>(a.N / 64) * a.G * (mt > 4 ? 2 : 1));
+#endif
   const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(a.G * (mt > 4 ? 2 : 1)), static_cast<unsigned>(a.splitk));
 #define SKINNY(TY, MT_, RB_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_, RB_>), grid, dim3(256), 0, s, a)
 #define SKINNY_MT(TY)                                                                          \

@@ -1,5 +1,5 @@
 // mla512_oct_kernel: the r = 512 / rope = 64 latent-attention kernel with TWO waves per SIMD.
-// Included by mla_attn.hip after mla512_pair.h (shares mlap_k_issue, MlaArgs, mla_mfma).
+// Included by mla_attn.hip (shares MlaArgs, mla_mfma); the default for pages below 16 tokens, MOJO_HIP_MLA_KERNEL=oct elsewhere.
 //
 // Same paired-halves idea as mla512_pair_kernel, but a wave owns 16 heads instead of 32: wave = (hq, half) with
 // hq = wave & 3 (heads 16*hq .. +15 of the workgroup's 64) and half = wave >> 2 (QK^T over keys 32*half .. +31, PV over
@@ -10,6 +10,18 @@
 #pragma once
 
 namespace mojo {
+
+// K-fragment batch B of the paired kernel's QK^T: 4 reads, linear index n = 4B + i -> key tile n / 18, k-step n % 18
+template <int B, int I = 0>
+__device__ __forceinline__ void mlap_k_issue(u32x4 (&dst)[4], const unsigned (&kav)[4], const unsigned (&kbv)[2]) {
+  constexpr int n = 4 * B + I, tt = n / 18, ks = n % 18;
+  if constexpr (ks < 16)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kav[ks & 3]), "i"(tt * 16384 + (ks >> 2) * 256) : "memory");
+  else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[I]) : "v"(kbv[ks - 16]), "i"(tt * 2048) : "memory");
+  if constexpr (I + 1 < 4) mlap_k_issue<B, I + 1>(dst, kav, kbv);
+}
+
 
 #ifdef MLA_STAMPS
 // In-kernel stamps (build with MOJO_HIP_EXTRA_CXXFLAGS=-DMLA_STAMPS): lane i of `tacc` accumulates the cycles between stamp

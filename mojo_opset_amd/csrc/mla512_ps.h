@@ -1,5 +1,5 @@
 // mla512_ps_kernel: the r = 512 / rope = 64 latent-attention kernel with SPECIALISED waves (round 3).
-// Included by mla_attn.hip after mla512_pp.h (shares MlaArgs, lds_m).
+// Included by mla_attn.hip after mla512_oct.h (shares MlaArgs, lds_m).
 //
 // What bounded the lock-step kernel (mla512_oct.h) and the ping-pong kernel (mla512_pp.h) was the length of ONE wave's serial
 // stream per key: every wave did QK^T, softmax, an exchange with its partner, PV and its share of the staging, so at most

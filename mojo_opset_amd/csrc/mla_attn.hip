@@ -349,9 +349,11 @@ __global__ __launch_bounds__(512 / NQ, NQ == 1 ? 2 : 1) void mla_latent_kernel(M
 }
 
 }  // namespace mojo
-#include "mla512_pair.h"
 #include "mla512_oct.h"
-#include "mla512_pp.h"
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS        // measured-slower kernels of rounds 2-3 (DESIGN Appendix A #12): opt-in build only
+#include "experiments/mla512_pair.h"
+#include "experiments/mla512_pp.h"
+#endif
 #include "mla512_ps.h"
 namespace mojo {
 
@@ -426,29 +428,33 @@ template <typename T>
 static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
   if (r == 512 && rope == 64 && a.page_shift >= 0) {
     const int head_blocks = (a.heads + 63) / 64;
-    // MOJO_HIP_MLA_KERNEL: "pp" the ping-pong kernel (32-key tiles, the two waves of a SIMD one segment apart), "oct" two
-    // waves per SIMD in lock-step on 64-key tiles, "pair" one wave per SIMD with 32 heads
+    // MOJO_HIP_MLA_KERNEL: "ps" specialised waves (default), "oct" two waves per SIMD in lock-step on 64-key tiles (the
+    // kernel for pages below 16 tokens); an experiments build adds "pp" (ping-pong) and "pair" (one wave per SIMD)
     int which = [] {                                     // read per call: the tests switch kernels inside one process
       const char* e = getenv("MOJO_HIP_MLA_KERNEL");
       if (!e) return MLA512_DEFAULT_KERNEL;
-      if (e[0] == 'p' && e[1] == 'a') return 1;
       if (e[0] == 'p' && e[1] == 's') return 3;
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+      if (e[0] == 'p' && e[1] == 'a') return 1;
       if (e[0] == 'p') return 2;
+#endif
       return 0;
     }();
     if (which == 3 && a.page_shift < 4) which = 0;       // a loader's 16 rows must share one page id: pages of >= 16 tokens
-    if (which == 1) {
-      void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
-      hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
-    } else if (which == 3) {
+    if (which == 3) {
       void (*fn)(MlaArgs) = mla512_ps_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PS_LDS);
       hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(512), MLA512_PS_LDS, s, a);
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+    } else if (which == 1) {
+      void (*fn)(MlaArgs) = mla512_pair_kernel<T>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PAIR_LDS);
+      hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(256), MLA512_PAIR_LDS, s, a);
     } else if (which == 2) {
       void (*fn)(MlaArgs) = mla512_pp_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_PP_LDS);
       hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(512), MLA512_PP_LDS, s, a);
+#endif
     } else {
       void (*fn)(MlaArgs) = mla512_oct_kernel<T>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MLA512_OCT_LDS);

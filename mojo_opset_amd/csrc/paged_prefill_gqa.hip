@@ -54,7 +54,7 @@ struct PrefillArgs {
   // becomes `ksplit` workgroups that each walk a slice of the block's key tiles and leave un-normalised fp32 partials;
   // prefill_merge_kernel combines them.  ksplit == 1: no workspace, the workgroup writes `out` itself.
   int ksplit;
-  int pp;                    // 1: prefill_pp_kernel (paged_prefill_pp.h): 8-wave workgroups of 256 rows, n_qb counts blocks of 256 / G positions
+  int pp;                    // 1 (experiments build only): prefill_pp_kernel (experiments/paged_prefill_pp.h): 8-wave workgroups of 256 rows, n_qb counts blocks of 256 / G positions
   float* ws_o;               // [blocks * ksplit][128 rows][dim]
   float* ws_ml;              // [blocks * ksplit][128 rows][2]   reference maximum (log2 units), row sum
 };
@@ -718,7 +718,11 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
 }
 
 }  // namespace mojo
-#include "paged_prefill_pp.h"
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS        // phase-alternating kernel, measured 5-20 % slower (DESIGN Appendix A #10a): opt-in build only
+#include "experiments/paged_prefill_pp.h"
+#else
+namespace mojo { constexpr int PP_TABLE = 0; }
+#endif
 namespace mojo {
 
 template <typename T, int G, int DK>
@@ -728,12 +732,16 @@ static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_kernel<T, G, DK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_kernel<T, G, DK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
   }
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   if (a.pp) {
     static std::atomic<uint64_t> pp_attr_set{0};
     if (first_call_on_device(pp_attr_set))
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_pp_kernel<T, G, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     hipLaunchKernelGGL((prefill_pp_kernel<T, G, DK>), grid, dim3(512), PP_LDS, s, a);
-  } else if (a.ksplit > 1) {
+    return;
+  }
+#endif
+  if (a.ksplit > 1) {
     hipLaunchKernelGGL((prefill_kernel<T, G, DK, true>), grid, dim3(256), PF_LDS, s, a);
     hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch * PF_MERGE_SPLIT)), dim3(256), 0, s, a);
   } else {
@@ -754,16 +762,17 @@ static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
 }
 
 static bool prefill_use_pp(int64_t max_q) {
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   const char* e = getenv("MOJO_HIP_PREFILL_PP");
-  if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
+#endif
   return false;
 }
 
 template <typename T>
 static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStream_t s) {
-  // The phase-alternating kernel (paged_prefill_pp.h) takes unsplit launches over pages it can stage with scalar page ids.
-  // MOJO_HIP_PREFILL_PP: 0 = never, 1 = wherever it applies; unset = the measured policy (see prefill_use_pp).
+  // Experiments build only: the phase-alternating kernel takes unsplit launches over pages it can stage with scalar page
+  // ids when MOJO_HIP_PREFILL_PP=1.
   a.pp = (a.ksplit == 1 && a.fast_stage && a.max_pages <= PP_TABLE && prefill_use_pp(max_q)) ? 1 : 0;
   const int qpb = (a.pp ? 256 : 128) / G;
   const int64_t n_qb = ceil_div(max_q, qpb);

@@ -11,7 +11,9 @@
 #include <type_traits>
 
 #include "gemm256_core.h"
-#include "splitk_combine.h"
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS        // in-launch split-K combine, measured slower (DESIGN Appendix A #9): opt-in build only
+#include "experiments/splitk_combine.h"
+#endif
 
 namespace mojo {
 
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
     }
     *reinterpret_cast<V4*>(C + static_cast<int64_t>(m) * N + n) = o;
   };
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   if (splitk > 1 && sk_slot >= 0) {
     // raw accumulators of this K slice, write-through; the last slice of the tile to arrive sums all of them in slice order
     // (splitk_combine.h) and applies the scales: one launch instead of two
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
     }
     return;
   }
+#endif
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = m0 + mt * 16 + l15;
@@ -405,7 +409,11 @@ static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t*
   const uint8_t* W = static_cast<const uint8_t*>(a.W);
   TO* C = static_cast<TO*>(a.C);
   const int M = static_cast<int>(m);
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   const int slot = sk > 1 ? splitk_take_slot(static_cast<int64_t>(grid.x) * grid.z) : -1;   // K slices combined inside the launch
+#else
+  const int slot = -1;
+#endif
 #define SKINNY(MT_, NT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_, NT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk, slot)
   if (m <= 16) SKINNY(1, true); else if (m <= 32) SKINNY(2, true); else if (m <= 64) SKINNY(4, true); else SKINNY(4, false);
 #undef SKINNY

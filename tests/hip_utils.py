@@ -9,6 +9,17 @@ from conftest import build_op, clone_tree, to_device
 DEV = "cuda"
 
 
+def skip_unless_experiments_build():
+    """Kernels under csrc/experiments/ (measured slower, DESIGN Appendix A) are compiled only with
+    MOJO_HIP_BUILD_EXPERIMENTS=1; their tests run against such a build and skip otherwise."""
+    import pytest
+
+    from mojo_opset_amd.backends.hip import lib
+
+    if not lib.built_with_experiments():
+        pytest.skip("library built without MOJO_HIP_BUILD_EXPERIMENTS=1")
+
+
 def hip_cls(op_name):
     return getattr(mo, op_name).get_backend_impl("hip", strict=True)
 

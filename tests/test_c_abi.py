@@ -101,9 +101,30 @@ def test_every_environment_switch_of_the_package_is_documented():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = set()
-    for pat in ("mojo_opset_amd/csrc/*.hip", "mojo_opset_amd/csrc/*.h", "mojo_opset_amd/**/*.py"):
+    for pat in ("mojo_opset_amd/csrc/*.hip", "mojo_opset_amd/csrc/*.h", "mojo_opset_amd/csrc/experiments/*.h", "mojo_opset_amd/**/*.py"):
         for path in glob.glob(os.path.join(root, pat), recursive=True):
             names.update(re.findall(r"MOJO_HIP_[A-Z0-9_]+", open(path).read()))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc)
     assert len(names) > 30 and not missing, missing
+
+
+def test_library_is_stamped_with_the_hash_of_the_tree_and_a_stale_one_is_refused(monkeypatch):
+    """`mojo_hip_version()` ends in `src=<hash of csrc/ + include/>`; `lib.load()` recomputes the hash from the tree the
+    library sits in and refuses a library built from other sources (the prebuilt .so travels with the snapshot)."""
+    from mojo_opset_amd.backends.hip import lib
+    from mojo_opset_amd.csrc import build as B
+
+    version = lib.load().mojo_hip_version().decode()
+    assert version.endswith("src=" + B.source_hash()), version
+    assert all(f.endswith((".hip", ".h")) for f in B.hashed_files()) and "include/mojo_hip.h" in B.hashed_files()
+
+    class _Stale:
+        @staticmethod
+        def mojo_hip_version():
+            return b"mojo_hip 0.2.0 (gfx950) src=0000000000000000"
+
+    with pytest.raises(lib.MojoHipError, match="built from other sources"):
+        lib._check_source_hash(_Stale, lib.DEFAULT_LIB)
+    monkeypatch.setenv("MOJO_HIP_ALLOW_STALE", "1")
+    lib._check_source_hash(_Stale, lib.DEFAULT_LIB)              # explicit override

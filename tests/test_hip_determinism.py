@@ -8,7 +8,7 @@ import math
 import pytest
 import torch
 
-from hip_utils import DEV, hip_cls
+from hip_utils import DEV, hip_cls, skip_unless_experiments_build
 from test_hip_decode_gqa import make_decode_inputs
 from test_hip_mla import build, cu, make_mla
 from test_hip_prefill_gqa import make_prefill_inputs
@@ -49,6 +49,8 @@ def test_prefill_gqa_is_bit_stable(q_lens, cached):
 
 @pytest.mark.parametrize("kernel", ["ps", "oct", "pp", "pair"])
 def test_mla_decode_is_bit_stable(kernel, monkeypatch):
+    if kernel in ("pp", "pair"):
+        skip_unless_experiments_build()
     b, h, nope, rope, vd, r, page = 16, 128, 128, 64, 128, 512, 16
     g = torch.Generator().manual_seed(2)
     lens = torch.randint(300, 2049, (b,), generator=g).tolist()

@@ -113,11 +113,12 @@ def test_dense_gemm_split_over_k_for_few_output_tiles_is_exact(m, k, n, bias, dt
 
 
 def test_split_k_combined_inside_the_launch_gives_the_finalize_kernels_bits(monkeypatch):
-    """csrc/splitk_combine.h: the last K slice to arrive sums all slices in index order.  Same bits as the two-launch form
+    """csrc/experiments/splitk_combine.h (experiments build only): the last K slice to arrive sums all slices in index order.  Same bits as the two-launch form
     (the default; MOJO_HIP_SPLITK_INLAUNCH=1 selects the combine), the same bits launch after launch while OTHER products keep the chip unevenly busy (the
     hand-off must not depend on placement or timing), across more calls than there are ticket slots (64), for bf16, int8
     and fp8."""
-    from hip_utils import hip_cls
+    from hip_utils import hip_cls, skip_unless_experiments_build
+    skip_unless_experiments_build()
     torch.manual_seed(3)
     cases = []
     for m, k, n in ((64, 8192, 1024), (17, 14336, 512), (128, 8192, 512), (1, 28672, 64)):

@@ -256,3 +256,173 @@ def test_decoder_layer_as_one_graph_matches_the_oracle_chain():
         # the step wrote exactly one token per sequence into the cache
         changed = (to_cpu(k_cache) != k_cache0).flatten(2).any(-1)          # [blocks, hkv]
         assert int(changed.any(-1).sum()) <= b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Graph-captured PREFILL (the reference's test_paged_prefill_gqa_with_graph,
+# mojo_opset/tests/accuracy/operators/test_attention.py:584-760): bucket-padded static buffers sized by
+# (max_batch, max_q_len, max_kv_computed_len), one capture with the `max_q_len` / `max_total_seq_len` bounds, replay,
+# compare with the golden.  Beyond the reference's single replay, lengths / tables / data are then MUTATED IN PLACE and the
+# same graph is replayed again: everything the launch derived on the host (grid, key split, workspace) came from the static
+# bounds, so shorter sequences must still come out right, and padding tokens behind the last sequence must come out zero.
+# ---------------------------------------------------------------------------------------------------------------------
+def _prefill_bucket(batch, hq, hkv, d, max_q, max_cached, page, seed):
+    """Static buffers of one bucket, filled for the bucket's largest batch (as generate_paged_prefill_data_with_graph)."""
+    g = torch.Generator().manual_seed(seed)
+    max_kv = max_q + max_cached
+    width = (max_kv + page - 1) // page
+    n_blocks = batch * width + 10
+    return dict(
+        q=torch.randn(batch * max_q, hq, d, generator=g).to(torch.bfloat16),
+        k=torch.randn(n_blocks, hkv, page, d, generator=g).to(torch.bfloat16),
+        v=torch.randn(n_blocks, hkv, page, d, generator=g).to(torch.bfloat16),
+        table=torch.randperm(n_blocks, generator=g, dtype=torch.int32)[: batch * width].view(batch, width).contiguous(),
+        max_q=max_q, max_kv=max_kv, width=width, page=page)
+
+
+def _cu(lens):
+    return torch.tensor([0] + list(torch.tensor(lens).cumsum(0).tolist()), dtype=torch.int32)
+
+
+def _fill_lengths(bucket, q_lens, cached):
+    """cu_q / cu_kv / block table of a batch that fits the bucket; unused table entries are -1 (the reference pads its
+    decode tables the same way, test_attention.py:318-326)."""
+    kv = [a + b for a, b in zip(q_lens, cached)]
+    table = bucket["table"].clone()
+    for i, n in enumerate(kv):
+        table[i, (n + bucket["page"] - 1) // bucket["page"]:] = -1
+    return _cu(q_lens), _cu(kv), table, kv
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 16, 4, 128, 1024, 1024, 32), (2, 16, 4, 96, 1024, 1024, 128), (2, 8, 1, 128, 4096, 8192, 128), (2, 8, 1, 128, 1024, 2048, 1024),
+], ids=["M_BF16", "M_BF16_PADDIM", "M_BF16_WITH_CACHE", "M_BF16_BIGPAGE"])
+def test_paged_prefill_gqa_with_graph(cfg):
+    import math
+
+    from hip_utils import assert_close_tree, to_cpu, torch_cls
+
+    batch, hq, hkv, d, max_q, max_cached, page = cfg
+    bk = _prefill_bucket(batch, hq, hkv, d, max_q, max_cached, page, seed=sum(cfg))
+    op, ref = hip_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout="AABB"), torch_cls("MojoPagedPrefillGQA")(is_causal=True, gqa_layout="AABB")
+    scale = 1.0 / math.sqrt(d)
+    cu_q0, cu_kv0, table0, _ = _fill_lengths(bk, [max_q] * batch, [max_cached] * batch)
+    q, k, v = bk["q"].to(DEV), bk["k"].to(DEV), bk["v"].to(DEV)
+    cu_q, cu_kv, table = cu_q0.to(DEV), cu_kv0.to(DEV), table0.to(DEV)
+    kw = dict(softmax_scale=scale, max_q_len=bk["max_q"], max_total_seq_len=bk["max_kv"])
+    graph, static_out = _capture(lambda: op(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv, **kw), warmup=1)
+
+    def check(cu_q_c, cu_kv_c, table_c, q_c, what):
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ref(q_c, bk["k"], bk["v"], cu_q_c, table_c, cu_total_seq_lens=cu_kv_c, **kw)
+        got = to_cpu(static_out)
+        used = int(cu_q_c[-1])
+        assert_close_tree(got[:used], want[:used], 2e-2, 2e-2)
+        assert not got[used:].float().abs().any(), f"{what}: padding tokens behind the batch must come out zero"
+
+    # (1) the reference's test: replay on the capture-time inputs
+    check(cu_q0, cu_kv0, table0, bk["q"], "full bucket")
+    # (2) a smaller, ragged batch in the same bucket: mutate lengths, table and queries in place, replay the same graph
+    g = torch.Generator().manual_seed(7)
+    q_lens = [max_q // 2 + 13, 1][:batch]
+    cached = [max_cached // 3 + 5, max_cached][:batch]
+    cu_q1, cu_kv1, table1, _ = _fill_lengths(bk, q_lens, cached)
+    q1 = torch.randn(bk["q"].shape, generator=g).to(torch.bfloat16)
+    for dst, src in ((cu_q, cu_q1), (cu_kv, cu_kv1), (table, table1), (q, q1)):
+        dst.copy_(src)
+    check(cu_q1, cu_kv1, table1, q1, "ragged batch")
+    # (3) one sequence only (the second row of the bucket is empty: q_len = 0)
+    cu_q2, cu_kv2, table2, _ = _fill_lengths(bk, [max_q - 1, 0], [0, 0])
+    for dst, src in ((cu_q, cu_q2), (cu_kv, cu_kv2), (table, table2)):
+        dst.copy_(src)
+    check(cu_q2, cu_kv2, table2, q1, "one live sequence")
+
+
+def test_paged_prefill_gqa_key_split_with_graph():
+    """A chunked prefill against a long cache takes the KEY SPLIT (fp32 partials in a workspace + a merge launch; the
+    number of slices and the workspace size are host decisions): captured with the bucket's bounds, replayed on shorter
+    caches — slices that hold no keys must contribute nothing."""
+    import math
+
+    from hip_utils import assert_close_tree, to_cpu, torch_cls
+    from mojo_opset_amd.backends.hip import lib as L
+
+    batch, hq, hkv, d, max_q, max_cached, page = 1, 32, 8, 128, 256, 6144, 16
+    bk = _prefill_bucket(batch, hq, hkv, d, max_q, max_cached, page, seed=5)
+    # the launch this bucket produces does take the split (a non-zero workspace is the library's own statement of it)
+    assert L.load().mojo_hip_paged_prefill_gqa_workspace_bytes(batch * max_q, batch, hq, hkv, d, page, bk["width"], max_q, bk["max_kv"]) > 0
+    op, ref = hip_cls("MojoPagedPrefillGQA")(), torch_cls("MojoPagedPrefillGQA")()
+    cu_q0, cu_kv0, table0, _ = _fill_lengths(bk, [max_q], [max_cached])
+    q, k, v = bk["q"].to(DEV), bk["k"].to(DEV), bk["v"].to(DEV)
+    cu_q, cu_kv, table = cu_q0.to(DEV), cu_kv0.to(DEV), table0.to(DEV)
+    kw = dict(softmax_scale=1.0 / math.sqrt(d), max_q_len=bk["max_q"], max_total_seq_len=bk["max_kv"])
+    graph, static_out = _capture(lambda: op(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv, **kw), warmup=1)
+    for q_len, cache in ((max_q, max_cached), (200, 3000), (256, 100), (17, 0)):
+        cu_q1, cu_kv1, table1, _ = _fill_lengths(bk, [q_len], [cache])
+        for dst, src in ((cu_q, cu_q1), (cu_kv, cu_kv1), (table, table1)):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = ref(bk["q"], bk["k"], bk["v"], cu_q1, table1, cu_total_seq_lens=cu_kv1, **kw)
+        got = to_cpu(static_out)
+        assert_close_tree(got[:q_len], want[:q_len], 2e-2, 2e-2)
+        assert not got[q_len:].float().abs().any()
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 128, 64, 128, 512, 512, 512, 16), (3, 8, 128, 64, 128, 512, 200, 0, 16)], ids=["cached", "nocache"])
+def test_paged_prefill_mla_with_graph(cfg):
+    """HIPPagedPrefillMLA on its decompressed route under capture: the un-paged latent, the decompressed K/V image and the
+    GEMM workspace are sized from STATIC bounds (block-table width x page, `max_total_seq_len`, the query buffer), the
+    device-side key count drives the GEMM's row count — so one graph serves every batch of the bucket."""
+    from hip_utils import to_cpu, torch_cls
+
+    batch, h, nope, rope, vd, r, max_q, max_cached, page = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    max_kv = max_q + max_cached
+    width = (max_kv + page - 1) // page
+    n_blocks = batch * width + 3
+    ckv = torch.randn(n_blocks, 1, page, r, generator=g).to(torch.bfloat16)
+    kpe = torch.randn(n_blocks, 1, page, rope, generator=g).to(torch.bfloat16)
+    table_full = torch.randperm(n_blocks, generator=g, dtype=torch.int32)[: batch * width].view(batch, width).contiguous()
+    w = (torch.randn(h * (nope + vd), r, generator=g) * 0.05).to(torch.bfloat16)
+    q_full = torch.randn(batch * max_q, h, nope + rope, generator=g).to(torch.bfloat16)
+
+    def make(cls, device):
+        op = cls("MojoPagedPrefillMLA")(h, nope, rope, vd, r, is_causal=True).to(torch.bfloat16).to(device)
+        with torch.no_grad():
+            op.kv_b_proj.copy_(w.to(device))
+        return op
+
+    op, ref = make(hip_cls, DEV), make(torch_cls, "cpu")
+    with_cache = max_cached > 0
+
+    def lengths(q_lens, cached):
+        kv = [a + b for a, b in zip(q_lens, cached)]
+        table = table_full.clone()
+        for i, n in enumerate(kv):
+            table[i, (n + page - 1) // page:] = -1
+        return _cu(q_lens), _cu(kv), table
+
+    cu_q0, cu_kv0, table0 = lengths([max_q] * batch, [max_cached] * batch)
+    q, ckv_d, kpe_d = q_full.to(DEV), ckv.to(DEV), kpe.to(DEV)
+    cu_q, cu_kv, table = cu_q0.to(DEV), cu_kv0.to(DEV), table0.to(DEV)
+
+    def call(o, q_, ckv_, kpe_, cu_q_, table_, cu_kv_, **extra):
+        return o(q_, ckv_, kpe_, cu_q_, table_, cu_total_seq_lens=cu_kv_ if with_cache else None, **extra)
+
+    graph, static_out = _capture(lambda: call(op, q, ckv_d, kpe_d, cu_q, table, cu_kv, max_total_seq_len=max_kv), warmup=1)
+    cases = [([max_q] * batch, [max_cached] * batch)]
+    cases.append(([max_q // 2 + 3] + [17] * (batch - 1), [max_cached // 4 * 3] + [max_cached] * (batch - 1) if with_cache else [0] * batch))
+    cases.append(([max_q - 1] + [0] * (batch - 1), [0] * batch))
+    for q_lens, cached in cases:
+        cu_q1, cu_kv1, table1 = lengths(q_lens, cached)
+        for dst, src in ((cu_q, cu_q1), (cu_kv, cu_kv1), (table, table1)):
+            dst.copy_(src)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = call(ref, q_full, ckv, kpe, cu_q1, table1, cu_kv1)
+        got = to_cpu(static_out)
+        used = sum(q_lens)
+        torch.testing.assert_close(got[:used].float(), want[:used].float(), atol=2e-2, rtol=2e-2)
+        assert not got[used:].float().abs().any()

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, skip_unless_experiments_build, to_cpu, torch_cls
 
 pytestmark = pytest.mark.gpu
 ATOL = RTOL = 2e-2
@@ -229,6 +229,7 @@ def test_prefill_key_split(cfg, layout, monkeypatch):
 def test_prefill_phase_alternating_kernel(cfg, monkeypatch):
     """prefill_pp_kernel (MOJO_HIP_PREFILL_PP=1; opt-in, see DESIGN Appendix A): 8-wave workgroups whose two wave groups
     alternate matrix and softmax phases over rings of four K / V tiles — against the oracle and against the default kernel."""
+    skip_unless_experiments_build()
     q_lens, cached, hq, hkv, d, page = cfg
     q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hq, hkv, d, page, seed=41)
     if len(q_lens) == 4:
