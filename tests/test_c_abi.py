@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 from mojo_opset_amd.backends.hip import lib as L
 
