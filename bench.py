@@ -267,7 +267,7 @@ def main():
     ap.add_argument("--settle-ms", type=float, default=300.0, help="untimed device settle time before the warmup steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--extras-deadline", type=float, default=600.0, help="seconds before the extras are abandoned")
+    ap.add_argument("--extras-deadline", type=float, default=900.0, help="seconds before the extras are abandoned")
     ns = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

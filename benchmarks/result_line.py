@@ -51,7 +51,8 @@ def _comm_summary(full):
     cc = (full.get("extras") or {}).get("compute_comm_bf16") if isinstance(full.get("extras"), dict) else None
     if isinstance(cc, dict):
         world = full.get("n_gpus", 1)
-        case = cc.get(f"gemm_allreduce_M4096_K28672_N8192_tp{world}")
+        base = f"gemm_allreduce_M4096_K28672_N8192_tp{world}"
+        case = next((cc[k] for k in (base + "_auto", base, base + "_rccl") if isinstance(cc.get(k), dict) and "us" in cc[k]), None)
         if isinstance(case, dict):
             out["gemm_allreduce_M4096_K28672_N8192"] = {
                 k: _num(case[k]) for k in ("us", "aggregate_tflops", "speedup_vs_tp1", "algorithm", "exposed_exchange_us")

@@ -3,7 +3,7 @@
 import torch
 
 from ....comm import GemmEngine, all_gather_gemm, gemm_all2all, gemm_all_reduce, gemm_reduce_scatter
-from ....comm import peer
+from ....comm import peer, select
 from ....core.operators.compute_with_comm import (MojoAllGatherGemm, MojoGemmAll2All, MojoGemmAllReduce,
                                                   MojoGemmReduceScatter, is_dist_initialized)
 from .. import lib as L
@@ -51,18 +51,28 @@ def _group_of(op):
     return op._group() if is_dist_initialized() else None
 
 
+def _exchange(group, op_name, payload_bytes, x2, direct_fn, pipeline_fn):
+    """Run the operator on the exchange `comm.select` picks for this (group, operator, payload): the direct peer exchange or
+    the collective-library pipeline (forced by MOJO_HIP_COMM_DIRECT=1/0, otherwise self-tested and timed once per key)."""
+    if select.choose(group, op_name, payload_bytes, x2, direct_fn, pipeline_fn) == "direct":
+        return direct_fn()
+    return pipeline_fn()
+
+
 class HIPGemmAllReduce(MojoGemmAllReduce):
     supported_platforms_list = _ROCM
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         group = _group_of(self)
-        if peer.direct_enabled(group, input):                 # MOJO_HIP_COMM_DIRECT=1: ring-free exchange over peer buffers
+        if group is not None and input.is_cuda:
             x2 = input.reshape(-1, input.shape[-1])
             x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
             n = _ENGINE.out_features(self.weight, self.trans_weight)
             if peer.direct_supported(x2, n, x2.shape[0]):
-                out = peer.gemm_all_reduce_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
-                return out.reshape(*input.shape[:-1], n)
+                return _exchange(
+                    group, "gemm_all_reduce", x2.shape[0] * n * x2.element_size(), x2,
+                    lambda: peer.gemm_all_reduce_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group).reshape(*input.shape[:-1], n),
+                    lambda: gemm_all_reduce(_ENGINE, input, self.weight, self.bias, self.trans_weight, group))
         return gemm_all_reduce(_ENGINE, input, self.weight, self.bias, self.trans_weight, group)
 
 
@@ -71,17 +81,19 @@ class HIPAllGatherGemm(MojoAllGatherGemm):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         group = _group_of(self)
-        if peer.direct_enabled(group, input) and self.gather_dim % input.dim() == 0 and input.dim() >= 2:
+        if group is not None and input.is_cuda and self.gather_dim % input.dim() == 0 and input.dim() >= 2:
             import torch.distributed as dist
 
             x2 = input.reshape(-1, input.shape[-1])
             x2 = x2 if x2.stride(-1) == 1 and x2.stride(0) == x2.shape[1] else x2.contiguous()
             n = _ENGINE.out_features(self.weight, self.trans_weight)
             if x2.shape[0] > 0 and (x2.shape[1] * x2.element_size()) % 16 == 0 and x2.dtype in (torch.bfloat16, torch.float16, torch.float32):
-                out = peer.all_gather_gemm_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
                 shape = list(input.shape[:-1]) + [n]
                 shape[0] *= dist.get_world_size(group)
-                return out.reshape(shape)
+                return _exchange(
+                    group, "all_gather_gemm", x2.numel() * x2.element_size() * dist.get_world_size(group), x2,
+                    lambda: peer.all_gather_gemm_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group).reshape(shape),
+                    lambda: all_gather_gemm(_ENGINE, input, self.weight, self.bias, self.trans_weight, group, self.gather_dim))
         return all_gather_gemm(_ENGINE, input, self.weight, self.bias, self.trans_weight, group, self.gather_dim)
 
 
@@ -98,7 +110,7 @@ class HIPGemmReduceScatter(MojoGemmReduceScatter):
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         group = _group_of(self)
-        if peer.direct_enabled(group, input) and self.scatter_dim % input.dim() == 0:
+        if group is not None and input.is_cuda and self.scatter_dim % input.dim() == 0:
             import torch.distributed as dist
 
             ws = dist.get_world_size(group)
@@ -106,8 +118,10 @@ class HIPGemmReduceScatter(MojoGemmReduceScatter):
             x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
             n = _ENGINE.out_features(self.weight, self.trans_weight)
             if input.shape[0] % ws == 0 and peer.direct_supported(x2, n, x2.shape[0] // ws):
-                out = peer.gemm_reduce_scatter_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group)
                 shape = list(input.shape[:-1]) + [n]
                 shape[0] //= ws
-                return out.reshape(shape)
+                return _exchange(
+                    group, "gemm_reduce_scatter", x2.shape[0] * n * x2.element_size(), x2,
+                    lambda: peer.gemm_reduce_scatter_direct(_ENGINE, x2, self.weight, self.bias, self.trans_weight, group).reshape(shape),
+                    lambda: gemm_reduce_scatter(_ENGINE, input, self.weight, self.bias, self.trans_weight, group, self.scatter_dim))
         return gemm_reduce_scatter(_ENGINE, input, self.weight, self.bias, self.trans_weight, group, self.scatter_dim)

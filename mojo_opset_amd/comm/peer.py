@@ -204,19 +204,6 @@ def release_all() -> None:
         _CACHE.clear()
 
 
-def direct_enabled(group, x: torch.Tensor) -> bool:
-    """MOJO_HIP_COMM_DIRECT: "1" = use the peer exchange (GemmAllReduce, GemmReduceScatter, AllGatherGemm), "0"/unset = the
-    collective library's ring (default until the direct path has been measured on an 8-GPU node)."""
-    if group is None or not x.is_cuda:
-        return False
-    if torch.cuda.is_current_stream_capturing():
-        # the exchange keeps its epoch / parity on the host and bakes them into kernel arguments: a replay would find every
-        # flag already at the captured epoch and read the peers' partials before they are written.  Captured steps take the
-        # collective library's path.
-        return False
-    return os.environ.get("MOJO_HIP_COMM_DIRECT", "0") == "1" and dist.get_world_size(group) > 1
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # the two operators whose exchange is a reduction
 # ---------------------------------------------------------------------------------------------------------------

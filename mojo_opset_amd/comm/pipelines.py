@@ -12,7 +12,8 @@ xGMI transfer of chunk c overlaps the matrix work of chunk c+1:
                       -> reduce_scatter_tensor(out[rows_c], buf_c)
     all-gather      : sub-chunk c of every rank's input rows -> all_gather_into_tensor(buf_c, x[rows_c]);
                       the GEMM on buf_c writes its rows to their final place through the C-row map
-    all-to-all      : one all_to_all_single of the whole product (no accelerated version exists upstream)
+    all-to-all      : (scatter along rows) sub-chunk c of every destination's row block, produced contiguously by the
+                      A-row map -> all_to_all of that chunk, received in place; other scatter dims: one exchange
 
 The pipelines only orchestrate; the matrix product is delegated to a `GemmEngine` (the hip backend passes
 the C-ABI GEMM; the multi-process CPU tests pass a torch engine over gloo).
@@ -225,36 +226,70 @@ def all_gather_gemm(engine: GemmEngine, x, weight, bias, trans_weight, group, ga
     return out.reshape(shape)
 
 
+def _all_to_all_rows(recv_views, send_views, group, ws, rank):
+    """Asynchronous all-to-all of row blocks: ``send_views[d]`` goes to rank d, ``recv_views[s]`` receives rank s's block
+    for this rank (both lists of ``ws`` contiguous row ranges).  RCCL: one grouped send/recv, asynchronous.  gloo (the
+    single-GPU / CPU tests; no all-to-all there): an all-gather of every rank's send buffer on the host, this rank's blocks
+    picked out — asynchronous as well when the staged route is (``_staged_async``)."""
+    if dist.get_backend(group) != "gloo":
+        return dist.all_to_all(list(recv_views), list(send_views), group=group, async_op=True)
+    mine = torch.stack([v.cpu() if v.is_cuda else v for v in send_views])           # [ws, rows, n] on the host
+    everyone = [torch.empty_like(mine) for _ in range(ws)]
+
+    def finish():
+        for src in range(ws):
+            recv_views[src].copy_(everyone[src][rank])
+
+    if _staged_async():
+        return _Staged(dist.all_gather(everyone, mine, group=group, async_op=True), finish)
+    dist.all_gather(everyone, mine, group=group)
+    finish()
+    return _Done()
+
+
 def gemm_all2all(engine: GemmEngine, x, weight, bias, trans_weight, group, scatter_dim: int, gather_dim: int) -> torch.Tensor:
-    """cat(all_to_all(chunk(x @ W (+ bias), ws, scatter_dim)), gather_dim)."""
+    """cat(all_to_all(chunk(x @ W (+ bias), ws, scatter_dim)), gather_dim)  (golden: compute_with_comm.py:234-253).
+
+    Scattering along dimension 0 (the Ulysses switch from sequence- to head-sharding) is ROW-blocked in the flattened
+    product, so it gets the same row-chunk pipeline as the other three operators: for sub-chunk c of every destination's
+    row block the GEMM's A-row map produces ``[dest rank][rc rows]`` contiguously, that chunk's all-to-all is enqueued
+    asynchronously and overlaps the matrix work of chunk c + 1; every source's rows land directly in their final place of
+    the ``[source rank][rows]`` receive buffer (no copy when ``gather_dim == 0``; one concatenation otherwise).  Any other
+    scatter dimension computes the product whole and exchanges contiguous copies, as the golden does."""
     n = engine.out_features(weight, trans_weight)
-    y = engine(_flatten(x), weight, bias, trans_weight).reshape(*x.shape[:-1], n)
     if group is None:
-        return y
+        return engine(_flatten(x), weight, bias, trans_weight).reshape(*x.shape[:-1], n)
     ws, rank = _group_info(group)
-    sd, gd = scatter_dim % y.dim(), gather_dim % y.dim()
-    if y.shape[sd] % ws != 0:
-        raise ValueError(f"all_to_all: dimension {sd} of size {y.shape[sd]} is not divisible by world size {ws}")
-    if sd == 0:
-        recv = torch.empty_like(y)
-        _all_to_all_single(recv, y, group, ws, rank)
-        pieces: Sequence[torch.Tensor] = recv.chunk(ws, dim=0)
-    else:
+    out_shape = list(x.shape[:-1]) + [n]
+    sd, gd = scatter_dim % len(out_shape), gather_dim % len(out_shape)
+    if out_shape[sd] % ws != 0:
+        raise ValueError(f"all_to_all: dimension {sd} of size {out_shape[sd]} is not divisible by world size {ws}")
+    if sd != 0 or len(out_shape) < 2:
+        y = engine(_flatten(x), weight, bias, trans_weight).reshape(out_shape)
         send = [c.contiguous() for c in y.chunk(ws, dim=sd)]
         pieces = [torch.empty_like(c) for c in send]
         _all_to_all_list(list(pieces), send, group, ws, rank)
-    return pieces[0] if ws == 1 else torch.cat(list(pieces), dim=gd)
-
-
-def _all_to_all_single(recv, send, group, ws, rank):
-    try:
-        dist.all_to_all_single(recv, send, group=group)
-    except RuntimeError:                           # gloo has no all-to-all: emulate with an all_gather (tests only)
-        everyone = [torch.empty_like(send) for _ in range(ws)]
-        dist.all_gather(everyone, send.contiguous(), group=group)
-        rows = send.shape[0] // ws
-        for src in range(ws):
-            recv[src * rows: (src + 1) * rows] = everyone[src][rank * rows: (rank + 1) * rows]
+        return pieces[0] if ws == 1 else torch.cat(list(pieces), dim=gd)
+    x2 = _flatten(x)
+    m = x2.shape[0]
+    ml = m // ws                                   # rows of the flattened product every destination receives from this rank
+    recv = torch.empty(m, n, dtype=x.dtype, device=x.device)          # [source rank][ml rows]
+    works, keep = [], []
+    for lo, hi in plan_row_chunks(ml):
+        rc = hi - lo
+        buf = torch.empty(ws * rc, n, dtype=x.dtype, device=x.device)  # [dest rank][rc rows]
+        engine(x2, weight, bias, trans_weight, out=buf, rows=ws * rc, a_map=(rc, ml, lo))
+        works.append(_all_to_all_rows([recv[s * ml + lo: s * ml + hi] for s in range(ws)],
+                                      [buf[d * rc: (d + 1) * rc] for d in range(ws)], group, ws, rank))
+        keep.append(buf)
+    for w in works:
+        w.wait()
+    piece_shape = list(out_shape)
+    piece_shape[0] //= ws
+    if gd == 0:
+        piece_shape[0] *= ws
+        return recv.reshape(piece_shape)
+    return torch.cat([recv[s * ml: (s + 1) * ml].reshape(piece_shape) for s in range(ws)], dim=gd)
 
 
 def _all_to_all_list(recv, send, group, ws, rank):

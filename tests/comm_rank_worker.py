@@ -300,6 +300,55 @@ def check_timeout_path(rank, ws, group):
     dist.barrier()
 
 
+def check_auto_selection(rank, ws, group):
+    """comm/select.py with MOJO_HIP_COMM_DIRECT unset: the first call of an operator at a payload runs the group's self-test
+    of the direct exchange (bit-exact on integer data), times both paths and caches the winner; the result of the chosen
+    path equals BOTH forced paths' results (bf16: the direct form rounds the fp32 sum once, the pipeline adds rounded
+    partials — equal at two ranks), and a second payload bucket gets its own decision without a second self-test."""
+    from hip_utils import hip_cls
+    from mojo_opset_amd.comm import peer, select
+
+    select.reset()
+    torch.manual_seed(7 + rank)
+    w = (torch.randn(512, 1024, dtype=torch.bfloat16) * 0.05).to(DEV)
+    outs = {}
+    for m in (2048, 8192):
+        x = torch.randn(m, 512, dtype=torch.bfloat16).to(DEV)
+        for name, kw in (("MojoGemmAllReduce", {}), ("MojoGemmReduceScatter", {"scatter_dim": 0})):
+            op = hip_cls(name)(weight=w, bias=None, trans_weight=True, process_group=group, **kw)
+            auto = op(x)
+            torch.cuda.synchronize()
+            for flag in ("0", "1"):
+                os.environ["MOJO_HIP_COMM_DIRECT"] = flag
+                outs[flag] = op(x)
+                torch.cuda.synchronize()
+            os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+            assert torch.equal(outs["0"], outs["1"]), f"{name}: pipeline and direct exchange disagree at two ranks"
+            assert torch.equal(auto, outs["0"]), f"{name}: the selected path's result differs"
+            _report(rank, check=f"auto:{name}:M{m}")
+        xs = x[: m // ws].contiguous()
+        op = hip_cls("MojoAllGatherGemm")(weight=w, bias=None, trans_weight=True, gather_dim=0, process_group=group)
+        auto = op(xs)
+        os.environ["MOJO_HIP_COMM_DIRECT"] = "0"
+        want = op(xs)
+        os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+        torch.cuda.synchronize()
+        assert torch.equal(auto, want)
+        _report(rank, check=f"auto:MojoAllGatherGemm:M{m}")
+    rep = select.report()
+    assert len(rep) >= 4 and all(r["algorithm"] in ("direct", "rccl") for r in rep), rep
+    assert all(r["self_test"].startswith("self-test passed") for r in rep), rep
+    assert all("direct_us" in r and "rccl_us" in r for r in rep), rep
+    for ex in peer._CACHE.values():
+        ex.check()
+    # every rank reached the same decisions
+    mine = [(r["op"], r["payload_bucket_MB"], r["algorithm"]) for r in rep]
+    everyone = [None] * ws
+    dist.all_gather_object(everyone, mine, group=group)
+    assert all(e == mine for e in everyone), everyone
+    _report(rank, selection=rep)
+
+
 def main():
     import faulthandler
 
@@ -316,7 +365,13 @@ def main():
     try:
         modes = [m for m in os.environ.get("MOJO_TEST_COMM_MODES", "chunks1,chunks4").split(",") if m]
         for mode in modes:
-            os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+            os.environ["MOJO_HIP_COMM_DIRECT"] = "0"     # pipeline unless the mode says otherwise ("auto": unset, comm/select.py decides)
+            if mode == "auto":
+                _report(rank, mode=mode)
+                os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+                os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+                check_auto_selection(rank, ws, group)
+                continue
             if mode == "timeout":
                 _report(rank, mode=mode)
                 check_timeout_path(rank, ws, group)

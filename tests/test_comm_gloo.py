@@ -152,6 +152,14 @@ def _check_against_oracle(rank, ws, chunks):
     ref = mo.MojoAllGatherGemm.get_backend_impl("torch")(w, None, True, gather_dim=1)(x3)
     got = comm.all_gather_gemm(eng, x3, w, None, True, group, 1)
     torch.testing.assert_close(got, torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
+    # 3-D input through the all-to-all: scatter along the leading dimension (the row-chunk pipeline; gather on every
+    # dimension) and along an inner one (whole-product fallback)
+    x3 = torch.randn(8 * ws, 160, k)
+    for sd, gd in ((0, 1), (0, 2), (0, 0), (1, 0), (1, 2)):
+        ref = mo.MojoGemmAll2All.get_backend_impl("torch")(w, None, True, scatter_dim=sd, gather_dim=gd)(x3)
+        got = comm.gemm_all2all(eng, x3, w, None, True, group, sd, gd)
+        assert got.shape == ref.shape
+        torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)
 
 
 def _check_chunks_in_flight(rank, ws):
@@ -172,7 +180,7 @@ def _check_chunks_in_flight(rank, ws):
             log.append(("wait", self.tag))
             return self.work.wait()
 
-    real = {n: getattr(dist, n) for n in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor")}
+    real = {n: getattr(dist, n) for n in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor", "all_gather")}
     counter = {"n": 0}
 
     def wrap(name):
@@ -221,6 +229,15 @@ def _check_chunks_in_flight(rank, ws):
         out, issues, waits, gemms = run(comm.all_gather_gemm, 0)
         assert max(issues) < min(waits), "all-gather: every gather is issued up front"
         assert any(waits[0] < g < waits[-1] for g in gemms), "the GEMM of chunk c must run while later gathers are in flight"
+        out, issues, waits, gemms = run(comm.gemm_all2all, 0, 1)                 # row-blocked scatter: chunked like the others
+        assert max(issues) < min(waits), "all-to-all: a chunk was waited for before the last one was issued"
+        assert any(issues[0] < g < issues[-1] for g in gemms), "all-to-all: no GEMM was enqueued while an exchange was in flight"
+        y = x @ w
+        mine = [torch.empty(m // ws, n) for _ in range(ws)]
+        everyone = [torch.empty_like(y) for _ in range(ws)]
+        real["all_gather"](everyone, y)
+        want = torch.cat([everyone[s].chunk(ws, 0)[rank] for s in range(ws)], dim=1)
+        torch.testing.assert_close(out, want, atol=1e-4, rtol=1e-4)
     finally:
         for name, fn in real.items():
             setattr(pipelines.dist, name, fn)
@@ -291,3 +308,38 @@ def _check_expert_parallel_moe(rank, ws, dp_input):
 @pytest.mark.parametrize("dp_input", [False, True])
 def test_moe_expert_parallel_wiring(dp_input):
     run_dist(_check_expert_parallel_moe, dp_input)
+
+
+def _check_selector_host_logic(rank, ws):
+    """comm/select.py without a GPU: forced switches, payload buckets, and CPU tensors never take the direct exchange."""
+    from mojo_opset_amd.comm import select
+
+    group = dist.group.WORLD
+    x = torch.zeros(4, 4)
+    calls = []
+    os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+    assert select.forced() is None
+    assert select.choose(group, "gemm_all_reduce", 1 << 22, x, lambda: calls.append("d"), lambda: calls.append("r")) == "rccl"
+    assert select.choose(None, "gemm_all_reduce", 1 << 22, x, None, None) == "rccl"
+    assert not calls and not select.report()                  # nothing timed, nothing cached for host tensors
+    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+    assert select.forced() == "direct"
+    os.environ["MOJO_HIP_COMM_DIRECT"] = "0"
+    assert select.forced() == "rccl"
+    os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+    assert select.bucket(1) == 1 << 20 and select.bucket((1 << 20) + 1) == 1 << 21 and select.bucket(64 << 20) == 64 << 20
+    assert select._agree_max(group, "cpu", float(rank), 5.0 - rank) == [float(ws - 1), 5.0]
+    # the self-test's row-copy engine honours both row maps
+    eng = select._RowCopyEngine(3)
+    src = torch.arange(24.0).view(8, 3)
+    got = eng(src, None, None, True, rows=4, a_map=(2, 4, 1))           # rows 1, 2, 5, 6
+    assert torch.equal(got, src[[1, 2, 5, 6]])
+    dst = torch.zeros(8, 3)
+    eng(src[:4], None, None, True, out=dst, rows=4, c_map=(2, 4, 1))
+    assert torch.equal(dst[[1, 2, 5, 6]], src[:4])
+    pat = select._pattern(rank, 64, 16, "cpu", torch.bfloat16)
+    assert pat.abs().max() <= 8 and torch.equal(pat, pat.float().round().to(torch.bfloat16))
+
+
+def test_selector_host_logic():
+    run_dist(_check_selector_host_logic)

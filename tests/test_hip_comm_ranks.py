@@ -106,3 +106,14 @@ def test_hip_compute_comm_config4_shapes_two_ranks():
     for mode, checks in per_mode.items():
         assert len(checks) == 2 * 2 * 4, (mode, checks)
         assert sum(c.startswith("oracle:") for c in checks) == 8 and sum(c.startswith("fp32ref:") for c in checks) == 8
+
+
+def test_hip_comm_auto_selection_two_ranks():
+    """with MOJO_HIP_COMM_DIRECT unset the exchange is chosen by a one-time self-test + timing per
+    (group, operator, payload bucket) — comm/select.py; both paths agree bit for bit at two ranks and every rank decides alike."""
+    recs = run_ranks("auto", timeout=420)
+    checks = [r["check"] for r in recs if "check" in r]
+    assert len(checks) == 2 * 3, checks
+    sel = [r["selection"] for r in recs if "selection" in r]
+    assert sel and len(sel[0]) >= 4
+    print(json.dumps(sel[0]))

@@ -21,7 +21,7 @@ def _canned(world=1):
         full["n_gpus"] = world
         full["comm"] = {"backend": "nccl", "world_observed": world, "ranks": [f"AMD Instinct MI355X (device {i})" for i in range(world)],
                         "rccl_version": "2.26.6", "xgmi_link_peak_GBps": 153.0, "per_case": "x" * 300}
-        full.setdefault("extras", {}).setdefault("compute_comm_bf16", {})[f"gemm_allreduce_M4096_K28672_N8192_tp{world}"] = {
+        full.setdefault("extras", {}).setdefault("compute_comm_bf16", {})[f"gemm_allreduce_M4096_K28672_N8192_tp{world}_auto"] = {
             "us": 400.123456, "aggregate_tflops": 9621.5, "speedup_vs_tp1": 6.7, "algorithm": "direct", "exposed_exchange_us": 31.0,
             "payload_MB_per_rank": 67.1}
     return full
