@@ -55,6 +55,7 @@ struct PrefillArgs {
   // prefill_merge_kernel combines them.  ksplit == 1: no workspace, the workgroup writes `out` itself.
   int ksplit;
   int pp;                    // 1 (experiments build only): prefill_pp_kernel (experiments/paged_prefill_pp.h): 8-wave workgroups of 256 rows, n_qb counts blocks of 256 / G positions
+  int w64;                   // 1: prefill_w64_kernel (paged_prefill_w64.h): one wave per SIMD, 256-row workgroups, n_qb counts blocks of 256 / G positions
   float* ws_o;               // [blocks * ksplit][128 rows][dim]
   float* ws_ml;              // [blocks * ksplit][128 rows][2]   reference maximum (log2 units), row sum
 };
@@ -723,6 +724,7 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
 #else
 namespace mojo { constexpr int PP_TABLE = 0; }
 #endif
+#include "paged_prefill_w64.h"
 namespace mojo {
 
 template <typename T, int G, int DK>
@@ -741,6 +743,15 @@ static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
     return;
   }
 #endif
+  if constexpr (DK == 4) {
+    if (a.w64) {
+      static std::atomic<uint64_t> w64_attr_set{0};
+      if (first_call_on_device(w64_attr_set))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_w64_kernel<T, G>), hipFuncAttributeMaxDynamicSharedMemorySize, W64_LDS);
+      hipLaunchKernelGGL((prefill_w64_kernel<T, G>), grid, dim3(256), W64_LDS, s, a);
+      return;
+    }
+  }
   if (a.ksplit > 1) {
     hipLaunchKernelGGL((prefill_kernel<T, G, DK, true>), grid, dim3(256), PF_LDS, s, a);
     hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch * PF_MERGE_SPLIT)), dim3(256), 0, s, a);
@@ -761,6 +772,15 @@ static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
   return MOJO_OK;
 }
 
+// The one-wave-per-SIMD kernel (paged_prefill_w64.h).  MOJO_HIP_PREFILL_W64: 0 = never, 1 = wherever it applies (head_dim 128,
+// pages of >= 16 keys, unsplit launches, block tables of <= W64_TABLE - 16 pages); unset = the measured policy.
+static bool prefill_use_w64(int64_t max_q, int64_t batch, int hkv, int G) {
+  const char* e = getenv("MOJO_HIP_PREFILL_W64");
+  if (e && e[0] == '0') return false;
+  if (e && e[0] == '1') return true;
+  return false;
+}
+
 static bool prefill_use_pp(int64_t max_q) {
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
   const char* e = getenv("MOJO_HIP_PREFILL_PP");
@@ -774,7 +794,9 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
   // Experiments build only: the phase-alternating kernel takes unsplit launches over pages it can stage with scalar page
   // ids when MOJO_HIP_PREFILL_PP=1.
   a.pp = (a.ksplit == 1 && a.fast_stage && a.max_pages <= PP_TABLE && prefill_use_pp(max_q)) ? 1 : 0;
-  const int qpb = (a.pp ? 256 : 128) / G;
+  a.w64 = (!a.pp && a.ksplit == 1 && a.fast_stage && a.dim == 128 && a.max_pages <= W64_TABLE - 16 &&
+           prefill_use_w64(max_q, batch, a.hkv, G)) ? 1 : 0;
+  const int qpb = ((a.pp || a.w64) ? 256 : 128) / G;
   const int64_t n_qb = ceil_div(max_q, qpb);
   const int64_t n_zero = ceil_div(a.total_tokens, static_cast<int64_t>(PF_ZERO_TOKENS));
   MOJO_REQUIRE((n_qb * a.hkv * batch + n_zero) * a.ksplit < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
