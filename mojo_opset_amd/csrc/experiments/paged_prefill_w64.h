@@ -1,5 +1,7 @@
 // prefill_w64_kernel: MojoPagedPrefillGQA with ONE wave per SIMD and 64 query rows per wave (head_dim 128, pages >= 16 keys).
-// Included by paged_prefill_gqa.hip behind prefill_kernel (shares PrefillArgs, lds_c, the block order, the zero-fill tail).
+// Included by paged_prefill_gqa.hip behind prefill_kernel in an EXPERIMENTS build (MOJO_HIP_BUILD_EXPERIMENTS=1; shares PrefillArgs,
+// lds_c, the block order, the zero-fill tail); selected per call with MOJO_HIP_PREFILL_W64=1.  Parity-green, measured slower than
+// prefill_kernel (round 4: 1x16384 1 073 vs 1 100 TF, 4x2048 793 vs 894, 16 ragged 468 vs 662) — why, with the numbers: DESIGN §4.4.
 //
 // Why a second kernel: prefill_kernel runs two free-running 4-wave workgroups per CU; its matrix pipe is
 // idle half of the time because a wave's softmax (vector unit) and its MFMAs overlap only with the OTHER workgroup's, by

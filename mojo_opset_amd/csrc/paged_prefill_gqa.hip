@@ -55,7 +55,7 @@ struct PrefillArgs {
   // prefill_merge_kernel combines them.  ksplit == 1: no workspace, the workgroup writes `out` itself.
   int ksplit;
   int pp;                    // 1 (experiments build only): prefill_pp_kernel (experiments/paged_prefill_pp.h): 8-wave workgroups of 256 rows, n_qb counts blocks of 256 / G positions
-  int w64;                   // 1: prefill_w64_kernel (paged_prefill_w64.h): one wave per SIMD, 256-row workgroups, n_qb counts blocks of 256 / G positions
+  int w64;                   // 1 (experiments build only): prefill_w64_kernel (experiments/paged_prefill_w64.h): one wave per SIMD, 256-row workgroups, n_qb counts blocks of 256 / G positions
   float* ws_o;               // [blocks * ksplit][128 rows][dim]
   float* ws_ml;              // [blocks * ksplit][128 rows][2]   reference maximum (log2 units), row sum
 };
@@ -724,7 +724,11 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
 #else
 namespace mojo { constexpr int PP_TABLE = 0; }
 #endif
-#include "paged_prefill_w64.h"
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS        // one-wave-per-SIMD kernel of round 4: parity-green, measured 2-30 % slower (DESIGN §4.4, Appendix A #10b)
+#include "experiments/paged_prefill_w64.h"
+#else
+namespace mojo { constexpr int W64_TABLE = 0; }
+#endif
 namespace mojo {
 
 template <typename T, int G, int DK>
@@ -743,6 +747,7 @@ static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
     return;
   }
 #endif
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   if constexpr (DK == 4) {
     if (a.w64) {
       static std::atomic<uint64_t> w64_attr_set{0};
@@ -752,6 +757,7 @@ static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
       return;
     }
   }
+#endif
   if (a.ksplit > 1) {
     hipLaunchKernelGGL((prefill_kernel<T, G, DK, true>), grid, dim3(256), PF_LDS, s, a);
     hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch * PF_MERGE_SPLIT)), dim3(256), 0, s, a);
@@ -772,12 +778,13 @@ static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
   return MOJO_OK;
 }
 
-// The one-wave-per-SIMD kernel (paged_prefill_w64.h).  MOJO_HIP_PREFILL_W64: 0 = never, 1 = wherever it applies (head_dim 128,
-// pages of >= 16 keys, unsplit launches, block tables of <= W64_TABLE - 16 pages); unset = the measured policy.
+// Experiments build only: the one-wave-per-SIMD kernel (experiments/paged_prefill_w64.h) takes the launches it applies to
+// (head_dim 128, pages of >= 16 keys, unsplit, block tables of <= W64_TABLE - 16 pages) when MOJO_HIP_PREFILL_W64=1.
 static bool prefill_use_w64(int64_t max_q, int64_t batch, int hkv, int G) {
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
   const char* e = getenv("MOJO_HIP_PREFILL_W64");
-  if (e && e[0] == '0') return false;
   if (e && e[0] == '1') return true;
+#endif
   return false;
 }
 

@@ -275,3 +275,34 @@ def test_prefill_key_split_at_the_bench_size(monkeypatch):
         sc = torch.einsum("kgd,ktd->kgt", qi, keys[:, :n]) / math.sqrt(d)
         want = torch.einsum("kgt,ktd->kgd", torch.softmax(sc, -1).to(torch.bfloat16).float(), vals[:, :n]).reshape(hq, d)
         torch.testing.assert_close(got[i].float().cpu(), want, atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    ([1024], [0], 32, 8, 128, 16),                      # pipelined iterations, 2x-unrolled loop taken several times
+    ([513, 300, 64], [0, 2000, 100], 32, 8, 128, 16),   # ragged, cached, blocks of every length
+    ([384], [0], 8, 8, 128, 64),                        # G = 1: 256 positions per workgroup, 64-key pages
+    ([700, 129], [31, 0], 16, 2, 128, 32),              # G = 8
+], ids=["long", "ragged_cached", "g1_page64", "g8"])
+def test_prefill_one_wave_per_simd_kernel(cfg, monkeypatch):
+    """prefill_w64_kernel (csrc/experiments/paged_prefill_w64.h, MOJO_HIP_PREFILL_W64=1 in an experiments build): one wave per
+    SIMD, 64 rows per wave, the loop skewed one tile with the softmax in the MFMA gaps — against the oracle, against the
+    default kernel, the same bits run to run, with a hole in a block table."""
+    skip_unless_experiments_build()
+    monkeypatch.setenv("MOJO_HIP_PREFILL_KSPLIT", "1")         # (the key split belongs to the default kernel)
+    q_lens, cached, hq, hkv, d, page = cfg
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hq, hkv, d, page, seed=43)
+    if len(q_lens) == 3:
+        table[1, 40] = -1                                       # a hole: rows behind it read as zero K / V
+    op, ref = hip_cls("MojoPagedPrefillGQA")(), torch_cls("MojoPagedPrefillGQA")()
+    kw = dict(softmax_scale=1.0 / math.sqrt(d), max_q_len=max(q_lens), max_total_seq_len=max(kv_lens), cu_total_seq_lens=cu_kv)
+    want = ref(q, k, v, cu_q, table, **kw)
+    dkw = {k_: (v_.to(DEV) if isinstance(v_, torch.Tensor) else v_) for k_, v_ in kw.items()}
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV))
+    monkeypatch.setenv("MOJO_HIP_PREFILL_W64", "0")
+    base = op(*args, **dkw)
+    monkeypatch.setenv("MOJO_HIP_PREFILL_W64", "1")
+    got = op(*args, **dkw)
+    again = op(*args, **dkw)
+    assert torch.equal(got, again)
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    torch.testing.assert_close(got.float(), base.float(), atol=2e-2, rtol=2e-2)
