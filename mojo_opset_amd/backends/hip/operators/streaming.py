@@ -19,6 +19,24 @@ def _dense(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _row_view(t: torch.Tensor):
+    """(rows, row stride in elements) when ``t`` is a stack of rows with one uniform row stride and a dense last dimension
+    (a column slice of a dense [.., N] tensor); None otherwise."""
+    if t.dim() == 0 or t.stride(-1) != 1 or t.numel() == 0:
+        return None
+    cols = t.shape[-1]
+    if t.dim() == 1:
+        return 1, cols
+    ld = t.stride(-2)
+    rows, expect = 1, ld
+    for size, stride in zip(reversed(t.shape[:-1]), reversed(t.stride()[:-1])):
+        if size != 1 and stride != expect:
+            return None
+        expect *= size
+        rows *= size
+    return rows, ld
+
+
 class HIPSwiGLU(MojoSwiGLU):
     supported_platforms_list = _ROCM
 
@@ -26,10 +44,22 @@ class HIPSwiGLU(MojoSwiGLU):
         L.require_cuda(gate_out, up_out)
         if gate_out.shape != up_out.shape or gate_out.dtype != up_out.dtype:
             raise NotImplementedError("HIPSwiGLU: gate_out and up_out must have identical shape and dtype")
-        g, u = _dense(gate_out), _dense(up_out)
-        out = torch.empty_like(g)
-        L.check(L.load().mojo_hip_swiglu(L.ptr(g), L.ptr(u), L.ptr(out), g.numel(), L.dtype_code(g.dtype),
-                                         float(self.swiglu_limit), L.stream_of(g)), "HIPSwiGLU")
+        if gate_out.is_contiguous() and up_out.is_contiguous():
+            g, u = gate_out, up_out
+            out = torch.empty_like(g)
+            L.check(L.load().mojo_hip_swiglu(L.ptr(g), L.ptr(u), L.ptr(out), g.numel(), L.dtype_code(g.dtype),
+                                             float(self.swiglu_limit), L.stream_of(g)), "HIPSwiGLU")
+            return out
+        # Row-strided views — the two halves of a fused [.., 2 * inter] projection (`gate, up = gu.chunk(2, -1)`) — are read in
+        # place: no copy of either half.  Anything else is made dense first.
+        rows_g, rows_u = _row_view(gate_out), _row_view(up_out)
+        if rows_g is None or rows_u is None or (rows_g[1] * gate_out.element_size()) % 16 or (rows_u[1] * up_out.element_size()) % 16 \
+                or gate_out.data_ptr() % 16 or up_out.data_ptr() % 16:
+            return self.forward(_dense(gate_out), _dense(up_out))
+        cols = gate_out.shape[-1]
+        out = torch.empty(gate_out.shape, dtype=gate_out.dtype, device=gate_out.device)
+        L.check(L.load().mojo_hip_swiglu_rows(L.ptr(gate_out), L.ptr(up_out), L.ptr(out), rows_g[0], cols, rows_g[1], rows_u[1], cols,
+                                              L.dtype_code(gate_out.dtype), float(self.swiglu_limit), L.stream_of(gate_out)), "HIPSwiGLU")
         return out
 
 

@@ -89,6 +89,26 @@ def test_swiglu_reference_space(shape):
     assert max_ulp_bf16ish(to_cpu(got), ref(g, u)) <= 1
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_swiglu_reads_the_halves_of_a_fused_projection_in_place(dtype):
+    """`gate, up = gu.chunk(2, -1)` are row-strided views: HIPSwiGLU reads them where they are (mojo_hip_swiglu_rows) and gives
+    the bits of the dense call; views it cannot address as rows (a transposed tensor, an odd column offset) are made dense."""
+    torch.manual_seed(3)
+    op = hip_cls("MojoSwiGLU")()
+    for lead, inter in (((64,), 14336), ((3, 17), 1024), ((5,), 264)):
+        gu = torch.randn(*lead, 2 * inter).to(dtype).to(DEV)
+        gate, up = gu.chunk(2, dim=-1)
+        assert not gate.is_contiguous()
+        got = op(gate, up)
+        want = op(gate.contiguous(), up.contiguous())
+        assert got.shape == want.shape and got.is_contiguous() and torch.equal(got, want)
+    gu = torch.randn(40, 2 * 100 + 3).to(dtype).to(DEV)             # odd offsets: not 16-byte aligned -> dense fallback
+    gate, up = gu[:, 1:101], gu[:, 103:203]
+    assert torch.equal(op(gate, up), op(gate.contiguous(), up.contiguous()))
+    gt = torch.randn(128, 96).to(dtype).to(DEV).t()                   # transposed: no dense last dimension
+    assert torch.equal(op(gt, gt), op(gt.contiguous(), gt.contiguous()))
+
+
 @pytest.mark.parametrize("bs,seqlen", [(1, 124), (6, 555), (2, 2048)])
 @pytest.mark.parametrize("dtype,hq,hk,head_first,d,pct", [
     (torch.float16, 32, 8, True, 96, 1.0), (torch.bfloat16, 8, 2, False, 96, 1 / 3),
