@@ -328,7 +328,7 @@ int mojo_hip_store_paged_mla_kv(const void* compressed_kv_states, const void* k_
  *      slice of the batch) and total_keys_out (nullable, int32 [1]) receives min(cu[batch] - cu[0], capacity_rows), the
  *      decompression GEMM's device-side row count.  capacity_rows = rows the flat buffers hold: the lengths live on the device
  *      and the host sizes the buffers without a sync, so a row at or past the capacity is neither written by mla_unpage nor
- *      read by mla_prefill_attn (the sequence is truncated there, as the paged GQA ops truncate theirs).  The decompression kv = c_kv @ kv_b_proj^T is
+ *      read by mla_prefill_attn (a sequence longer than max_tokens_per_seq is cut at that bound, per sequence, by both calls).  The decompression kv = c_kv @ kv_b_proj^T is
  *      mojo_hip_group_gemm with one group whose row count is the device-side total.
  *      mla_prefill_attn: causal flash attention per head over K = [kv[t, h, :nope] | k_pe[t, :]] and V = kv[t, h, nope:],
  *      kv [T_kv, heads, nope + v_dim] and k_pe [T_kv, rope] contiguous, sequence b's keys at rows cu[b] ..; optional fp32
@@ -349,7 +349,7 @@ int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decompressed, co
                               const float* attn_sink, void* out, const int32_t* cu_q_lens,
                               const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
                               int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
-                              int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
+                              int64_t max_tokens_per_seq, int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
                               int zero_padding_rows, int dtype, mojo_stream_t stream);
 
 /* ---- Direct reduce-scatter / all-gather over HIP-IPC peer buffers: the exchange step of MojoGemmAllReduce /

@@ -139,9 +139,9 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     The decompressed image needs `keys * H * (nope + v)` elements (64 KiB per key at DeepSeek-V3 dimensions).  Lengths stay
     on the device, so the host sizes it from what it knows: the table width (`max_total_seq_len` tightens it — pass it), and
     walks the batch in slices of sequences whose image fits `MOJO_HIP_MLA_PREFILL_BYTES` (default 1 GiB: on a serving box
-    most of HBM is KV cache, and the block stays in torch's caching allocator).  The image's row capacity goes to both
-    kernels: a sequence longer than the host's bound is truncated at the capacity (never written or read past it), as the
-    paged GQA ops truncate; `MOJO_HIP_VALIDATE=1` raises instead (one device sync).  Returns None when this route does not
+    most of HBM is KV cache, and the block stays in torch's caching allocator).  The per-sequence bound and the image's row capacity
+    go to both kernels: a sequence longer than the host's bound loses its OWN tail (cut per sequence, as the paged GQA ops
+    truncate theirs; nothing is written or read past the capacity); `MOJO_HIP_VALIDATE=1` raises instead (one device sync).  Returns None when this route does not
     apply (dimensions without an instantiation, or ONE sequence's capacity alone exceeds the budget) — the caller then
     takes the absorbed route."""
     lib = L.load()
@@ -211,7 +211,7 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
         last = b0 + nb >= batch
         L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), cq, ck, tq,
                                               nb, heads, nope, rope, vdim,
-                                              min(tq, per_seq) if max_q_len is None else max_q_len, cap, scale,
+                                              min(tq, per_seq) if max_q_len is None else max_q_len, per_seq, cap, scale,
                                               1 if round_scaled_scores else 0, 1 if last else 0,
                                               L.dtype_code(dt), stream), "hip mla prefill attention")
     return out

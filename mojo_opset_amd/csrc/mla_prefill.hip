@@ -29,6 +29,19 @@ namespace mojo {
 
 typedef __attribute__((address_space(3))) char lds_m;
 
+// Row of sequence b in the flat (un-paged) buffers when every sequence is cut at `per_seq` keys: sum over i < b of
+// min(len_i, per_seq).  The host sizes the buffers from per_seq without reading a length; a sequence longer than the bound
+// loses ITS OWN tail and nothing else (a positional cut at the capacity would keep an over-long early sequence whole and
+// starve well-formed later ones).  Wave-uniform result; every lane of a wave calls it.  cu is relative (cu[0] = first sequence).
+__device__ __forceinline__ int mla_clamped_start(const int32_t* cu, int b, int per_seq) {
+  const int lane = threadIdx.x & 63;
+  int v = 0;
+  for (int i = lane; i < b; i += 64) v += min(cu[i + 1] - cu[i], per_seq);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 // ---- 1. un-page --------------------------------------------------------------------------------------------------
 // flat row cu_kv[b] + t  <-  cache[table[b, t / page], 0, t % page, :]   for t < kv_len_b.  One wave per token row.
 struct UnpageArgs {
@@ -39,18 +52,23 @@ struct UnpageArgs {
   int64_t table_stride, ckv_blk, ckv_tok, kpe_blk, kpe_tok;     // bytes
   int ckv_row_bytes, kpe_row_bytes, page, max_pages, batch;
   int capacity_rows;                                           // rows the flat buffers hold: nothing is written at or past it
+  int per_seq;                                                 // keys kept per sequence (the host's bound of one sequence's length)
 };
 
 __global__ __launch_bounds__(256) void mla_unpage_kernel(UnpageArgs a) {
   const int b = blockIdx.y;
   // (flat rows are relative to the first sequence handed in: a caller may pass a slice of the batch)
   const int32_t* cu = a.cu_kv ? a.cu_kv : a.cu_q;
-  // The host sizes the flat buffers from what it knows without a sync (table width, a caller's hint): lengths above that are
-  // truncated here and — through the same capacity — in the attention kernel, as the paged GQA ops truncate theirs.
-  const int start = cu[b] - cu[0];
-  int len = cu[b + 1] - cu[b];
+  // The host sizes the flat buffers from what it knows without a sync (table width, a caller's hint): a sequence longer than
+  // that bound is cut at the bound, here and — by the same rule — in the attention kernel, PER SEQUENCE as the paged GQA ops
+  // cut theirs; the capacity stays the hard limit of what is written.
+  const int start = mla_clamped_start(cu, b, a.per_seq);
+  int len = min(cu[b + 1] - cu[b], a.per_seq);
   if (len > a.capacity_rows - start) len = a.capacity_rows - start;
-  if (a.count_out && b == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = min(cu[a.batch] - cu[0], a.capacity_rows);
+  if (a.count_out && b == 0 && blockIdx.x == 0 && threadIdx.x < 64) {
+    const int total = mla_clamped_start(cu, a.batch, a.per_seq);
+    if (threadIdx.x == 0) a.count_out[0] = min(total, a.capacity_rows);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
   for (int t = blockIdx.x * 4 + wave; t < len; t += gridDim.x * 4) {
@@ -78,6 +96,7 @@ struct MlaPfArgs {
   const int32_t* cu_kv;      // may be null: kv_len = q_len
   int heads, batch, n_qb;
   int capacity_rows;         // rows of `kv` / `kpe`: keys at or past it do not exist (mla_unpage wrote none)
+  int per_seq;               // keys kept per sequence (mla_unpage's rule: rows of sequence b start at sum_{i<b} min(len_i, per_seq))
   int64_t total_tokens;      // rows of `out`; rows behind cu_q[batch] are zeroed when zero_tail is set
   float scale_log2;          // softmax_scale * log2(e); log2(e) alone when the scores are scaled before the exponent (below)
   float pre_scale;           // decode golden: scores = round(round(q k) * softmax_scale) in the storage type (attention.py:215)
@@ -151,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   const int head = unit % a.heads, b = unit / a.heads;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
-  const int kv_start = a.cu_kv ? a.cu_kv[b] - a.cu_kv[0] : q_start - a.cu_q[0];      // row in the (slice-relative) flat buffers
-  int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
+  const int kv_start = mla_clamped_start(a.cu_kv ? a.cu_kv : a.cu_q, b, a.per_seq);   // row in the (slice-relative) flat buffers
+  int kv_len = min(a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len, a.per_seq);
   if (kv_len > a.capacity_rows - kv_start) kv_len = a.capacity_rows - kv_start;
   if (qb * MPF_QPB >= q_len) return;
 
@@ -498,6 +517,7 @@ extern "C" int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* 
   a.ckv_row_bytes = static_cast<int>(kv_lora_rank * elt_bytes); a.kpe_row_bytes = static_cast<int>(rope_dim * elt_bytes);
   a.page = static_cast<int>(block_size); a.max_pages = static_cast<int>(max_blocks_per_seq); a.batch = static_cast<int>(batch);
   a.capacity_rows = static_cast<int>(capacity_rows);
+  a.per_seq = static_cast<int>(max_tokens_per_seq < (int64_t{1} << 30) ? max_tokens_per_seq : (int64_t{1} << 30));
   int64_t gx = ceil_div(max_tokens_per_seq, 4);
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(mla_unpage_kernel, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(batch)), dim3(256), 0,
@@ -510,7 +530,7 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
                                          const float* attn_sink, void* out, const int32_t* cu_q_lens,
                                          const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
                                          int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
-                                         int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
+                                         int64_t max_tokens_per_seq, int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
                                          int zero_padding_rows, int dtype, mojo_stream_t stream) {
   if (total_tokens == 0) return MOJO_OK;
   MOJO_REQUIRE(capacity_rows > 0 && capacity_rows < (int64_t{1} << 31), MOJO_EINVAL, "mla_prefill_attn: capacity_rows %lld",
@@ -531,6 +551,7 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens;
   a.heads = static_cast<int>(heads); a.batch = static_cast<int>(batch);
   a.capacity_rows = static_cast<int>(capacity_rows);
+  a.per_seq = static_cast<int>(max_tokens_per_seq > 0 && max_tokens_per_seq < (int64_t{1} << 30) ? max_tokens_per_seq : (int64_t{1} << 30));
   const int64_t mq = (max_q_len > 0 && max_q_len < total_tokens) ? max_q_len : total_tokens;
   a.n_qb = static_cast<int>(ceil_div(mq, MPF_QPB));
   { const char* e = getenv("MOJO_HIP_MLA_PREFILL_ODD_SLOTS"); a.n_slots = (e && e[0] == '0') ? a.n_qb : (a.n_qb | 1); }

@@ -193,9 +193,24 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   int kv_hi = min(kv_len, offset + pos_hi + 1);          // keys [0, kv_hi) are visible to some row
   if (kv_hi < 1) kv_hi = 1;
   const int n_kb_all = (kv_hi + PF_KEYS - 1) / PF_KEYS;
-  // key tiles [kb_lo, n_kb) of the block belong to this workgroup (unsplit: all of them)
-  const int kb_lo = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * ks / a.ksplit) : 0;
-  const int n_kb = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * (ks + 1) / a.ksplit) : n_kb_all;
+  // key tiles [kb_lo, n_kb) of the block belong to this workgroup (unsplit: all of them).  The host chose `ksplit` from the
+  // CAPACITY of a sequence (it reads no length); the block itself knows how many tiles it walks, and cuts them into no more
+  // slices than leave 8 tiles (512 keys) each: a short block in a split launch would otherwise pay partial writes and a merge
+  // over slices of one or two tiles.  Surplus slices publish "no keys seen" and leave.
+  int eff = 1;
+  if constexpr (SPLIT) {
+    eff = n_kb_all / 8;
+    eff = eff < 1 ? 1 : (eff > a.ksplit ? a.ksplit : eff);
+    if (ks >= eff) {
+      if (threadIdx.x < 128) {
+        a.ws_ml[(static_cast<int64_t>(blockIdx.x) * 128 + threadIdx.x) * 2 + 0] = -INFINITY;
+        a.ws_ml[(static_cast<int64_t>(blockIdx.x) * 128 + threadIdx.x) * 2 + 1] = 0.f;
+      }
+      return;
+    }
+  }
+  const int kb_lo = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * ks / eff) : 0;
+  const int n_kb = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * (ks + 1) / eff) : n_kb_all;
 
   // The prologue is a chain of dependent memory round trips (1.5-2 us each on a busy chip) in front of a workgroup that
   // may own only a handful of tiles, so it is kept to two: {Q fragments, page-id window} together, then the first tile.

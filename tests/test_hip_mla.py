@@ -87,7 +87,12 @@ def check_mla(got, want_golden, exact, route="absorbed"):
         err_hip, err_gold = (got - exact).abs().max(), (want_golden - exact).abs().max()
         assert err_hip <= err_gold + 2e-2 * (1.0 + exact.abs().max()), (err_hip, err_gold)
         return
-    torch.testing.assert_close(got, exact, atol=ATOL * max(1.0, float(exact.abs().max()) / 4.0), rtol=RTOL)   # (1)
+    # (1) against the exactly computed result: the reference's own numbers, atol = rtol = 1e-2, for all but a bounded handful
+    # of elements (<= 1e-4 of them: one fuzz case measured 0.0105 at |exact| = 5.1), and NO element outside twice that
+    # however large the outputs are (a bound that grows with the output scale could hide a regression)
+    inside = (got - exact).abs() <= ATOL + RTOL * exact.abs()
+    assert float((~inside).double().mean()) <= 1e-4, float((~inside).double().mean())
+    torch.testing.assert_close(got, exact, atol=2 * ATOL, rtol=RTOL)
     err_hip, err_gold = (got - exact).abs().max(), (want_golden - exact).abs().max()
     assert err_hip <= err_gold + 2.0 ** -8 * exact.abs().max().clamp_min(1.0), (err_hip, err_gold)   # (2)
     torch.testing.assert_close(got, want_golden, atol=GOLDEN_BAND, rtol=GOLDEN_BAND)           # (3)
@@ -429,12 +434,15 @@ def test_mla_decode_golden_route_fixtures_sink_and_empty_rows(monkeypatch):
     want = ref(q, ckv, kpe, lens, table)
     slack = 2.0 ** -8 * max(float(want.float().abs().max()), 1.0)
     torch.testing.assert_close(whole.float(), want.float(), atol=1e-2 + slack, rtol=1e-2)
-    # a bound below the real lengths: the image holds 5 x 128 rows; nothing is written or read at or past its capacity
-    # (sequences that end inside it are complete, the others are cut at it), every output stays finite
+    # a bound below the real lengths: every sequence is cut at the bound ON ITS OWN — the two over-long ones
+    # (300, 512 keys) attend to their first 128 keys, the well-formed ones (0, 17, 64 keys) are untouched by their
+    # neighbours' excess — nothing is written or read past the image's capacity, every output stays finite
     monkeypatch.delenv("MOJO_HIP_MLA_PREFILL_BYTES")
     short = to_cpu(op(*args, max_total_seq_len=128))
-    torch.testing.assert_close(short[[0, 1, 2]].float(), want[[0, 1, 2]].float(), atol=1e-2 + slack, rtol=1e-2)
-    assert torch.isfinite(short.float()).all() and float(short[4].abs().max()) == 0.0
+    torch.testing.assert_close(short[[1, 2, 4]].float(), want[[1, 2, 4]].float(), atol=1e-2 + slack, rtol=1e-2)
+    cut = ref(q, ckv, kpe, torch.minimum(lens, torch.tensor(128, dtype=torch.int32)), table)
+    torch.testing.assert_close(short[[0, 3]].float(), cut[[0, 3]].float(), atol=1e-2 + slack, rtol=1e-2)
+    assert torch.isfinite(short.float()).all()
     monkeypatch.setenv("MOJO_HIP_VALIDATE", "1")
     with pytest.raises(ValueError):
         op(*args, max_total_seq_len=128)
