@@ -348,7 +348,8 @@ int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* k_pe_cache,
 int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decompressed, const void* k_pe_flat,
                               const float* attn_sink, void* out, const int32_t* cu_q_lens,
                               const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
-                              int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
+                              int64_t heads, int64_t head_begin, int64_t head_count, int64_t nope, int64_t rope,
+                              int64_t v_dim, int64_t max_q_len,
                               int64_t max_tokens_per_seq, int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
                               int zero_padding_rows, int dtype, mojo_stream_t stream);
 

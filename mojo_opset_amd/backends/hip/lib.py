@@ -69,7 +69,7 @@ SIGNATURES = {
     "mojo_hip_gemm_rowmap": (c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, c_int, _P, _I, _P]),
     "mojo_hip_mla_prefill_supported": (c_int, [_I, _I, _I, c_int]),
     "mojo_hip_mla_unpage": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P, _P]),
-    "mojo_hip_mla_prefill_attn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_float, c_int, c_int, c_int, _P]),
+    "mojo_hip_mla_prefill_attn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_float, c_int, c_int, c_int, _P]),
     "mojo_hip_peer_ctrl_bytes": (c_int64, []),
     "mojo_hip_peer_max_ranks": (c_int64, []),
     "mojo_hip_peer_max_chunks": (c_int64, []),

@@ -194,27 +194,84 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     kpe_flat = torch.empty(cap, rope, dtype=dt, device=dev)
     kv = torch.empty(cap, kv_cols, dtype=dt, device=dev)
     count = torch.empty(1, dtype=torch.int32, device=dev)
-    ws = torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(1), dtype=torch.uint8, device=dev)
+    # Head groups (opt-in, MOJO_HIP_MLA_PREFILL_GROUPS; measured slower by default, see _head_groups): the decompression of
+    # group g + 1 runs on a side stream beside the attention of group g.  Each group's GEMM fills its own
+    # columns of the image (`group_gemm_strided`, output row stride = the whole row), the attention launch covers the
+    # group's heads only.
+    groups = _head_groups(heads, cap)
+    cols_g = (heads // groups) * (nope + vdim)
+    wss = [torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(1), dtype=torch.uint8, device=dev) for _ in range(groups)]
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if groups > 1 else None
+    identity = None
+
+    def decompress(g, on):
+        # kv[t, g*cols_g + j] = sum_k ckv[t, k] * kv_b_proj[g*cols_g + j, k]: one group whose row count is the slice's
+        # device-side number of keys, so rows past it are never computed
+        L.check(lib.mojo_hip_group_gemm_strided(
+            L.ptr(ckv_flat), L.c_void_p(proj.data_ptr() + g * cols_g * r * es), L.c_void_p(kv.data_ptr() + g * cols_g * es),
+            L.ptr(count), 0, cap, r, cols_g, 1, r, kv_cols, 0, 1, r, identity, identity, L.dtype_code(dt),
+            L.ptr(wss[g]), wss[g].numel(), L.c_void_p(on.cuda_stream)), "hip mla decompression")
+
     for b0 in range(0, batch, seqs_per_slice):
         nb = min(seqs_per_slice, batch - b0)
         cq = L.c_void_p(cu_q.data_ptr() + 4 * b0)
         ck = None if cu_kv is None else L.c_void_p(cu_kv.data_ptr() + 4 * b0)
         tb = L.c_void_p(tables.data_ptr() + 4 * b0 * tables.stride(0))
+        if side is not None and b0 > 0:
+            main.wait_stream(side)                          # (the image is rewritten: the previous slice's side work is done)
         L.check(lib.mojo_hip_mla_unpage(L.ptr(ckv_cache), L.ptr(kpe_cache), L.ptr(ckv_flat), L.ptr(kpe_flat), cq, ck, tb,
                                         tables.stride(0), width, nb, r, rope, page, es, ckv_cache.stride(0),
                                         ckv_cache.stride(2), kpe_cache.stride(0), kpe_cache.stride(2), per_seq, cap, L.ptr(count),
                                         stream), "hip mla un-page")
-        # kv[t, h*(nope+v) + j] = sum_k ckv[t, k] * kv_b_proj[h*(nope+v) + j, k]: one group whose row count is the slice's
-        # device-side number of keys, so rows past it are never computed
-        L.check(lib.mojo_hip_group_gemm(L.ptr(ckv_flat), L.ptr(proj), L.ptr(kv), L.ptr(count), 0, cap, r, kv_cols, 1, 1,
-                                        L.dtype_code(dt), L.ptr(ws), ws.numel(), stream), "hip mla decompression")
         last = b0 + nb >= batch
-        L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), cq, ck, tq,
-                                              nb, heads, nope, rope, vdim,
-                                              min(tq, per_seq) if max_q_len is None else max_q_len, per_seq, cap, scale,
-                                              1 if round_scaled_scores else 0, 1 if last else 0,
-                                              L.dtype_code(dt), stream), "hip mla prefill attention")
+        events = []
+        if side is not None:
+            side.wait_stream(main)                          # the un-paged latent and the key count are ready
+            for g in range(1, groups):
+                decompress(g, side)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                events.append(ev)
+        decompress(0, main)
+        for g in range(groups):
+            if g > 0:
+                main.wait_event(events[g - 1])
+            L.check(lib.mojo_hip_mla_prefill_attn(L.ptr(query), L.ptr(kv), L.ptr(kpe_flat), L.ptr(sink), L.ptr(out), cq, ck, tq,
+                                                  nb, heads, g * (heads // groups), heads // groups, nope, rope, vdim,
+                                                  min(tq, per_seq) if max_q_len is None else max_q_len, per_seq, cap, scale,
+                                                  1 if round_scaled_scores else 0, 1 if (last and g == 0) else 0,
+                                                  L.dtype_code(dt), stream), "hip mla prefill attention")
     return out
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """One side stream per device for the decompression GEMMs that run beside the attention (created once, outside any
+    capture when possible; every use is joined back into the caller's stream by an event before the call returns)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _head_groups(heads: int, keys_capacity: int) -> int:
+    """How many head groups the decompression / attention pipeline uses.  Default ONE (a single GEMM, then a single attention
+    launch): measured on an MI355X at DeepSeek-V3 dims (scripts/probes/mla_prefill_groups_ab.py, round 4; same bits for every
+    group count): 4 x 512 211 us as one group, 237 us as two, 235-246 us as four; + 2048 cached 1 000 / 971 / 1 007 us.  The
+    two kernels do not share the chip — the GEMM's 256 x 256 tiles occupy every CU, a half-width GEMM runs at the same
+    tiles per second — so the side stream buys at most 3 % on the long case and costs 12 % on the short one.
+    ``MOJO_HIP_MLA_PREFILL_GROUPS=<n>`` selects the pipeline."""
+    env = os.environ.get("MOJO_HIP_MLA_PREFILL_GROUPS")
+    if env:
+        g = max(1, int(env))
+        while g > 1 and heads % g:
+            g -= 1
+        return g
+    return 1
 
 
 def _decode_decompressed(op, query, ckv_cache, kpe_cache, total_seq_lens, block_tables, softmax_scale, max_total_seq_len):

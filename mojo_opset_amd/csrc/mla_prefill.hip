@@ -94,7 +94,9 @@ struct MlaPfArgs {
   void* out;                 // [T, H, vd]
   const int32_t* cu_q;
   const int32_t* cu_kv;      // may be null: kv_len = q_len
-  int heads, batch, n_qb;
+  int heads, batch, n_qb;    // heads = heads of the tensors (row strides)
+  int head0, heads_here;     // this launch covers heads [head0, head0 + heads_here): the decompression of the next head group
+                             // can run beside it on another stream (operators/mla.py)
   int capacity_rows;         // rows of `kv` / `kpe`: keys at or past it do not exist (mla_unpage wrote none)
   int per_seq;               // keys kept per sequence (mla_unpage's rule: rows of sequence b start at sum_{i<b} min(len_i, per_seq))
   int64_t total_tokens;      // rows of `out`; rows behind cu_q[batch] are zeroed when zero_tail is set
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   // is pinned to XCD (unit % 8) and its query blocks take consecutive slots there, longest first — they are resident together
   // and the later ones find the tiles of the first in L2.  (Query block as the slow coordinate, as in the GQA kernel, put 64
   // other units' streams — ~80 MB through a 4 MiB L2 — between two readers of the same keys: every block read HBM.)
-  const int inner = a.heads * a.batch;
+  const int inner = a.heads_here * a.batch;
   const int units_per_xcd = (inner + 7) / 8;
   const int n_attn = 8 * units_per_xcd * a.n_slots;
   if (static_cast<int>(blockIdx.x) >= n_attn) {          // trailing workgroups: rows no sequence owns read as zeros
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   // slot when n_qb is even), so consecutive units start on consecutive engines and the order inside a unit stays.
   if (slot % a.n_slots >= a.n_qb) return;
   const int qb = a.n_qb - 1 - slot % a.n_slots;
-  const int head = unit % a.heads, b = unit / a.heads;
+  const int head = a.head0 + unit % a.heads_here, b = unit / a.heads_here;
   const int q_start = a.cu_q[b];
   const int q_len = a.cu_q[b + 1] - q_start;
   const int kv_start = mla_clamped_start(a.cu_kv ? a.cu_kv : a.cu_q, b, a.per_seq);   // row in the (slice-relative) flat buffers
@@ -471,7 +473,7 @@ static int launch_mla_pf(const MlaPfArgs& a, hipStream_t s) {
   static std::atomic<uint64_t> attr_set{0};
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MPF_LDS);
   const int64_t n_zero = a.zero_tail ? ceil_div(a.total_tokens, static_cast<int64_t>(MPF_ZERO_TOKENS)) : 0;
-  const int64_t blocks = static_cast<int64_t>(a.n_slots) * 8 * ceil_div(static_cast<int64_t>(a.heads) * a.batch, 8) + n_zero;
+  const int64_t blocks = static_cast<int64_t>(a.n_slots) * 8 * ceil_div(static_cast<int64_t>(a.heads_here) * a.batch, 8) + n_zero;
   MOJO_REQUIRE(blocks < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "mla_prefill: grid limit");
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(256), MPF_LDS, s, a);
   MOJO_CHECK_LAUNCH("mla_prefill");
@@ -529,7 +531,8 @@ extern "C" int mojo_hip_mla_unpage(const void* compressed_kv_cache, const void* 
 extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decompressed, const void* k_pe_flat,
                                          const float* attn_sink, void* out, const int32_t* cu_q_lens,
                                          const int32_t* cu_total_seq_lens, int64_t total_tokens, int64_t batch,
-                                         int64_t heads, int64_t nope, int64_t rope, int64_t v_dim, int64_t max_q_len,
+                                         int64_t heads, int64_t head_begin, int64_t head_count, int64_t nope, int64_t rope,
+                                         int64_t v_dim, int64_t max_q_len,
                                          int64_t max_tokens_per_seq, int64_t capacity_rows, float softmax_scale, int round_scaled_scores,
                                          int zero_padding_rows, int dtype, mojo_stream_t stream) {
   if (total_tokens == 0) return MOJO_OK;
@@ -538,6 +541,8 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   MOJO_REQUIRE(query && kv_decompressed && k_pe_flat && out && cu_q_lens, MOJO_EINVAL, "mla_prefill_attn: null pointer");
   MOJO_REQUIRE(mojo_hip_mla_prefill_supported(nope, rope, v_dim, dtype), MOJO_EUNSUPPORTED,
                "mla_prefill_attn: (nope, rope, v) = (%lld, %lld, %lld) has no instantiation", (long long)nope, (long long)rope, (long long)v_dim);
+  MOJO_REQUIRE(head_begin >= 0 && head_count > 0 && head_begin + head_count <= heads, MOJO_EINVAL,
+               "mla_prefill_attn: head range [%lld, +%lld) of %lld", (long long)head_begin, (long long)head_count, (long long)heads);
   MOJO_REQUIRE(heads > 0 && batch >= 0 && aligned_to(query, 16) && aligned_to(kv_decompressed, 16) && aligned_to(k_pe_flat, 16) &&
                    aligned_to(out, 16), MOJO_EINVAL, "mla_prefill_attn: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -550,6 +555,7 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   a.q = query; a.kv = kv_decompressed; a.kpe = k_pe_flat; a.sink = attn_sink; a.out = out;
   a.cu_q = cu_q_lens; a.cu_kv = cu_total_seq_lens;
   a.heads = static_cast<int>(heads); a.batch = static_cast<int>(batch);
+  a.head0 = static_cast<int>(head_begin); a.heads_here = static_cast<int>(head_count);
   a.capacity_rows = static_cast<int>(capacity_rows);
   a.per_seq = static_cast<int>(max_tokens_per_seq > 0 && max_tokens_per_seq < (int64_t{1} << 30) ? max_tokens_per_seq : (int64_t{1} << 30));
   const int64_t mq = (max_q_len > 0 && max_q_len < total_tokens) ? max_q_len : total_tokens;

@@ -579,3 +579,25 @@ def test_mla_prefill_decompressed_route(cfg, sink):
     got3 = to_cpu(op(torch.cat([q, pad]).to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV),
                      cu_total_seq_lens=cu(kv_lens).to(DEV)))
     assert torch.equal(got3[: q.shape[0]], got) and torch.count_nonzero(got3[q.shape[0]:]) == 0
+
+
+def test_mla_prefill_head_group_pipeline_gives_the_same_bits(monkeypatch):
+    """MOJO_HIP_MLA_PREFILL_GROUPS: the decompression of head group g + 1 on a side stream beside the attention of group g
+    (opt-in; `mojo_hip_mla_prefill_attn` takes a head range, the GEMM writes a column block of the image).  Per-head work is
+    independent: every group count gives the bits of the single launch, also when the batch is walked in slices."""
+    h, nope, rope, vd, r, page = 64, 128, 64, 128, 512, 16
+    q_lens, cached = [300, 512, 77], [0, 640, 100]
+    kv_lens = [a + b for a, b in zip(q_lens, cached)]
+    g = torch.Generator().manual_seed(11)
+    ckv, kpe, table, w, _ = make_mla(kv_lens, h, nope, rope, vd, r, page, seed=12, wscale=0.05)
+    q = torch.randn(sum(q_lens), h, nope + rope, generator=g).to(torch.bfloat16)
+    op = build("MojoPagedPrefillMLA", h, nope, rope, vd, r, False, w, None, DEV, is_causal=True)
+    args = [t.to(DEV) for t in (q, ckv, kpe, cu(q_lens), table)]
+    kw = dict(cu_total_seq_lens=cu(kv_lens).to(DEV), max_total_seq_len=max(kv_lens))
+    outs = {}
+    for groups in ("1", "2", "4"):
+        monkeypatch.setenv("MOJO_HIP_MLA_PREFILL_GROUPS", groups)
+        outs[groups] = to_cpu(op(*args, **kw))
+    assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["4"])
+    monkeypatch.setenv("MOJO_HIP_MLA_PREFILL_BYTES", str(max(kv_lens) * h * (nope + vd) * 2))      # one sequence per slice
+    assert torch.equal(to_cpu(op(*args, **kw)), outs["1"])
