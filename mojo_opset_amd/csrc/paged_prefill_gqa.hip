@@ -55,6 +55,7 @@ struct PrefillArgs {
   // prefill_merge_kernel combines them.  ksplit == 1: no workspace, the workgroup writes `out` itself.
   int ksplit;
   int pp;                    // 1 (experiments build only): prefill_pp_kernel (experiments/paged_prefill_pp.h): 8-wave workgroups of 256 rows, n_qb counts blocks of 256 / G positions
+  int m32;                   // 1 (experiments build only): prefill_m32_kernel (experiments/paged_prefill_m32.h): the same decomposition on 32x32x16 MFMAs (head_dim 128)
   int w64;                   // 1 (experiments build only): prefill_w64_kernel (experiments/paged_prefill_w64.h): one wave per SIMD, 256-row workgroups, n_qb counts blocks of 256 / G positions
   float* ws_o;               // [blocks * ksplit][128 rows][dim]
   float* ws_ml;              // [blocks * ksplit][128 rows][2]   reference maximum (log2 units), row sum
@@ -734,6 +735,9 @@ __global__ __launch_bounds__(256) void prefill_merge_kernel(PrefillArgs a) {
 }
 
 }  // namespace mojo
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS        // the default decomposition on 32x32x16 MFMAs: parity-green, measured 4-5 % slower (DESIGN Appendix A #10c)
+#include "experiments/paged_prefill_m32.h"
+#endif
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS        // phase-alternating kernel, measured 5-20 % slower (DESIGN Appendix A #10a): opt-in build only
 #include "experiments/paged_prefill_pp.h"
 #else
@@ -773,6 +777,24 @@ static void launch_pf(const PrefillArgs& a, dim3 grid, hipStream_t s) {
     }
   }
 #endif
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+  if constexpr (DK == 4) {
+    if (a.m32) {
+      static std::atomic<uint64_t> m32_attr_set{0};
+      if (first_call_on_device(m32_attr_set)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_m32_kernel<T, G, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_m32_kernel<T, G, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_LDS);
+      }
+      if (a.ksplit > 1) {
+        hipLaunchKernelGGL((prefill_m32_kernel<T, G, true>), grid, dim3(256), PF_LDS, s, a);
+        hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch * PF_MERGE_SPLIT)), dim3(256), 0, s, a);
+      } else {
+        hipLaunchKernelGGL((prefill_m32_kernel<T, G, false>), grid, dim3(256), PF_LDS, s, a);
+      }
+      return;
+    }
+  }
+#endif
   if (a.ksplit > 1) {
     hipLaunchKernelGGL((prefill_kernel<T, G, DK, true>), grid, dim3(256), PF_LDS, s, a);
     hipLaunchKernelGGL((prefill_merge_kernel<T, G>), dim3(static_cast<unsigned>(a.n_qb * a.hkv * a.batch * PF_MERGE_SPLIT)), dim3(256), 0, s, a);
@@ -803,6 +825,16 @@ static bool prefill_use_w64(int64_t max_q, int64_t batch, int hkv, int G) {
   return false;
 }
 
+// Experiments build only: the 32x32x16 form of the default decomposition (experiments/paged_prefill_m32.h), head_dim 128,
+// when MOJO_HIP_PREFILL_M32=1.
+static bool prefill_use_m32() {
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+  const char* e = getenv("MOJO_HIP_PREFILL_M32");
+  if (e && e[0] == '1') return true;
+#endif
+  return false;
+}
+
 static bool prefill_use_pp(int64_t max_q) {
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
   const char* e = getenv("MOJO_HIP_PREFILL_PP");
@@ -818,6 +850,7 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
   a.pp = (a.ksplit == 1 && a.fast_stage && a.max_pages <= PP_TABLE && prefill_use_pp(max_q)) ? 1 : 0;
   a.w64 = (!a.pp && a.ksplit == 1 && a.fast_stage && a.dim == 128 && a.max_pages <= W64_TABLE - 16 &&
            prefill_use_w64(max_q, batch, a.hkv, G)) ? 1 : 0;
+  a.m32 = (!a.pp && !a.w64 && a.dim == 128 && prefill_use_m32()) ? 1 : 0;
   const int qpb = ((a.pp || a.w64) ? 256 : 128) / G;
   const int64_t n_qb = ceil_div(max_q, qpb);
   const int64_t n_zero = ceil_div(a.total_tokens, static_cast<int64_t>(PF_ZERO_TOKENS));

@@ -306,3 +306,25 @@ def test_prefill_one_wave_per_simd_kernel(cfg, monkeypatch):
     assert torch.equal(got, again)
     assert_close_tree(to_cpu(got), want, ATOL, RTOL)
     torch.testing.assert_close(got.float(), base.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("cfg", [([513, 300, 64], [0, 2000, 100], 32, 8, 128, 16), ([700, 129], [31, 0], 16, 2, 128, 32), ([512], [6000], 8, 8, 128, 16)],
+                         ids=["ragged_cached", "g8", "key_split"])
+def test_prefill_32x32_mfma_form(cfg, monkeypatch):
+    """prefill_m32_kernel (csrc/experiments/paged_prefill_m32.h, MOJO_HIP_PREFILL_M32=1 in an experiments build): the default
+    decomposition on v_mfma_f32_32x32x16 — oracle, default kernel, bit stability, key split included."""
+    skip_unless_experiments_build()
+    q_lens, cached, hq, hkv, d, page = cfg
+    q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, hq, hkv, d, page, seed=47)
+    op, ref = hip_cls("MojoPagedPrefillGQA")(), torch_cls("MojoPagedPrefillGQA")()
+    kw = dict(softmax_scale=1.0 / math.sqrt(d), max_q_len=max(q_lens), max_total_seq_len=max(kv_lens), cu_total_seq_lens=cu_kv)
+    want = ref(q, k, v, cu_q, table, **kw)
+    dkw = {k_: (v_.to(DEV) if isinstance(v_, torch.Tensor) else v_) for k_, v_ in kw.items()}
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), cu_q.to(DEV), table.to(DEV))
+    monkeypatch.setenv("MOJO_HIP_PREFILL_M32", "0")
+    base = op(*args, **dkw)
+    monkeypatch.setenv("MOJO_HIP_PREFILL_M32", "1")
+    got = op(*args, **dkw)
+    assert torch.equal(got, op(*args, **dkw))
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    torch.testing.assert_close(got.float(), base.float(), atol=2e-2, rtol=2e-2)
