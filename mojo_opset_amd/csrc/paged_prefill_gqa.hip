@@ -232,7 +232,13 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-    for (int ks = 0; ks < DK; ++ks) qf[qt][ks] = *reinterpret_cast<const frag*>(qptr[qt] + ks * 32 + grp * 8);
+    for (int ks = 0; ks < DK; ++ks) {
+      frag f = *reinterpret_cast<const frag*>(qptr[qt] + ks * 32 + grp * 8);
+      // q * scale * log2(e), rounded once to the storage type: the scores leave the MFMA chain in log2 units
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = static_cast<T>(static_cast<float>(f[e]) * a.scale_log2);
+      qf[qt][ks] = f;
+    }
 
 
   // A window of PF_TABLE page ids of this sequence lives in LDS (refilled when the key loop walks past it), so the
@@ -372,7 +378,6 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  const float lazy_raw = PF_LAZY_LOG2 / a.scale_log2;    // the lag in raw-score units (scale > 0)
   const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
   // V^T transposed-read lane offset: lane 4q+p of a 16-group -> key row (4*grp + q), 8 bytes at column 4p
   const int tq = l15 >> 2, tp = l15 & 3;
@@ -438,8 +443,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     if constexpr (FAST) { PF_STAMP(1); }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[0][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // S starts at -reference: the MFMA chain does the subtraction, p = 2^s needs no multiply-add of its own
+      const float s0 = m[0] == -INFINITY ? 0.f : -m[0], s1 = m[1] == -INFINITY ? 0.f : -m[1];
+      s[0][t] = f32x4{s0, s0, s0, s0};
+      s[1][t] = f32x4{s1, s1, s1, s1};
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         s[0][t] = pf_mfma<T>::run(kf[t][ks], qf[0][ks], s[0][t]);
@@ -509,8 +516,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     const int key0 = kb * PF_KEYS + 4 * grp;
     const bool has_hole = MASKED && (kb + 1) * PF_KEYS > first_neg_key;
     frag pf[2][2];                                                                   // [q tile][32-key step]
-    // p = 2^(s*scale_log2 - m): the maximum is taken over the RAW scores (scale > 0) and the scale is folded into
-    // one fma per element.  The masked variant (diagonal / tail / hole tiles) is a separate wave-uniform path.
+    // p = 2^s, ONE vector instruction per element ahead of the conversion: Q was multiplied by scale * log2(e) when it was
+    // loaded and the accumulators of S were seeded with -m, so s arrives as (q.k * scale - m) * log2(e) (a lone wave hides
+    // three vector instructions per MFMA, profiles/r4_mfma_gap_probe.txt — the multiply-add was the one too many).
+    // The masked variant (diagonal / tail / hole tiles) is a separate wave-uniform path.
     // Lazy reference maximum: every lane takes the maximum of its own 16 scores (vector unit only); the cross-lane
     // reduction, the new reference and the rescale of O run only when some lane's maximum exceeds the reference by more
     // than 2^PF_LAZY_LOG2 (one wave-uniform branch on a ballot).  Any reference within that distance of the true
@@ -525,32 +534,38 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = key0 + 16 * t + r;
-            if (has_hole && key >= first_neg_key) sc[t][r] = 0.f;                   // zero K rows: score 0
+            if (has_hole && key >= first_neg_key) sc[t][r] = m[qt] == -INFINITY ? 0.f : -m[qt];   // zero K rows: score 0 (relative to the reference)
             if (key > offset + row_pos[qt] || key >= kv_len) sc[t][r] = -INFINITY;
           }
       }
       float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
 #pragma unroll
       for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
-      if (__any(mx > m[qt] + lazy_raw)) {                                            // m = -inf: any finite score triggers
+      // the scores are already relative to the reference m (log2 units; 0 while no key has been seen)
+      if (__any(m[qt] == -INFINITY ? mx > -INFINITY : mx > PF_LAZY_LOG2)) {
         mx = xor_max_16_32(mx);
-        mx = fmaxf(mx, m[qt]);
-        const float ms_new = (mx == -INFINITY ? 0.f : mx) * a.scale_log2;
-        const float alpha = fast_exp2(m[qt] * a.scale_log2 - ms_new);
-        m[qt] = mx;
-        lsum[qt] *= alpha;
+        const bool first = m[qt] == -INFINITY;
+        const float d = first ? mx : fmaxf(mx, 0.f);                              // -inf: still no visible key, nothing moves
+        if (d != -INFINITY) {
+          const float alpha = first ? 0.f : fast_exp2(-d);
+          m[qt] = (first ? 0.f : m[qt]) + d;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[t][r] -= d;
+          lsum[qt] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+        }
       }
-      const float ms = (m[qt] == -INFINITY ? 0.f : m[qt]) * a.scale_log2;
       float ps = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         frag f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p0 = fast_exp2(fmaf(sc[2 * kk][r], a.scale_log2, -ms));
-          float p1 = fast_exp2(fmaf(sc[2 * kk + 1][r], a.scale_log2, -ms));
+          float p0 = fast_exp2(sc[2 * kk][r]);
+          float p1 = fast_exp2(sc[2 * kk + 1][r]);
           ps += p0 + p1;
           if constexpr (MASKED) {                                                    // zero V rows: no contribution
             if (has_hole && key0 + 32 * kk + r >= first_neg_key) p0 = 0.f;
@@ -632,7 +647,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16) = o[qt][dt];
       if (grp == 0) {
-        a.ws_ml[(item * 128 + r) * 2 + 0] = m[qt] * a.scale_log2;      // (-inf for a slice that saw no visible key)
+        a.ws_ml[(item * 128 + r) * 2 + 0] = m[qt];      // (-inf for a slice that saw no visible key)
         a.ws_ml[(item * 128 + r) * 2 + 1] = ls;
       }
     }
