@@ -184,3 +184,22 @@ def test_group_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(trans,
     monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")
     direct = op(x, cnt)
     assert torch.equal(staged, direct)
+
+
+@pytest.mark.parametrize("counts,k,n", [([300, 0, 17, 1000, 255, 1], 512, 768), ([2560] * 2, 1024, 512), ([513, 7], 448, 264 + 248)])
+def test_group_gemm_four_wave_experiment_is_bit_identical(counts, k, n, monkeypatch):
+    """experiments/gemm_w128.h (experiments build, MOJO_HIP_GEMM_W128=1): four waves of 128x128 per
+    256x256 tile, [N,K] weights.  Same 16x16x32 MFMA chain per output element as the shipped kernel -> the same bits,
+    ragged and empty groups and partial N tiles included."""
+    from hip_utils import skip_unless_experiments_build
+    skip_unless_experiments_build()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(sum(counts), k, generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randn(len(counts), n, k, generator=g).to(torch.bfloat16).to(DEV)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    op = hip_cls("MojoGroupGemm")(w, True)
+    monkeypatch.setenv("MOJO_HIP_GEMM_W128", "0")
+    shipped = op(x, cnt)
+    monkeypatch.setenv("MOJO_HIP_GEMM_W128", "1")
+    four = op(x, cnt)
+    assert torch.equal(shipped, four)
