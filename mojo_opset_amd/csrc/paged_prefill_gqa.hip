@@ -369,11 +369,25 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 
   // ---- state ----------------------------------------------------------------------------------------------
   f32x4 o[2][DT];
-  float m[2], lsum[2];
+  // m: reference of the running softmax (log2 units; -inf until a key was seen).  seed = -m (0 until then) starts every S
+  // accumulator; thr = what a lane maximum of relative scores must exceed to move the reference (-inf until then: any finite
+  // score does).  All three change only on the rare reference-update path.
+  // The row sums come out of the matrix pipe: osum[qt] accumulates P against a V^T tile of ones (one MFMA per 32 keys and q
+  // tile, +6 % MFMAs) — every lane then holds the sum over ALL keys of its query column, and the 32 vector adds per tile and
+  // the closing cross-lane reduction are gone (the kernel is issue-bound on vector instructions, section 4.4).
+  float m[2], seed[2], thr[2];
+  f32x4 osum[2];
+  frag ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = static_cast<T>(1.0f);
+  float lhole[2] = {0.f, 0.f};   // keys behind a negative page id: score 0 counts in the denominator, their V rows are zero -> P is
+                                 // zeroed in front of the matrix pipe and their share of the row sum is kept here (masked tiles only)
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     m[qt] = -INFINITY;
-    lsum[qt] = 0.f;
+    seed[qt] = 0.f;
+    thr[qt] = -INFINITY;
+    osum[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -444,9 +458,8 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       // S starts at -reference: the MFMA chain does the subtraction, p = 2^s needs no multiply-add of its own
-      const float s0 = m[0] == -INFINITY ? 0.f : -m[0], s1 = m[1] == -INFINITY ? 0.f : -m[1];
-      s[0][t] = f32x4{s0, s0, s0, s0};
-      s[1][t] = f32x4{s1, s1, s1, s1};
+      s[0][t] = f32x4{seed[0], seed[0], seed[0], seed[0]};
+      s[1][t] = f32x4{seed[1], seed[1], seed[1], seed[1]};
 #pragma unroll
       for (int ks = 0; ks < DK; ++ks) {
         s[0][t] = pf_mfma<T>::run(kf[t][ks], qf[0][ks], s[0][t]);
@@ -534,31 +547,41 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int key = key0 + 16 * t + r;
-            if (has_hole && key >= first_neg_key) sc[t][r] = m[qt] == -INFINITY ? 0.f : -m[qt];   // zero K rows: score 0 (relative to the reference)
+            if (has_hole && key >= first_neg_key) sc[t][r] = seed[qt];   // zero K rows: score 0 (relative to the reference)
             if (key > offset + row_pos[qt] || key >= kv_len) sc[t][r] = -INFINITY;
           }
       }
-      float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
-#pragma unroll
-      for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
+      // lane maximum of its 16 scores as a CHAIN max(max(m, x), y): hipcc folds each link into one v_max3 (8 instructions; a
+      // balanced tree of fmaxf became 22 v_max + 5 v_max3).  Not inline asm: the hazard recogniser does not see into asm and
+      // a v_max3 that reads S too early behind its MFMA returns stale scores.
+      float mx = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
+      mx = fmaxf(fmaxf(mx, sc[0][3]), sc[1][0]);
+      mx = fmaxf(fmaxf(mx, sc[1][1]), sc[1][2]);
+      mx = fmaxf(fmaxf(mx, sc[1][3]), sc[2][0]);
+      mx = fmaxf(fmaxf(mx, sc[2][1]), sc[2][2]);
+      mx = fmaxf(fmaxf(mx, sc[2][3]), sc[3][0]);
+      mx = fmaxf(fmaxf(mx, sc[3][1]), sc[3][2]);
+      mx = fmaxf(mx, sc[3][3]);
       // the scores are already relative to the reference m (log2 units; 0 while no key has been seen)
-      if (__any(m[qt] == -INFINITY ? mx > -INFINITY : mx > PF_LAZY_LOG2)) {
+      if (__any(mx > thr[qt])) {
         mx = xor_max_16_32(mx);
         const bool first = m[qt] == -INFINITY;
         const float d = first ? mx : fmaxf(mx, 0.f);                              // -inf: still no visible key, nothing moves
         if (d != -INFINITY) {
           const float alpha = first ? 0.f : fast_exp2(-d);
           m[qt] = (first ? 0.f : m[qt]) + d;
+          seed[qt] = -m[qt];
+          thr[qt] = PF_LAZY_LOG2;
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[t][r] -= d;
-          lsum[qt] *= alpha;
+          osum[qt] *= alpha;
+          if constexpr (MASKED) lhole[qt] *= alpha;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
         }
       }
-      float ps = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         frag f;
@@ -566,10 +589,9 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         for (int r = 0; r < 4; ++r) {
           float p0 = fast_exp2(sc[2 * kk][r]);
           float p1 = fast_exp2(sc[2 * kk + 1][r]);
-          ps += p0 + p1;
           if constexpr (MASKED) {                                                    // zero V rows: no contribution
-            if (has_hole && key0 + 32 * kk + r >= first_neg_key) p0 = 0.f;
-            if (has_hole && key0 + 32 * kk + 16 + r >= first_neg_key) p1 = 0.f;
+            if (has_hole && key0 + 32 * kk + r >= first_neg_key) { lhole[qt] += p0; p0 = 0.f; }
+            if (has_hole && key0 + 32 * kk + 16 + r >= first_neg_key) { lhole[qt] += p1; p1 = 0.f; }
           }
           f[r] = static_cast<T>(p0);
           f[4 + r] = static_cast<T>(p1);
@@ -577,7 +599,6 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
         }
         pf[qt][kk] = f;
       }
-      lsum[qt] += ps;
     };
     // V^T batch 0 is requested before the softmax (its LDS latency hides behind the vector work), batch 1 before batch
     // 0's MFMAs; every wait is lgkmcnt(0) on data that has long landed.
@@ -600,6 +621,13 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
           o[0][dt0 + i] = pf_mfma<T>::run(vf, pf[0][kk], o[0][dt0 + i]);
           o[1][dt0 + i] = pf_mfma<T>::run(vf, pf[1][kk], o[1][dt0 + i]);
         }
+      if (dt0 == 0) {                                    // row sums: P against a V^T tile of ones
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          osum[0] = pf_mfma<T>::run(ones, pf[0][kk], osum[0]);
+          osum[1] = pf_mfma<T>::run(ones, pf[1][kk], osum[1]);
+        }
+      }
     };
     retire_v(vb0);
     issue_v(vb1, DT / 2);                                // into the registers the scores just vacated
@@ -642,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const int r = wave * 32 + qt * 16 + l15;
-      const float ls = xor_sum_16_32(lsum[qt]);
+      const float ls = osum[qt][0] + xor_sum_16_32(lhole[qt]);
       float* po = a.ws_o + (item * 128 + r) * a.dim + grp * 4;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) *reinterpret_cast<f32x4*>(po + dt * 16) = o[qt][dt];
@@ -658,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   typedef typename vec_of<T, 4>::type V4;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    const float inv = 1.0f / xor_sum_16_32(lsum[qt]);
+    const float inv = 1.0f / (osum[qt][0] + xor_sum_16_32(lhole[qt]));
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       V4 ov;
