@@ -360,8 +360,13 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     return (static_cast<int64_t>(phys) * a.c_blk + static_cast<int64_t>(key_w & (a.page - 1)) * a.c_tok) * static_cast<int64_t>(sizeof(T));
   };
   // piece i of the 8 DMA instructions of a tile: K (even i) or V (odd i) of the 4 keys i/2 of this wave's 16
-  auto stage_fast_piece = [&](int buf, int64_t sb, int i) {
-    const char* src = reinterpret_cast<const char*>((i & 1) ? vbase : kbase) + sb + ((i & 1) ? voff_v[i >> 1] : voff_k[i >> 1]);
+  // (sk / sv: the tile's K / V row bases as SCALAR pointers pinned by an empty asm — left to itself hipcc hoists
+  // `kbase + voff` out of the loop as a 64-bit vector and adds the tile's base with two vector instructions per piece; a
+  // scalar base + a 32-bit lane offset is the instruction's own addressing mode)
+  auto stage_fast_piece = [&](int buf, const char* sk, const char* sv, int i) {
+    unsigned vo = (i & 1) ? voff_v[i >> 1] : voff_k[i >> 1];
+    asm volatile("" : "+v"(vo));                         // keeps the zero-extension next to the load (instruction selection is per block)
+    const char* src = ((i & 1) ? sv : sk) + vo;
     lds_c* dst = smem + buf * 2 * PF_TILE_BYTES + (i & 1) * PF_TILE_BYTES + (wave * 16 + (i >> 1) * 4) * 256;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   // tile, +6 % MFMAs) — every lane then holds the sum over ALL keys of its query column, and the 32 vector adds per tile and
   // the closing cross-lane reduction are gone (the kernel is issue-bound on vector instructions, section 4.4).
   float m[2], seed[2], thr[2];
+  f32x4 seedv[2];                // seed in the four registers an MFMA reads its C operand from
   f32x4 osum[2];
   frag ones;
 #pragma unroll
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   for (int qt = 0; qt < 2; ++qt) {
     m[qt] = -INFINITY;
     seed[qt] = 0.f;
+    seedv[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
     thr[qt] = -INFINITY;
     osum[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -393,6 +400,9 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   }
 
   const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
+  unsigned klane[DK];            // K fragment read offsets inside a tile: key row l15 of a 16-key block, swizzled chunk of k-step ks
+#pragma unroll
+  for (int ks = 0; ks < DK; ++ks) klane[ks] = l15 * 256 + (((ks * 4 + grp) ^ l15) * 16);
   // V^T transposed-read lane offset: lane 4q+p of a 16-group -> key row (4*grp + q), 8 bytes at column 4p
   const int tq = l15 >> 2, tp = l15 & 3;
 
@@ -417,11 +427,15 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     if constexpr (FAST) { PF_STAMP(0); }
     const int buf = kb & 1;
     int64_t stage_base = 0;
+    const char* stage_k = nullptr;
+    const char* stage_v = nullptr;
     if constexpr (FAST) {
       page_ready(phys_next);
       stage_base = stage_fast_base(kb + 1, phys_next);
       asm volatile("" : "+s"(stage_base));               // computed here, not sunk behind the reads
-      phys_next = page_of_tile(kb + 2);                  // lands long before the next tile asks for it
+      stage_k = reinterpret_cast<const char*>(kbase) + stage_base;
+      stage_v = reinterpret_cast<const char*>(vbase) + stage_base;
+      asm volatile("" : "+s"(stage_k), "+s"(stage_v));
     }
     const lds_c* kt = smem + buf * 2 * PF_TILE_BYTES;
     const unsigned vt = smem_u32 + buf * 2 * PF_TILE_BYTES + PF_TILE_BYTES;
@@ -432,13 +446,37 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     // read issued two steps ahead (what hipcc schedules for a read-then-use loop) leaves the LDS latency exposed on
     // every step
     frag kf[4][DK];
+    if constexpr (FAST) {
+      // asm reads, retired key block by key block with COUNTED waits (LDS reads return in order): hipcc put one lgkmcnt(0) in
+      // front of the first MFMA, i.e. waited for all sixteen reads before using the first four
+      unsigned ka[DK];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int key_row = t * 16 + l15;
+      for (int ks = 0; ks < DK; ++ks) ka[ks] = smem_u32 + buf * 2 * PF_TILE_BYTES + klane[ks];
+#define PF_KREAD(T_)                                                                                                        \
+      if constexpr (DK == 4)                                                                                                \
+        asm volatile("ds_read_b128 %0, %4 offset:" #T_ "*4096\n\tds_read_b128 %1, %5 offset:" #T_ "*4096\n\t"               \
+                     "ds_read_b128 %2, %6 offset:" #T_ "*4096\n\tds_read_b128 %3, %7 offset:" #T_ "*4096"                   \
+                     : "=&v"(kf[T_][0]), "=&v"(kf[T_][1]), "=&v"(kf[T_][DK > 2 ? 2 : 0]), "=&v"(kf[T_][DK > 3 ? 3 : 0])     \
+                     : "v"(ka[0]), "v"(ka[1]), "v"(ka[DK > 2 ? 2 : 0]), "v"(ka[DK > 3 ? 3 : 0]) : "memory");               \
+      else if constexpr (DK == 3)                                                                                           \
+        asm volatile("ds_read_b128 %0, %3 offset:" #T_ "*4096\n\tds_read_b128 %1, %4 offset:" #T_ "*4096\n\t"               \
+                     "ds_read_b128 %2, %5 offset:" #T_ "*4096"                                                              \
+                     : "=&v"(kf[T_][0]), "=&v"(kf[T_][1]), "=&v"(kf[T_][DK > 2 ? 2 : 0])                                    \
+                     : "v"(ka[0]), "v"(ka[1]), "v"(ka[DK > 2 ? 2 : 0]) : "memory");                                        \
+      else                                                                                                                  \
+        asm volatile("ds_read_b128 %0, %2 offset:" #T_ "*4096\n\tds_read_b128 %1, %3 offset:" #T_ "*4096"                   \
+                     : "=&v"(kf[T_][0]), "=&v"(kf[T_][1]) : "v"(ka[0]), "v"(ka[1]) : "memory")
+      PF_KREAD(0); PF_KREAD(1); PF_KREAD(2); PF_KREAD(3);
+#undef PF_KREAD
+    } else {
 #pragma unroll
-      for (int ks = 0; ks < DK; ++ks) {
-        const int chunk = (ks * 4 + grp) ^ (key_row & 15);
-        kf[t][ks] = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(kt + key_row * 256 + chunk * 16);
+      for (int t = 0; t < 4; ++t) {
+        const int key_row = t * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+          const int chunk = (ks * 4 + grp) ^ (key_row & 15);
+          kf[t][ks] = *reinterpret_cast<const __attribute__((address_space(3))) frag*>(kt + key_row * 256 + chunk * 16);
+        }
       }
     }
     // General staging goes out behind the reads (its issue time covers their latency).  Fast staging is issued one DMA
@@ -449,23 +487,33 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     }
     auto dma_piece = [&](int i) {
       if constexpr (FAST) {
-        stage_fast_piece(buf ^ 1, stage_base, i);
+        stage_fast_piece(buf ^ 1, stage_k, stage_v, i);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FAST) { PF_STAMP(1); }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      // S starts at -reference: the MFMA chain does the subtraction, p = 2^s needs no multiply-add of its own
-      s[0][t] = f32x4{seed[0], seed[0], seed[0], seed[0]};
-      s[1][t] = f32x4{seed[1], seed[1], seed[1], seed[1]};
-#pragma unroll
-      for (int ks = 0; ks < DK; ++ks) {
-        s[0][t] = pf_mfma<T>::run(kf[t][ks], qf[0][ks], s[0][t]);
-        s[1][t] = pf_mfma<T>::run(kf[t][ks], qf[1][ks], s[1][t]);
-      }
+    // key block T_ of the asm reads has arrived when (3 - T_) * DK reads are still in flight; then its 2 * DK MFMAs.
+    // S starts at -reference: the MFMA chain does the subtraction, p = 2^s needs no multiply-add of its own
+#define PF_QK(T_)                                                                                                           \
+    if constexpr (FAST) {                                                                                                   \
+      if (T_ > 0) __builtin_amdgcn_sched_barrier(0);          /* the MFMAs of block T_ - 1 stay in front of this wait */     \
+      if constexpr (DK == 4)                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(kf[T_][0]), "+v"(kf[T_][1]), "+v"(kf[T_][DK > 2 ? 2 : 0]), "+v"(kf[T_][DK > 3 ? 3 : 0]) \
+                     : "n"((3 - T_) * DK) : "memory");                                                                      \
+      else if constexpr (DK == 3)                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(kf[T_][0]), "+v"(kf[T_][1]), "+v"(kf[T_][DK > 2 ? 2 : 0]) : "n"((3 - T_) * DK) : "memory"); \
+      else                                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(kf[T_][0]), "+v"(kf[T_][1]) : "n"((3 - T_) * DK) : "memory");           \
+    }                                                                                                                       \
+    s[0][T_] = seedv[0];                                                                                                    \
+    s[1][T_] = seedv[1];                                                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < DK; ++ks) {                                                                     \
+      s[0][T_] = pf_mfma<T>::run(kf[T_][ks], qf[0][ks], s[0][T_]);                                                          \
+      s[1][T_] = pf_mfma<T>::run(kf[T_][ks], qf[1][ks], s[1][T_]);                                                          \
     }
+    PF_QK(0) PF_QK(1) PF_QK(2) PF_QK(3)
+#undef PF_QK
     // ---- V^T fragments: transposed reads, 4 per d tile, issued in two batches of DT/2 d tiles.
     // Each batch is one asm statement (issue) + one wait statement naming every destination (hipcc must not touch
     // them in between); the waits are lgkmcnt(0) because scalar loads share the counter and return out of order.
@@ -571,6 +619,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
           const float alpha = first ? 0.f : fast_exp2(-d);
           m[qt] = (first ? 0.f : m[qt]) + d;
           seed[qt] = -m[qt];
+          seedv[qt] = f32x4{seed[qt], seed[qt], seed[qt], seed[qt]};
           thr[qt] = PF_LAZY_LOG2;
 #pragma unroll
           for (int t = 0; t < 4; ++t)
@@ -604,6 +653,10 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     // 0's MFMAs; every wait is lgkmcnt(0) on data that has long landed.
     s16x4 vb0[16], vb1[16];
     if constexpr (FAST) { PF_STAMP(2); }
+    // the page id of tile kb + 2 (a whole tile ahead of its use).  Requested HERE, behind the QK^T MFMAs: a scalar load in flight
+    // makes every LDS wait an lgkmcnt(0) (scalar loads return out of order), and in front of the K fragment reads that meant
+    // the first MFMA waited for all sixteen of them instead of the first four.
+    if constexpr (FAST) phys_next = page_of_tile(kb + 2);
     issue_v(vb0, 0);
     softmax_tile(0);
     softmax_tile(1);
