@@ -715,6 +715,27 @@ def bench_decode_layer(device):
         return _ENGINE(m, w_dn, None, False), r2
 
     t = _time_graph(layer, reps=4, replays=5)
+
+    # The same layer period with the decode-sized fusions (round 4): output projection -> residual RMSNorm with the K-slice
+    # sums feeding the norm kernel, gate|up projection -> SwiGLU in ONE launch, down projection -> the NEXT layer's residual
+    # RMSNorm likewise.  Same operators' work (two norms, four projections, RoPE, store, attention); the period starts behind
+    # the first norm and ends behind the next layer's, as it would inside a stack.
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_residual_rmsnorm as _GEMM_NORM, dense_gemm_swiglu as _GEMM_GLU
+    h0, r0 = norm1(x, resid)
+
+    def layer_fused():
+        qkv = _ENGINE(h0, w_qkv, None, False)
+        q = qkv[:, : hq * d].reshape(bsz, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].reshape(bsz, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].reshape(bsz, hkv, d).contiguous()
+        q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
+        store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, None, ctx_t)
+        o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1)
+        h2, r2 = _GEMM_NORM(o.reshape(bsz, hq * d), w_o, None, r0, norm2.weight, 1e-5)
+        m = _GEMM_GLU(h2, w_gu)
+        return _GEMM_NORM(m, w_dn, None, r2, norm1.weight, 1e-5)
+
+    t_fused = _time_graph(layer_fused, reps=4, replays=5)
     # the same operators one at a time (each under graph replay on its own): their sum against the whole layer shows what
     # chaining costs (cold weights: each GEMM's 0.1 - 0.2 GB of weights is evicted from the 256 MB MALL by the next one)
     h, r1 = norm1(x, resid)
@@ -740,10 +761,17 @@ def bench_decode_layer(device):
     weights = (w_qkv.numel() + w_o.numel() + w_gu.numel() + w_dn.numel()) * 2
     kv = sum(lens) * hkv * d * 2 * 2
     res = _hbm(t, weights + kv)
+    fused = _hbm(t_fused, weights + kv)
+    fused.update({"tokens_per_s_one_layer": bsz / t_fused,
+                  "per_op_us": {"o_gemm+norm": _time_graph(lambda: _GEMM_NORM(o, w_o, None, r1, norm2.weight, 1e-5)) * 1e6,
+                                "gate_up_gemm+swiglu": _time_graph(lambda: _GEMM_GLU(h, w_gu), reps=4) * 1e6,
+                                "down_gemm+norm": _time_graph(lambda: _GEMM_NORM(m, w_dn, None, r1, norm1.weight, 1e-5), reps=4) * 1e6},
+                  "note": "graph replay; one period of the layer stack with mojo_hip_gemm_residual_rmsnorm (o-proj and down-proj, "
+                          "the latter feeding the next layer's norm) and mojo_hip_gemm_swiglu; bit-identical to the separate calls"})
     res.update({"weights_MB": weights / 1e6, "kv_MB": kv / 1e6, "tokens_per_s_one_layer": bsz / t,
                 "per_op_us": {n: v * 1e6 for n, v in parts.items()}, "sum_of_ops_us": sum(parts.values()) * 1e6,
                 "note": "graph replay; bytes = the layer's weights + the K/V the attention reads (activations are noise at B = 64)"})
-    return {"llama3_8b_layer_B64_ctx4096": res}
+    return {"llama3_8b_layer_B64_ctx4096": res, "llama3_8b_layer_B64_ctx4096_fused": fused}
 
 
 def bench_dense_decode(device):

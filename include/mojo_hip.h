@@ -222,6 +222,28 @@ int mojo_hip_gemm(const void* input, const void* weight, const void* bias, void*
                   int64_t w_n_stride, int dtype, void* workspace, int64_t workspace_bytes,
                   mojo_stream_t stream);
 
+/*      Decode-sized fusions of a decoder layer's dense chain (the op sequence of core/operators/moe.py:402-449 and of
+ *      modeling/*: linear -> MojoSwiGLU, linear -> MojoResidualAddRMSNorm).  Results are bit-identical to the separate
+ *      calls (mojo_hip_gemm, mojo_hip_swiglu_rows, mojo_hip_residual_add_rmsnorm): the fused kernels round where
+ *      those round (gemm_swiglu never cuts K; where the separate projection would, the fp32 sums differ in order).
+ *      gemm_swiglu: weight = [gate | up] rows, [2*inter, k] K-major (row stride w_n_stride); out [m, inter] =
+ *      silu(x @ gate^T) * (x @ up^T).  m <= 64: ONE launch, wave units dealt evenly over the CUs; otherwise the
+ *      product goes through the workspace.                                                                        */
+int64_t mojo_hip_gemm_swiglu_workspace_bytes(int64_t m, int64_t k, int64_t inter);
+int mojo_hip_gemm_swiglu(const void* input, const void* weight, void* out, int64_t m, int64_t k,
+                         int64_t inter, int64_t lda, int64_t ldc, int64_t w_n_stride, int dtype,
+                         void* workspace, int64_t workspace_bytes, mojo_stream_t stream);
+/*      gemm_residual_rmsnorm: normed_out = RMSNorm(x @ W (+ bias) + residual) * norm_weight, sum_out (may be NULL) =
+ *      the sum, gemm_out (may be NULL) = the product.  With a K split (decode-sized m, few column tiles) the
+ *      fp32 K-slice slabs are summed by the norm kernel itself: the product makes no round trip through HBM.      */
+int64_t mojo_hip_gemm_residual_rmsnorm_workspace_bytes(int64_t m, int64_t k, int64_t n);
+int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* weight, const void* bias,
+                                   const void* residual, const void* norm_weight, void* normed_out,
+                                   void* sum_out, void* gemm_out, int64_t m, int64_t k, int64_t n,
+                                   int64_t lda, int64_t w_k_stride, int64_t w_n_stride, int dtype,
+                                   float eps, void* workspace, int64_t workspace_bytes,
+                                   mojo_stream_t stream);
+
 /*      Same with row maps {rc, ml, off} (NULL or rc == 0: identity): logical row m reads A row
  *      (m / rc) * ml + off + m % rc, and likewise for the C row it writes.  One launch can thus consume or
  *      produce the "c-th sub-chunk of every rank" view of the chunked reduce-scatter / all-gather pipelines. */

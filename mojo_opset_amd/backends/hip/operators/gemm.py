@@ -35,6 +35,63 @@ def dense_gemm(x: torch.Tensor, weight: torch.Tensor, bias, trans_weight: bool) 
     return out.reshape(*x.shape[:-1], n)
 
 
+def dense_gemm_swiglu(x: torch.Tensor, weight_gate_up: torch.Tensor) -> torch.Tensor:
+    """``silu(x @ Wg.T) * (x @ Wu.T)`` for ``weight_gate_up = [Wg; Wu]`` of shape ``[2*inter, K]`` (F.linear layout, the
+    fused gate|up projection of a gated MLP; op chain core/operators/moe.py:441-445, activation.py:38-66) through
+    `mojo_hip_gemm_swiglu`.  Same bits as ``dense_gemm`` followed by ``HIPSwiGLU`` on the two halves; at <= 64 rows it is
+    one launch and the ``[M, 2*inter]`` product never exists."""
+    L.require_cuda(x, weight_gate_up)
+    w = weight_gate_up
+    if w.dim() != 2 or x.dtype != w.dtype or w.shape[0] % 2 or x.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError("hip gemm_swiglu: one 16-bit dtype and a [2*inter, K] weight required")
+    k, inter = x.shape[-1], w.shape[0] // 2
+    assert w.shape[1] == k, "input K must match weight K"
+    if w.stride(1) != 1:
+        w = w.contiguous()
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    out = torch.empty(m, inter, dtype=x.dtype, device=x.device)
+    lib = L.load()
+    ws = torch.empty(lib.mojo_hip_gemm_swiglu_workspace_bytes(m, k, inter), dtype=torch.uint8, device=x.device)
+    L.check(lib.mojo_hip_gemm_swiglu(L.ptr(x2), L.ptr(w), L.ptr(out), m, k, inter, x2.stride(0), inter, w.stride(0),
+                                     L.dtype_code(x.dtype), L.ptr(ws), ws.numel(), L.stream_of(x2)), "hip gemm_swiglu")
+    return out.reshape(*x.shape[:-1], inter)
+
+
+def dense_gemm_residual_rmsnorm(x: torch.Tensor, weight: torch.Tensor, bias, residual, norm_weight: torch.Tensor,
+                                eps: float, trans_weight: bool = False):
+    """``(RMSNorm(x @ W (+ bias) + residual) * norm_weight, x @ W (+ bias) + residual)`` — a projection followed by
+    `MojoResidualAddRMSNorm(norm_pos="pre")` (core/operators/normalization.py:308-362) through
+    `mojo_hip_gemm_residual_rmsnorm`.  Same bits as ``dense_gemm`` followed by ``HIPResidualAddRMSNorm``; when the
+    projection is cut along K (decode-sized M) the K-slice sums feed the norm kernel directly."""
+    L.require_cuda(x, weight, bias, residual, norm_weight)
+    if weight.dim() != 2 or x.dtype != weight.dtype or x.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError("hip gemm_residual_rmsnorm: 2-D weight and one 16-bit dtype required")
+    k = x.shape[-1]
+    n = weight.shape[1] if trans_weight else weight.shape[0]
+    assert (weight.shape[0] if trans_weight else weight.shape[1]) == k, "input K must match weight K"
+    if weight.stride(0) != 1 and weight.stride(1) != 1:
+        weight = weight.contiguous()
+    w_k, w_n = (weight.stride(0), weight.stride(1)) if trans_weight else (weight.stride(1), weight.stride(0))
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    res2 = None if residual is None else residual.reshape(m, n).contiguous()
+    normed = torch.empty(m, n, dtype=x.dtype, device=x.device)
+    summed = torch.empty(m, n, dtype=x.dtype, device=x.device) if residual is not None else None
+    lib = L.load()
+    ws = torch.empty(lib.mojo_hip_gemm_residual_rmsnorm_workspace_bytes(m, k, n), dtype=torch.uint8, device=x.device)
+    L.check(lib.mojo_hip_gemm_residual_rmsnorm(
+        L.ptr(x2), L.ptr(weight), L.ptr(None if bias is None else bias.contiguous()), L.ptr(res2),
+        L.ptr(norm_weight.to(x.dtype).contiguous()), L.ptr(normed), L.ptr(summed), None, m, k, n, x2.stride(0), w_k, w_n,
+        L.dtype_code(x.dtype), float(eps), L.ptr(ws), ws.numel(), L.stream_of(x2)), "hip gemm_residual_rmsnorm")
+    shape = (*x.shape[:-1], n)
+    return normed.reshape(shape), (None if summed is None else summed.reshape(shape))
+
+
 class HIPGroupGemm(MojoGroupGemm):
     supported_platforms_list = _ROCM
 

@@ -65,6 +65,14 @@ void set_error(const char* fmt, ...);
 
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// Threads per row of the RMSNorm kernels (rmsnorm.hip, and the split-K finalize that norms in gemm_skinny.hip: both must cut a
+// row alike, the square sums are added in partition order).  Short rows: one wave per row, four rows per block; up to 512
+// 16-byte vectors: two waves; else a whole block.  With few rows (a decode batch) a whole block per row as soon as every
+// thread has a vector: 64 rows x 4096 would otherwise run on 32 workgroups.
+static inline int rms_threads_per_row(int64_t rows, int64_t n_vec) {
+  if (rows <= 128 && n_vec >= 256) return 256;
+  return n_vec <= 64 * 4 ? 64 : (n_vec <= 128 * 4 ? 128 : 256);
+}
 
 // DPP lane exchange (one VALU instruction, no LDS) --------------------------------------------
 constexpr int DPP_QUAD_XOR1 = 0xB1;          // quad_perm:[1,0,3,2]

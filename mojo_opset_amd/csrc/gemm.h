@@ -43,6 +43,7 @@ struct GemmArgs {
   int splitk = 1;
   void* slab = nullptr;
   int slab_rows = 0;
+  int defer_finalize = 0;    // split-K: leave the slabs to the caller's own finalize (launch_gemm_splitk_resnorm)
   int sk_slot = -1;          // decode-sized kernel: >= 0 = combine the K slices inside the launch (splitk_combine.h), ticket slot
 };
 
@@ -90,6 +91,12 @@ bool gemm_skinny_ok(const GemmArgs& a, int dtype);
 int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups);
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s);
 int launch_gemm_splitk_finalize(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);   // C = round(sum of the fp32 K-slice slabs) (+ bias)
+bool gemm_skinny_glu_ok(const GemmArgs& a, int dtype);                            // dense, <= 64 rows, W = [gate | up] rows: SwiGLU in the epilogue
+int launch_gemm_skinny_glu(const GemmArgs& a, int dtype, hipStream_t s);
+// split-K slabs -> round -> (+ bias) -> + residual -> RMSNorm, one row per workgroup (N <= 16384)
+bool gemm_splitk_resnorm_ok(const GemmArgs& a, int dtype, const void* residual, const void* norm_w, const void* normed, const void* summed);
+int launch_gemm_splitk_resnorm(const GemmArgs& a, int dtype, int64_t m_total, const void* residual, const void* norm_weight,
+                               void* normed, void* summed, float eps, hipStream_t s);
 bool gemm_skinny_ragged_ok(const GemmArgs& a, int dtype, int64_t m_total);        // ragged groups of <= 64 rows on average; prefix arrays for tile height 64
 int launch_gemm_skinny_ragged(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
 int launch_gemm_mfma256_f32out(const GemmArgs& a, int dtype, int accumulate, int64_t m_total, hipStream_t s);

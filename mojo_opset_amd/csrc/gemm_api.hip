@@ -191,3 +191,89 @@ extern "C" int mojo_hip_gemm(const void* input, const void* weight, const void* 
   return mojo_hip_gemm_rowmap(input, weight, bias, out, m, k, n, lda, ldc, w_k_stride, w_n_stride, nullptr, nullptr,
                               dtype, workspace, workspace_bytes, stream);
 }
+
+// ---- decode-sized fusions (a decoder layer's MLP and projections at M <= 64; core/operators/moe.py:402-449 is the op chain) ----
+extern "C" int mojo_hip_swiglu_rows(const void* gate, const void* up, void* out, int64_t rows, int64_t cols, int64_t ld_gate,
+                                    int64_t ld_up, int64_t ld_out, int dtype, float swiglu_limit, mojo_stream_t stream);
+extern "C" int mojo_hip_residual_add_rmsnorm(const void* hidden, const void* residual, const void* weight, void* normed_out,
+                                             void* sum_out, int64_t rows, int64_t dim, int dtype, float eps, mojo_stream_t stream);
+
+extern "C" int64_t mojo_hip_gemm_swiglu_workspace_bytes(int64_t m, int64_t k, int64_t inter) {
+  return 64 + m * 2 * inter * 2 + mojo_hip_gemm_workspace_bytes(m, k, 2 * inter);
+}
+
+extern "C" int mojo_hip_gemm_swiglu(const void* input, const void* weight, void* out, int64_t m, int64_t k, int64_t inter,
+                                    int64_t lda, int64_t ldc, int64_t w_n_stride, int dtype, void* workspace,
+                                    int64_t workspace_bytes, mojo_stream_t stream) {
+  MOJO_REQUIRE(k > 0 && inter > 0 && m >= 0, MOJO_EINVAL, "gemm_swiglu: bad shape");
+  if (m == 0) return MOJO_OK;
+  MOJO_REQUIRE(input && weight && out, MOJO_EINVAL, "gemm_swiglu: null pointer");
+  MOJO_REQUIRE(dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED, "gemm_swiglu: dtype %d (bf16 / fp16 only)", dtype);
+  MOJO_REQUIRE(m < (1LL << 31) && k < (1LL << 31) && inter < (1LL << 30), MOJO_EUNSUPPORTED, "gemm_swiglu: dimension too large");
+  MOJO_REQUIRE(lda >= k && ldc >= inter && w_n_stride >= k, MOJO_EINVAL, "gemm_swiglu: bad strides");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GemmArgs a;
+  a.A = input; a.W = weight; a.C = out; a.bias = nullptr;
+  a.lda = lda; a.ldc = ldc; a.w_group = 0; a.w_k = 1; a.w_n = w_n_stride;
+  a.K = static_cast<int>(k); a.N = static_cast<int>(2 * inter); a.G = 1;
+  a.row_start = nullptr; a.tile_start = nullptr;
+  a.uniform_rows = static_cast<int>(m);
+  a.glu = 1;
+  if (gemm_skinny_glu_ok(a, dtype)) return launch_gemm_skinny_glu(a, dtype, s);
+  // any other shape: the product into the workspace, then the activation over its two halves (same bits: the fused
+  // epilogue rounds where these two launches round)
+  MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_gemm_swiglu_workspace_bytes(m, k, inter) && aligned_to(workspace, 16),
+               MOJO_EWORKSPACE, "gemm_swiglu: workspace too small");
+  char* gu = static_cast<char*>(workspace) + 64;
+  char* ws2 = gu + m * 2 * inter * 2;
+  ws2 += (16 - (reinterpret_cast<uintptr_t>(ws2) & 15)) & 15;
+  const int64_t ws2_bytes = workspace_bytes - (ws2 - static_cast<char*>(workspace));
+  int rc = mojo_hip_gemm(input, weight, nullptr, gu, m, k, 2 * inter, lda, 2 * inter, 1, w_n_stride, dtype, ws2, ws2_bytes, stream);
+  if (rc) return rc;
+  return mojo_hip_swiglu_rows(gu, gu + inter * 2, out, m, inter, 2 * inter, 2 * inter, ldc, dtype, 0.f, stream);
+}
+
+extern "C" int64_t mojo_hip_gemm_residual_rmsnorm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
+  return 64 + m * n * 2 + 16 + mojo_hip_gemm_workspace_bytes(m, k, n);
+}
+
+extern "C" int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* weight, const void* bias, const void* residual,
+                                              const void* norm_weight, void* normed_out, void* sum_out, void* gemm_out,
+                                              int64_t m, int64_t k, int64_t n, int64_t lda, int64_t w_k_stride,
+                                              int64_t w_n_stride, int dtype, float eps, void* workspace,
+                                              int64_t workspace_bytes, mojo_stream_t stream) {
+  MOJO_REQUIRE(k > 0 && n > 0 && m >= 0, MOJO_EINVAL, "gemm_residual_rmsnorm: bad shape");
+  if (m == 0) return MOJO_OK;
+  MOJO_REQUIRE(input && weight && norm_weight && normed_out, MOJO_EINVAL, "gemm_residual_rmsnorm: null pointer");
+  MOJO_REQUIRE(dtype == MOJO_F16 || dtype == MOJO_BF16, MOJO_EUNSUPPORTED, "gemm_residual_rmsnorm: dtype %d (bf16 / fp16 only)", dtype);
+  MOJO_REQUIRE(m < (1LL << 31) && k < (1LL << 31) && n < (1LL << 30), MOJO_EUNSUPPORTED, "gemm_residual_rmsnorm: dimension too large");
+  MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_gemm_residual_rmsnorm_workspace_bytes(m, k, n) && aligned_to(workspace, 16),
+               MOJO_EWORKSPACE, "gemm_residual_rmsnorm: workspace too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* prod = static_cast<char*>(workspace) + 64;                      // the product when the caller does not want it
+  char* ws2 = prod + m * n * 2;
+  ws2 += (16 - (reinterpret_cast<uintptr_t>(ws2) & 15)) & 15;
+  const int64_t ws2_bytes = workspace_bytes - (ws2 - static_cast<char*>(workspace));
+  if (w_k_stride == 1) {                                                // decode-sized split: slabs straight into the norm
+    const int sk = gemm_skinny_splitk(m, k, n, 1);
+    if (sk > 1 && ws2_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4) {
+      GemmArgs a;
+      a.A = input; a.W = weight; a.C = gemm_out; a.bias = bias;
+      a.lda = lda; a.ldc = n; a.w_group = 0; a.w_k = 1; a.w_n = w_n_stride;
+      a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
+      a.row_start = nullptr; a.tile_start = nullptr;
+      a.uniform_rows = static_cast<int>(m);
+      a.splitk = sk; a.slab = ws2 + 64; a.slab_rows = static_cast<int>(m);
+      a.defer_finalize = 1;
+      if (gemm_skinny_ok(a, dtype) && gemm_splitk_resnorm_ok(a, dtype, residual, norm_weight, normed_out, sum_out)) {
+        const int rc = launch_gemm_skinny(a, dtype, s);
+        if (rc) return rc;
+        return launch_gemm_splitk_resnorm(a, dtype, m, residual, norm_weight, normed_out, sum_out, eps, s);
+      }
+    }
+  }
+  void* p = gemm_out ? gemm_out : static_cast<void*>(prod);
+  int rc = mojo_hip_gemm(input, weight, bias, p, m, k, n, lda, n, w_k_stride, w_n_stride, dtype, ws2, ws2_bytes, stream);
+  if (rc) return rc;
+  return mojo_hip_residual_add_rmsnorm(p, residual, norm_weight, normed_out, sum_out, m, n, dtype, eps, stream);
+}

@@ -37,12 +37,25 @@ template <> struct skinny_mfma<f16_t> {
 // RAGGED: groups of different sizes (the experts of an MoE layer at decode: a few rows each, counts known on the device
 // only).  blockIdx.y is then a 64-row block of the prefix arrays built for tile height 64 (gemm_locate_tile): group, first
 // row and the group's end; blocks past the last one exit.  Row maps are not supported in this form.
-template <typename T, int MT, int RB, bool RAGGED = false>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
+//
+// NW = waves per workgroup (each wave owns 16 weight rows; the waves step through K together and share the activation
+// image).  GLU (dense, no K split): the weight is [gate | up] = [2 I, K]; a wave's 16 rows are gate rows c .. c+7 and up rows
+// I + c .. I + c + 7, lanes l and l ^ 32 hold a (gate, up) pair after the last MFMA, and the epilogue stores
+// round(round(silu(round(gate))) * round(up)) — the rounding points of GEMM -> MojoSwiGLU run one after the other — to
+// C [M, I].  NW is chosen on the host so that the wave units divide evenly over the CUs (gemm_skinny_glu_waves): with 64-column
+// workgroups Llama-3-8B's gate|up projection is 448 workgroups on 512 slots — three CUs in four stream twice the bytes of
+// the fourth; seven-wave workgroups are one per CU.
+template <typename T, int MT, int RB, bool RAGGED = false, int NW = 4, bool GLU = false>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
   constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
   constexpr int KB = 128;                                    // elements of K per block
+  constexpr int NT = NW * 64;                                // threads
+  constexpr int AP = (MT * 256 + NT - 1) / NT;               // activation chunks per thread and K block
+  constexpr bool A_EVEN = (MT * 256) % NT == 0;
+  static_assert(!GLU || (!RAGGED && RB == 1), "GLU: dense form only");
+  static_assert(NW == 4 || GLU, "other workgroup sizes: GLU form only");
   __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
-  __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NW][2][16 * ROW];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g4 = lane >> 4;
@@ -60,7 +73,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
     R = a.uniform_rows;
     row_base = grp * R;
   }
-  const int n0 = blockIdx.x * 64 + wave * 16;
+  // wave unit: 16 output columns (GLU: 8 gate + 8 up columns).  A unit past the last one (NW not dividing the count)
+  // streams the last unit again and stores nothing.
+  const int units = a.N / 16;                                // (GLU: N = 2 I, a unit is 8 + 8 columns)
+  const int unit_raw = static_cast<int>(blockIdx.x) * NW + wave;
+  const bool unit_live = unit_raw < units;
+  const int unit = unit_live ? unit_raw : units - 1;
+  const int n0 = GLU ? unit * 8 : unit * 16;                 // first output column (GLU: of C [M, I])
   const int nkb = a.K / KB;
   const int slice = blockIdx.z;
   const int kb0 = static_cast<int>(static_cast<int64_t>(nkb) * slice / a.splitk);
@@ -68,27 +87,32 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
   const T* A = static_cast<const T*>(a.A);
   const T* W = static_cast<const T*>(a.W) + static_cast<int64_t>(grp) * a.w_group;
   // weight rows: instruction sx covers rows 4 sx .. 4 sx + 3 of the wave's 16; lane (row l / 16, 16-byte chunk l % 16)
-  const T* wrow = W + static_cast<int64_t>(n0 + (lane >> 4)) * a.w_n + (lane & 15) * 8;
+  const T* wrow[4];
+#pragma unroll
+  for (int sx = 0; sx < 4; ++sx) {
+    const int64_t r = GLU ? (sx < 2 ? n0 + 4 * sx : a.N / 2 + n0 + 4 * (sx - 2)) + (lane >> 4) : n0 + 4 * sx + (lane >> 4);
+    wrow[sx] = W + r * a.w_n + (lane & 15) * 8;
+  }
 
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // activation chunk p of this thread: row idx / 16 of the group, 16-byte chunk idx % 16 of the K block
-  const T* arow[MT];
+  const T* arow[AP];
 #pragma unroll
-  for (int p = 0; p < MT; ++p) {
-    const int idx = threadIdx.x + 256 * p;
+  for (int p = 0; p < AP; ++p) {
+    const int idx = min(static_cast<int>(threadIdx.x) + NT * p, MT * 256 - 1);
     const int t = min(t0 + (idx >> 4), R - 1);
     arow[p] = A + static_cast<int64_t>(RAGGED ? row_base + t : map_row(row_base + t, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda + (idx & 15) * 8;
   }
   constexpr int DEPTH = 3;
-  u32x4 wreg[DEPTH + 1][4], areg[2][MT];
+  u32x4 wreg[DEPTH + 1][4], areg[2][AP];
   auto load_w = [&](int i, u32x4 (&wr)[4]) {
 #pragma unroll
     for (int sx = 0; sx < 4; ++sx)
     {
-      const u32x4* src = reinterpret_cast<const u32x4*>(wrow + static_cast<int64_t>(sx) * 4 * a.w_n + (kb0 + i) * KB);
+      const u32x4* src = reinterpret_cast<const u32x4*>(wrow[sx] + (kb0 + i) * KB);
       if constexpr (RB == 1) wr[sx] = __builtin_nontemporal_load(src); else wr[sx] = *src;
     }
   };
@@ -97,15 +121,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
     for (int sx = 0; sx < 4; ++sx)
       *reinterpret_cast<u32x4*>(&s_w[wave][buf][(4 * sx + (lane >> 4)) * ROW + (lane & 15) * 16]) = wr[sx];
   };
-  auto load_a = [&](int i, u32x4 (&ar)[MT]) {
+  auto load_a = [&](int i, u32x4 (&ar)[AP]) {
 #pragma unroll
-    for (int p = 0; p < MT; ++p) ar[p] = *reinterpret_cast<const u32x4*>(arow[p] + (kb0 + i) * KB);
+    for (int p = 0; p < AP; ++p) ar[p] = *reinterpret_cast<const u32x4*>(arow[p] + (kb0 + i) * KB);
   };
-  auto store_a = [&](int buf, const u32x4 (&ar)[MT]) {
+  auto store_a = [&](int buf, const u32x4 (&ar)[AP]) {
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      const int idx = threadIdx.x + 256 * p;
-      *reinterpret_cast<u32x4*>(&s_a[buf][(idx >> 4) * ROW + (idx & 15) * 16]) = ar[p];
+    for (int p = 0; p < AP; ++p) {
+      const int idx = threadIdx.x + NT * p;
+      if (A_EVEN || idx < MT * 256) *reinterpret_cast<u32x4*>(&s_a[buf][(idx >> 4) * ROW + (idx & 15) * 16]) = ar[p];
     }
   };
   if (nb > 0) {
@@ -146,11 +170,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs a) {
       constexpr int r = decltype(RC)::value;
       if (i0 + r < nb) body(i0 + r, RC, std::true_type{});
     });
+  if (!unit_live) return;
+  T* C = static_cast<T*>(a.C);
+  typedef typename vec_of<T, 4>::type V4;
+  if constexpr (GLU) {
+    // lane (g4, l15) holds weight rows 4 g4 .. 4 g4 + 3 of the wave's 16 for token l15: g4 0, 1 = gate columns n0 + 4 g4 + e,
+    // g4 2, 3 = the up columns of the same index: the partner sits 32 lanes up
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x4 other;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) other[e] = __shfl_xor(acc[mt][e], 32);
+      const int t = t0 + mt * 16 + l15;
+      if (g4 >= 2 || t >= R) continue;
+      V4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gf = static_cast<float>(static_cast<T>(acc[mt][e])), uf = static_cast<float>(static_cast<T>(other[e]));
+        const float sg = static_cast<float>(static_cast<T>(silu_f(gf)));
+        o[e] = static_cast<T>(sg * uf);
+      }
+      *reinterpret_cast<V4*>(C + static_cast<int64_t>(map_row(row_base + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n0 + 4 * g4) = o;
+    }
+    return;
+  }
   // lane holds rows t = mt*16 + l15 of the group, columns n0 + 4 g4 .. +3
   const int n = n0 + 4 * g4;
-  T* C = static_cast<T*>(a.C);
   const T* bias = static_cast<const T*>(a.bias);
-  typedef typename vec_of<T, 4>::type V4;
   auto emit = [&](int t, f32x4 v) {
     V4 o;
 #pragma unroll
@@ -218,6 +264,129 @@ __global__ __launch_bounds__(256) void gemm_skinny_finalize_kernel(GemmArgs a, i
     }
     *reinterpret_cast<V4*>(C + static_cast<int64_t>(map_row(static_cast<int>(m), a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
   }
+}
+
+// split-K finalize fused with MojoResidualAddRMSNorm (the consumer of a decoder layer's output / down projection):
+//   x      = round_T(sum_s slab[s][m][:]) (+ bias after the rounding)      -- what gemm_skinny_finalize_kernel stores
+//   sum    = round_T(x + residual)                                        -- rmsnorm.hip, same thread / row partition and the
+//   normed = round_T(sum * rsqrt(mean(sum^2) + eps) * weight)                same order of the square sum: identical bits
+// The product never reaches HBM as a tensor (gemm_out == nullptr) and one launch + one round trip fall away.
+template <typename T, int TPR>
+__global__ __launch_bounds__(256) void gemm_splitk_resnorm_kernel(GemmArgs a, int64_t rows, const T* __restrict__ residual,
+                                                                  const T* __restrict__ norm_w, T* __restrict__ normed,
+                                                                  T* __restrict__ summed, T* __restrict__ gemm_out, float eps) {
+  constexpr int VEC = 8, CACHE = 8;
+  typedef typename vec_of<T, VEC>::type V;
+  constexpr int ROWS_PER_BLOCK = 256 / TPR;
+  constexpr int NWV = TPR / 64;
+  __shared__ float red[4];
+  const int sub = threadIdx.x / TPR, tid = threadIdx.x % TPR;
+  const int dim = a.N, n_vec = dim / VEC;
+  const float inv_dim = 1.0f / static_cast<float>(dim);
+  const float* slab = static_cast<const float*>(a.slab);
+  const T* bias = static_cast<const T*>(a.bias);
+  const int64_t row0 = static_cast<int64_t>(blockIdx.x) * ROWS_PER_BLOCK;
+  const bool live = row0 + sub < rows;
+  const int64_t row = live ? row0 + sub : rows - 1;
+  V cache[CACHE];
+  float ss = 0.f;
+  int c = 0;
+  // K-slice sums, slices in index order; four slices' loads are issued together (the loop is otherwise one round trip per slice)
+  constexpr int SB = 4;
+#pragma unroll
+  for (int cc = 0; cc < CACHE; ++cc) {
+    const int v = tid + cc * TPR;
+    if (v >= n_vec) break;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    for (int sx0 = 0; sx0 < a.splitk; sx0 += SB) {
+      f32x4 pl[SB], ph[SB];
+#pragma unroll
+      for (int i = 0; i < SB; ++i) {
+        const int sx = min(sx0 + i, a.splitk - 1);
+        const float* p = slab + (static_cast<int64_t>(sx) * rows + row) * dim + v * VEC;
+        pl[i] = *reinterpret_cast<const f32x4*>(p);
+        ph[i] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < SB; ++i)
+        if (sx0 + i < a.splitk) { lo += pl[i]; hi += ph[i]; }
+    }
+    V x;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) x[j] = static_cast<T>(j < 4 ? lo[j & 3] : hi[j & 3]);
+    if (bias) {
+      const V b = load_vec<T, VEC>(bias + v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) x[j] = static_cast<T>(static_cast<float>(x[j]) + static_cast<float>(b[j]));
+    }
+    if (gemm_out && live) store_vec<T, VEC>(gemm_out + row * dim + v * VEC, x);
+    if (residual) {
+      const V y = load_vec<T, VEC>(residual + row * dim + v * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) x[j] = static_cast<T>(static_cast<float>(x[j]) + static_cast<float>(y[j]));
+      if (summed && live) store_vec<T, VEC>(summed + row * dim + v * VEC, x);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float f = static_cast<float>(x[j]);
+      ss += f * f;
+    }
+    cache[cc] = x;
+    c = cc + 1;
+  }
+  ss = wave_sum(ss);
+  if constexpr (NWV > 1) {
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = ss;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) t += red[sub * NWV + i];
+    ss = t;
+  }
+  const float rstd = rsqrtf(ss * inv_dim + eps);
+#pragma unroll
+  for (int cc = 0; cc < CACHE; ++cc) {
+    const int v = tid + cc * TPR;
+    if (cc >= c) break;
+    const V w = load_vec<T, VEC>(norm_w + v * VEC);
+    V o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = static_cast<T>(static_cast<float>(cache[cc][j]) * rstd * static_cast<float>(w[j]));
+    if (live) store_vec<T, VEC>(normed + row * dim + v * VEC, o);
+  }
+}
+
+bool gemm_splitk_resnorm_ok(const GemmArgs& a, int dtype, const void* residual, const void* norm_w, const void* normed, const void* summed) {
+  if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
+  if (const char* e = getenv("MOJO_HIP_GEMM_RESNORM")) { if (e[0] == '0') return false; }
+  return a.splitk > 1 && a.slab && a.N % 8 == 0 && a.N <= 16384 && a.c_rc == 0 && aligned_to(norm_w, 16) && aligned_to(normed, 16) &&
+         (!residual || aligned_to(residual, 16)) && (!summed || aligned_to(summed, 16)) && (!a.bias || aligned_to(a.bias, 16)) &&
+         (!a.C || aligned_to(a.C, 16));
+}
+
+int launch_gemm_splitk_resnorm(const GemmArgs& a, int dtype, int64_t m_total, const void* residual, const void* norm_weight,
+                               void* normed, void* summed, float eps, hipStream_t s) {
+  MOJO_REQUIRE(gemm_splitk_resnorm_ok(a, dtype, residual, norm_weight, normed, summed), MOJO_EUNSUPPORTED, "gemm split-K -> residual RMSNorm: preconditions not met");
+  const int n_vec = a.N / 8;
+  // the row partition of rmsnorm.hip's launch_rms (16-byte vectors, rms_threads_per_row).  (Its long-row form
+  // re-reads what 4 cached vectors per thread do not hold; 8 cached vectors cover every row this kernel accepts.)
+#define RESNORM(TY, TPR_, BLOCKS)                                                                                            \
+  hipLaunchKernelGGL((gemm_splitk_resnorm_kernel<TY, TPR_>), dim3(static_cast<unsigned>(BLOCKS)), dim3(256), 0, s, a, m_total, \
+                     static_cast<const TY*>(residual), static_cast<const TY*>(norm_weight), static_cast<TY*>(normed),        \
+                     static_cast<TY*>(summed), static_cast<TY*>(a.C), eps)
+#define RESNORM_T(TY)                                                                              \
+  do {                                                                                             \
+    const int tpr = rms_threads_per_row(m_total, n_vec);                                           \
+    if (tpr == 64) RESNORM(TY, 64, ceil_div(m_total, 4));                                          \
+    else if (tpr == 128) RESNORM(TY, 128, ceil_div(m_total, 2));                                   \
+    else RESNORM(TY, 256, m_total);                                                                \
+  } while (0)
+  if (dtype == MOJO_BF16) RESNORM_T(bf16_t); else RESNORM_T(f16_t);
+#undef RESNORM_T
+#undef RESNORM
+  MOJO_CHECK_LAUNCH("gemm(split-K -> residual RMSNorm)");
+  return MOJO_OK;
 }
 
 // Cut K so that the weight stream covers the chip: two workgroups fit a CU (70 KiB of LDS each), so up to 512 are resident;
@@ -289,7 +458,50 @@ int launch_gemm_skinny(const GemmArgs& a_in, int dtype, hipStream_t s) {
 #undef SKINNY_MT
 #undef SKINNY
   MOJO_CHECK_LAUNCH("gemm_skinny");
-  if (a.splitk > 1 && a.sk_slot < 0) return launch_gemm_splitk_finalize(a, dtype, a.uniform_rows, s);
+  if (a.splitk > 1 && a.sk_slot < 0 && !a.defer_finalize) return launch_gemm_splitk_finalize(a, dtype, a.uniform_rows, s);
+  return MOJO_OK;
+}
+
+// ---- dense GEMM + SwiGLU in one launch (decode-sized M, [2 I, K] weights) --------------------------------------------------
+bool gemm_skinny_glu_ok(const GemmArgs& a, int dtype) {
+  if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
+  if (const char* e = getenv("MOJO_HIP_GEMM_SKINNY_GLU")) { if (e[0] == '0') return false; }
+  return a.G == 1 && a.uniform_rows > 0 && a.uniform_rows <= 64 && a.w_k == 1 && a.K % 128 == 0 && a.N % 16 == 0 && a.lda % 8 == 0 &&
+         a.w_n % 8 == 0 && a.ldc % 4 == 0 && a.splitk == 1 && !a.bias && aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
+}
+
+// Waves per workgroup: the count whose workgroups deal the wave units (8 + 8 weight rows each) most evenly over 256 CUs —
+// the stream is per-CU bound, so the launch takes as long as the CU with the most units.  Ties: fewer waves.
+int gemm_skinny_glu_waves(int64_t inter) {
+  if (const char* e = getenv("MOJO_HIP_GEMM_GLU_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 8) return v; }
+  const int64_t units = inter / 8;
+  int best = 4;
+  int64_t best_cost = -1;
+  for (int nw = 4; nw <= 8; ++nw) {
+    const int64_t cost = ceil_div(ceil_div(units, nw), 256) * nw;
+    if (best_cost < 0 || cost < best_cost) { best = nw; best_cost = cost; }
+  }
+  return best;
+}
+
+int launch_gemm_skinny_glu(const GemmArgs& a, int dtype, hipStream_t s) {
+  MOJO_REQUIRE(gemm_skinny_glu_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_skinny(glu): preconditions not met");
+  const int mt = (a.uniform_rows + 15) / 16;
+  const int nw = gemm_skinny_glu_waves(a.N / 2);
+  const dim3 grid(static_cast<unsigned>(ceil_div(a.N / 16, nw)), 1u, 1u);
+#define GLU_K(TY, MT_, NW_) hipLaunchKernelGGL((gemm_skinny_kernel<TY, MT_, 1, false, NW_, true>), grid, dim3(NW_ * 64), 0, s, a)
+#define GLU_NW(TY, MT_)                                                                                   \
+  do {                                                                                                    \
+    switch (nw) { case 4: GLU_K(TY, MT_, 4); break; case 5: GLU_K(TY, MT_, 5); break; case 6: GLU_K(TY, MT_, 6); break; \
+                  case 7: GLU_K(TY, MT_, 7); break; default: GLU_K(TY, MT_, 8); break; }                  \
+  } while (0)
+#define GLU_MT(TY)                                                                                        \
+  do { if (mt <= 1) GLU_NW(TY, 1); else if (mt <= 2) GLU_NW(TY, 2); else GLU_NW(TY, 4); } while (0)
+  if (dtype == MOJO_BF16) GLU_MT(bf16_t); else GLU_MT(f16_t);
+#undef GLU_MT
+#undef GLU_NW
+#undef GLU_K
+  MOJO_CHECK_LAUNCH("gemm_skinny(glu)");
   return MOJO_OK;
 }
 

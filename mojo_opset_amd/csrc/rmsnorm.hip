@@ -114,8 +114,9 @@ static void launch_rms(const void* hidden, const void* residual, const void* wei
     if (nt) hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, TPR, 4, true>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows, static_cast<int>(dim), eps);
     else hipLaunchKernelGGL((rmsnorm_kernel<T, VEC, TPR, 4, false>), dim3(blocks), dim3(256), 0, s, h, r, w, o, so, rows, static_cast<int>(dim), eps);
   };
-  if (n_vec <= 64 * 4) go(std::integral_constant<int, 64>{}, ceil_div(rows, 4));          // short rows: one wave per row, 4 rows per block
-  else if (n_vec <= 128 * 4) go(std::integral_constant<int, 128>{}, ceil_div(rows, 2));   // two waves per row, two rows per block
+  const int tpr = VEC * sizeof(T) == 16 ? rms_threads_per_row(rows, n_vec) : (n_vec <= 64 * 4 ? 64 : (n_vec <= 128 * 4 ? 128 : 256));
+  if (tpr == 64) go(std::integral_constant<int, 64>{}, ceil_div(rows, 4));          // short rows: one wave per row, 4 rows per block
+  else if (tpr == 128) go(std::integral_constant<int, 128>{}, ceil_div(rows, 2));   // two waves per row, two rows per block
   else go(std::integral_constant<int, 256>{}, rows);
 }
 

@@ -149,3 +149,107 @@ def test_split_k_combined_inside_the_launch_gives_the_finalize_kernels_bits(monk
         for c, want in zip(cases, two_launch):
             assert torch.equal(c(), want)
     torch.cuda.synchronize()
+
+
+# ---- decode-sized fusions: GEMM + SwiGLU in one launch, split-K slabs summed by the residual RMSNorm ----------------------
+
+def _swiglu_chain(x, w_gu):
+    from hip_utils import hip_cls
+    gu = dense_gemm(x, w_gu, None, False)
+    inter = w_gu.shape[0] // 2
+    return hip_cls("MojoSwiGLU")()(gu[:, :inter], gu[:, inter:])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,inter", [(64, 4096, 14336), (1, 128, 8), (17, 256, 56), (33, 384, 1024), (64, 1024, 2304),
+                                       (5, 512, 40), (48, 128, 4104),
+                                       (100, 256, 128), (64, 192, 64)])      # > 64 rows / K % 128: the two-launch route
+def test_gemm_swiglu_fused_equals_the_separate_calls_and_the_oracle(dtype, m, k, inter):
+    """`mojo_hip_gemm_swiglu`: same bits as linear -> MojoSwiGLU wherever the separate linear runs unsplit (every workgroup size the balancing rule picks: 56 columns
+    -> 7 units, 1024 -> 128, 2304 -> 288, 40 -> 5, 4104 -> 513 units), and the oracle's chain within its tolerance."""
+    from hip_utils import torch_cls
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_swiglu
+    torch.manual_seed(m * 31 + inter)
+    x = torch.randn(m, k, dtype=dtype)
+    w = (torch.randn(2 * inter, k) * (2.0 / k ** 0.5)).to(dtype)
+    got = dense_gemm_swiglu(x.to(DEV), w.to(DEV))
+    chain = _swiglu_chain(x.to(DEV), w.to(DEV))
+    assert got.shape == (m, inter)
+    if L.load().mojo_hip_gemm_workspace_bytes(m, k, 2 * inter) <= 64:       # the separate projection does not cut K: same bits
+        assert torch.equal(got, chain)
+    else:                                                                    # it sums two or more K slices: another fp32 order
+        assert max_ulp_bf16ish(to_cpu(got), to_cpu(chain), atol=2e-3) <= 2
+    gu = (x.float() @ w.float().t()).to(dtype)
+    want = torch_cls("MojoSwiGLU")()(gu[:, :inter], gu[:, inter:])
+    torch.testing.assert_close(to_cpu(got).float(), want.float(), atol=3e-2, rtol=3e-2)
+
+
+def test_gemm_swiglu_every_workgroup_size_gives_the_same_bits(monkeypatch):
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_swiglu
+    torch.manual_seed(5)
+    m, k, inter = 64, 512, 1016                                              # 127 wave units: every size leaves a partial workgroup
+    x = torch.randn(m, k, dtype=torch.bfloat16, device=DEV)
+    w = (torch.randn(2 * inter, k, device=DEV) * 0.1).to(torch.bfloat16)
+    ref = _swiglu_chain(x, w)
+    for nw in (4, 5, 6, 7, 8):
+        monkeypatch.setenv("MOJO_HIP_GEMM_GLU_WAVES", str(nw))
+        assert torch.equal(dense_gemm_swiglu(x, w), ref), nw
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY_GLU", "0")
+    assert torch.equal(dense_gemm_swiglu(x, w), ref)
+
+
+def test_gemm_swiglu_integer_data_is_exact():
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_swiglu
+    g = torch.Generator().manual_seed(9)
+    m, k, inter = 37, 256, 72
+    x = torch.randint(-2, 3, (m, k), generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (2 * inter, k), generator=g).to(torch.bfloat16)
+    gu = (x.float() @ w.float().t()).to(torch.bfloat16)                       # exact
+    want = (torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:])
+    got = to_cpu(dense_gemm_swiglu(x.to(DEV), w.to(DEV)))
+    assert max_ulp_bf16ish(got, want, atol=1e-3) <= 1                        # (device exp2 / rcp vs torch's silu: one step)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n,bias,resid", [(64, 4096, 4096, False, True), (64, 14336, 4096, False, True), (1, 2048, 512, True, True),
+                                              (33, 8192, 8192, True, True), (64, 4096, 2048, False, False), (16, 1024, 16384, False, True),
+                                              (7, 256, 192, True, True),          # no K split: the two-launch route
+                                              (200, 512, 1024, False, True)])     # 256-row tile kernel, then the norm
+def test_gemm_residual_rmsnorm_fused_equals_the_separate_calls_and_the_oracle(dtype, m, k, n, bias, resid):
+    from hip_utils import hip_cls, torch_cls
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_residual_rmsnorm
+    torch.manual_seed(m + n)
+    x = torch.randn(m, k, dtype=dtype)
+    w = (torch.randn(n, k) / k ** 0.5).to(dtype)
+    b = torch.randn(n, dtype=dtype) if bias else None
+    r = torch.randn(m, n, dtype=dtype) if resid else None
+    nw = (1.0 + 0.1 * torch.randn(n)).to(dtype)
+    eps = 1e-5
+    dev = lambda t: None if t is None else t.to(DEV)
+    normed, summed = dense_gemm_residual_rmsnorm(dev(x), dev(w), dev(b), dev(r), dev(nw), eps)
+    a = dense_gemm(dev(x), dev(w), dev(b), False)
+    if resid:
+        op = hip_cls("MojoResidualAddRMSNorm")(n, eps, "pre", dtype=dtype, device=DEV)
+        op.weight.data.copy_(nw)
+        want_n, want_s = op(a, dev(r))
+        assert torch.equal(summed, want_s)
+    else:
+        op = hip_cls("MojoRMSNorm")(n, eps, dtype=dtype, device=DEV)
+        op.weight.data.copy_(nw)
+        want_n = op(a)
+        assert summed is None
+    assert torch.equal(normed, want_n)
+    # the oracle's chain (fp32 product rounded once, then the golden norm)
+    a_ref = (x.float() @ w.float().t()).to(dtype)
+    if bias:
+        a_ref = (a_ref.float() + b.float()).to(dtype)
+    if resid:
+        ref = torch_cls("MojoResidualAddRMSNorm")(n, eps, "pre", dtype=dtype)
+        ref.weight.data.copy_(nw)
+        ref_n, ref_s = ref(a_ref, r)
+        torch.testing.assert_close(to_cpu(summed).float(), ref_s.float(), atol=3e-2, rtol=2e-2)
+    else:
+        ref = torch_cls("MojoRMSNorm")(n, eps, dtype=dtype)
+        ref.weight.data.copy_(nw)
+        ref_n = ref(a_ref)
+    torch.testing.assert_close(to_cpu(normed).float(), ref_n.float(), atol=3e-2, rtol=2e-2)
