@@ -716,21 +716,19 @@ def bench_decode_layer(device):
 
     t = _time_graph(layer, reps=4, replays=5)
 
-    # The same layer period with the decode-sized fusions (round 4): output projection -> residual RMSNorm with the K-slice
+    # The same layer period with the decode-sized fusions (round 4): QKV projection -> RoPE -> paged KV store with the K-slice
+    # sums taken by the kernel that rotates and stores, output projection -> residual RMSNorm with the K-slice
     # sums feeding the norm kernel, gate|up projection -> SwiGLU in ONE launch, down projection -> the NEXT layer's residual
     # RMSNorm likewise.  Same operators' work (two norms, four projections, RoPE, store, attention); the period starts behind
     # the first norm and ends behind the next layer's, as it would inside a stack.
     from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_residual_rmsnorm as _GEMM_NORM, dense_gemm_swiglu as _GEMM_GLU
     h0, r0 = norm1(x, resid)
 
+    from mojo_opset_amd.backends.hip.operators.gemm import qkv_rope_store as _QKV
+
     def layer_fused():
-        qkv = _ENGINE(h0, w_qkv, None, False)
-        q = qkv[:, : hq * d].reshape(bsz, hq, d)
-        k = qkv[:, hq * d: (hq + hkv) * d].reshape(bsz, hkv, d)
-        v = qkv[:, (hq + hkv) * d:].reshape(bsz, hkv, d).contiguous()
-        q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
-        store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, None, ctx_t)
-        o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1)
+        q_r = _QKV(h0, w_qkv, None, cos, sin, k_cache, v_cache, table, ctx_t, hq, hkv)
+        o = attn(q_r, k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1)
         h2, r2 = _GEMM_NORM(o.reshape(bsz, hq * d), w_o, None, r0, norm2.weight, 1e-5)
         m = _GEMM_GLU(h2, w_gu)
         return _GEMM_NORM(m, w_dn, None, r2, norm1.weight, 1e-5)
@@ -763,11 +761,13 @@ def bench_decode_layer(device):
     res = _hbm(t, weights + kv)
     fused = _hbm(t_fused, weights + kv)
     fused.update({"tokens_per_s_one_layer": bsz / t_fused,
-                  "per_op_us": {"o_gemm+norm": _time_graph(lambda: _GEMM_NORM(o, w_o, None, r1, norm2.weight, 1e-5)) * 1e6,
+                  "per_op_us": {"qkv_gemm+rope+store": _time_graph(lambda: _QKV(h, w_qkv, None, cos, sin, k_cache, v_cache, table, ctx_t, hq, hkv)) * 1e6,
+                                "o_gemm+norm": _time_graph(lambda: _GEMM_NORM(o, w_o, None, r1, norm2.weight, 1e-5)) * 1e6,
                                 "gate_up_gemm+swiglu": _time_graph(lambda: _GEMM_GLU(h, w_gu), reps=4) * 1e6,
                                 "down_gemm+norm": _time_graph(lambda: _GEMM_NORM(m, w_dn, None, r1, norm1.weight, 1e-5), reps=4) * 1e6},
-                  "note": "graph replay; one period of the layer stack with mojo_hip_gemm_residual_rmsnorm (o-proj and down-proj, "
-                          "the latter feeding the next layer's norm) and mojo_hip_gemm_swiglu; bit-identical to the separate calls"})
+                  "note": "graph replay; one period of the layer stack with mojo_hip_qkv_rope_store, mojo_hip_gemm_residual_rmsnorm (o-proj and "
+                          "down-proj, the latter feeding the next layer's norm) and mojo_hip_gemm_swiglu: 6 launches + the attention's; "
+                          "bit-identical to the separate calls"})
     res.update({"weights_MB": weights / 1e6, "kv_MB": kv / 1e6, "tokens_per_s_one_layer": bsz / t,
                 "per_op_us": {n: v * 1e6 for n, v in parts.items()}, "sum_of_ops_us": sum(parts.values()) * 1e6,
                 "note": "graph replay; bytes = the layer's weights + the K/V the attention reads (activations are noise at B = 64)"})

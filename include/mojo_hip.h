@@ -244,6 +244,22 @@ int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* weight, const 
                                    float eps, void* workspace, int64_t workspace_bytes,
                                    mojo_stream_t stream);
 
+/*      qkv_rope_store: one decode step's fused QKV projection (weight [(Hq + 2 Hkv) * D, k] K-major, heads in q | k | v
+ *      order) -> MojoApplyRoPE on q and k (rotate-half over the whole head; cos / sin fp32 [batch, D], one row per
+ *      sequence: core/operators/position_embedding.py) -> q_out [batch, Hq, D] -> MojoStorePagedKVCache in decode mode
+ *      (one token per sequence at position context_kv_lens[b]; kv_cache.py:33-101).  With a K split the slice sums are
+ *      taken by the kernel that rotates and stores: two launches for the chain's five.  Same bits as the separate calls. */
+int64_t mojo_hip_qkv_rope_store_workspace_bytes(int64_t m, int64_t k, int64_t n);
+int mojo_hip_qkv_rope_store(const void* input, const void* weight, const void* bias, const float* cos,
+                            const float* sin, int64_t cos_sin_row_stride, void* q_out, void* key_cache,
+                            void* value_cache, const int32_t* block_table, int64_t block_table_stride,
+                            int64_t max_blocks_per_seq, const int32_t* context_kv_lens, int64_t batch,
+                            int64_t k, int64_t q_heads, int64_t kv_heads, int64_t head_dim, int64_t lda,
+                            int64_t w_n_stride, int64_t num_blocks, int64_t block_size,
+                            int64_t cache_block_stride, int64_t cache_head_stride,
+                            int64_t cache_token_stride, int dtype, void* workspace,
+                            int64_t workspace_bytes, mojo_stream_t stream);
+
 /*      Same with row maps {rc, ml, off} (NULL or rc == 0: identity): logical row m reads A row
  *      (m / rc) * ml + off + m % rc, and likewise for the C row it writes.  One launch can thus consume or
  *      produce the "c-th sub-chunk of every rank" view of the chunked reduce-scatter / all-gather pipelines. */

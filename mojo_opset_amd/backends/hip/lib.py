@@ -71,6 +71,8 @@ SIGNATURES = {
     "mojo_hip_gemm_swiglu": (c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, c_int, _P, _I, _P]),
     "mojo_hip_gemm_residual_rmsnorm_workspace_bytes": (c_int64, [_I, _I, _I]),
     "mojo_hip_gemm_residual_rmsnorm": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, c_int, c_float, _P, _I, _P]),
+    "mojo_hip_qkv_rope_store_workspace_bytes": (c_int64, [_I, _I, _I]),
+    "mojo_hip_qkv_rope_store": (c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P] + [_I] * 12 + [c_int, _P, _I, _P]),
     "mojo_hip_mla_prefill_supported": (c_int, [_I, _I, _I, c_int]),
     "mojo_hip_mla_unpage": (c_int, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 13 + [_P, _P]),
     "mojo_hip_mla_prefill_attn": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, c_float, c_int, c_int, c_int, _P]),

@@ -92,6 +92,42 @@ def dense_gemm_residual_rmsnorm(x: torch.Tensor, weight: torch.Tensor, bias, res
     return normed.reshape(shape), (None if summed is None else summed.reshape(shape))
 
 
+def qkv_rope_store(x: torch.Tensor, weight_qkv: torch.Tensor, bias, cos: torch.Tensor, sin: torch.Tensor,
+                   key_cache: torch.Tensor, value_cache: torch.Tensor, block_table: torch.Tensor,
+                   context_kv_lens: torch.Tensor, q_heads: int, kv_heads: int) -> torch.Tensor:
+    """One decode step in front of the attention: ``qkv = x @ Wqkv.T (+ bias)`` (heads in q | k | v order), `MojoApplyRoPE`
+    on q and k (``cos`` / ``sin`` [B, D], rotate-half over the whole head), `MojoStorePagedKVCache` of the rotated k and of
+    v at position ``context_kv_lens[b]``; returns the rotated q ``[B, Hq, D]``.  Same bits as ``dense_gemm`` -> ``HIPApplyRoPE``
+    -> ``HIPStorePagedKVCache`` (decode mode); through `mojo_hip_qkv_rope_store` the chain is two launches."""
+    L.require_cuda(x, weight_qkv, bias, cos, sin, key_cache, value_cache, block_table, context_kv_lens)
+    if x.dtype not in (torch.bfloat16, torch.float16) or not (x.dtype == weight_qkv.dtype == key_cache.dtype == value_cache.dtype):
+        raise NotImplementedError("hip qkv_rope_store: one 16-bit dtype for activations, weights and caches required")
+    n_blocks, hkv, page, d = key_cache.shape
+    assert hkv == kv_heads and value_cache.shape == key_cache.shape and key_cache.stride() == value_cache.stride()
+    assert key_cache.stride(-1) == 1
+    b, k = x.shape
+    n = (q_heads + 2 * kv_heads) * d
+    assert weight_qkv.shape == (n, k), "weight must be [(Hq + 2 Hkv) * D, K]"
+    assert cos.shape == (b, d) and sin.shape == (b, d), "cos / sin: one [D] row per sequence (rope over the whole head)"
+    w = weight_qkv if weight_qkv.stride(1) == 1 else weight_qkv.contiguous()
+    x2 = x if x.stride(1) == 1 else x.contiguous()
+    cos = cos.float()
+    sin = sin.float()
+    if cos.stride(1) != 1 or sin.stride() != cos.stride():
+        cos, sin = cos.contiguous(), sin.contiguous()
+    table = block_table if block_table.stride(1) == 1 else block_table.contiguous()
+    ctx = context_kv_lens.to(torch.int32).contiguous()
+    q_out = torch.empty(b, q_heads, d, dtype=x.dtype, device=x.device)
+    lib = L.load()
+    ws = torch.empty(lib.mojo_hip_qkv_rope_store_workspace_bytes(b, k, n), dtype=torch.uint8, device=x.device)
+    L.check(lib.mojo_hip_qkv_rope_store(
+        L.ptr(x2), L.ptr(w), L.ptr(None if bias is None else bias.contiguous()), L.ptr(cos), L.ptr(sin), cos.stride(0),
+        L.ptr(q_out), L.ptr(key_cache), L.ptr(value_cache), L.ptr(table), table.stride(0), table.shape[1], L.ptr(ctx), b, k,
+        q_heads, kv_heads, d, x2.stride(0), w.stride(0), n_blocks, page, key_cache.stride(0), key_cache.stride(1),
+        key_cache.stride(2), L.dtype_code(x.dtype), L.ptr(ws), ws.numel(), L.stream_of(x2)), "hip qkv_rope_store")
+    return q_out
+
+
 class HIPGroupGemm(MojoGroupGemm):
     supported_platforms_list = _ROCM
 

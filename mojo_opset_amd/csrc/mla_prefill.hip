@@ -119,7 +119,7 @@ template <> struct mpf_mfma<f16_t> {
 
 constexpr float MPF_LAZY_LOG2 = 8.f;
 constexpr int MPF_KEYS = 64;
-constexpr int MPF_QPB = 128;
+constexpr int MPF_QPB = 128;                          // query positions per 4-wave workgroup (8 waves: 256)
 constexpr int MPF_KN_BYTES = MPF_KEYS * 256;          // K_nope image
 constexpr int MPF_KP_BYTES = MPF_KEYS * 128;          // K_pe image
 constexpr int MPF_V_BYTES = MPF_KEYS * 256;           // V image
@@ -127,8 +127,17 @@ constexpr int MPF_BUF_BYTES = MPF_KN_BYTES + MPF_KP_BYTES + MPF_V_BYTES;   // 40
 constexpr int MPF_LDS = 2 * MPF_BUF_BYTES;            // 80 KiB: two workgroups per CU
 constexpr int MPF_ZERO_TOKENS = 32;
 
-template <typename T, int DKN /* nope / 32 */, int DKR /* rope / 32 */, int DVV /* vd / 32 */>
-__global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
+// NW = waves per workgroup, 32 rows each (QPB = 32 NW query positions).  Waves skip the key tiles none of their rows sees and
+// take the masked form only on the tiles their OWN rows need it (the causal band of a block is QPB / 64 tiles wide).
+// Round 4: NW = 8 (256 rows, one workgroup per CU, half the K/V bytes through the LDS-DMA — every head has its own K/V, so a
+// 40 KiB tile feeds only one workgroup's rows) was built on the hypothesis that the launch is bound by that stream (2.9 GB
+// for 4 x 512 tokens against 2048 cached ones).  Parity-green and 10-20 % SLOWER (4 x 512: 203 -> 222 us, + 2048 cached: 930 ->
+// 1120 us, profiles/r4_mla_prefill_waves_ab.json): the stream is served by L2 (the query blocks of a (sequence, head) are
+// resident together on one XCD), and eight waves behind one barrier align their LDS reads as the phase-alternating GQA kernel
+// did (DESIGN Appendix A 10a).  Only NW = 4 is instantiated.
+template <typename T, int DKN /* nope / 32 */, int DKR /* rope / 32 */, int DVV /* vd / 32 */, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void mla_prefill_kernel(MlaPfArgs a) {
+  constexpr int QPB = 32 * NW, NT = 64 * NW;
   typedef typename mpf_mfma<T>::frag frag;
   constexpr int NOPE = DKN * 32, ROPE = DKR * 32, VD = DVV * 32;
   constexpr int QK = NOPE + ROPE, KVW = NOPE + VD;     // query row width, decompressed row width per head
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
     V8 zv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) zv[e] = static_cast<T>(0.f);
-    for (int64_t i = t0 * row_elems + threadIdx.x * 8; i < t1 * row_elems; i += 256 * 8)
+    for (int64_t i = t0 * row_elems + threadIdx.x * 8; i < t1 * row_elems; i += NT * 8)
       *reinterpret_cast<V8*>(static_cast<T*>(a.out) + i) = zv;
     return;
   }
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   const int kv_start = mla_clamped_start(a.cu_kv ? a.cu_kv : a.cu_q, b, a.per_seq);   // row in the (slice-relative) flat buffers
   int kv_len = min(a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len, a.per_seq);
   if (kv_len > a.capacity_rows - kv_start) kv_len = a.capacity_rows - kv_start;
-  if (qb * MPF_QPB >= q_len) return;
+  if (qb * QPB >= q_len) return;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -186,15 +195,15 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
     V8 zv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) zv[e] = static_cast<T>(0.f);
-    const int n_pos = min(q_len - qb * MPF_QPB, MPF_QPB);
-    for (int i = threadIdx.x; i < n_pos * (VD / 8); i += 256) {
-      const int c = i % (VD / 8), pos = qb * MPF_QPB + i / (VD / 8);
+    const int n_pos = min(q_len - qb * QPB, QPB);
+    for (int i = threadIdx.x; i < n_pos * (VD / 8); i += NT) {
+      const int c = i % (VD / 8), pos = qb * QPB + i / (VD / 8);
       *reinterpret_cast<V8*>(static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + pos) * a.heads + head) * VD + c * 8) = zv;
     }
     return;
   }
   const int offset = kv_len - q_len;                     // query i sees keys 0 .. offset + i
-  const int pos_hi = min(q_len, (qb + 1) * MPF_QPB) - 1;
+  const int pos_hi = min(q_len, (qb + 1) * QPB) - 1;
   int kv_hi = min(kv_len, offset + pos_hi + 1);          // keys [0, kv_hi) are visible to some row of this block
   if (kv_hi < 1) kv_hi = 1;
   const int n_kb = (kv_hi + MPF_KEYS - 1) / MPF_KEYS;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   frag qf[2][DK];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    int pos = qb * MPF_QPB + wave * 32 + qt * 16 + l15;
+    int pos = qb * QPB + wave * 32 + qt * 16 + l15;
     row_pos[qt] = pos;
     if (pos >= q_len) pos = q_len - 1;                   // clamp: computed, never stored
     const T* qp = static_cast<const T*>(a.q) + (static_cast<int64_t>(q_start + pos) * a.heads + head) * QK;
@@ -212,17 +221,18 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
     for (int ks = 0; ks < DK; ++ks) qf[qt][ks] = *reinterpret_cast<const frag*>(qp + ks * 32 + grp * 8);
   }
 
-  // ---- staging: wave w fills keys [16w, 16w + 16) of a tile ----------------------------------------------------------
+  // ---- staging: wave w fills keys [KPW w, KPW w + KPW) of a tile, KPW = 64 / NW ------------------------------------------
   //   K_nope / V: 4 LDS-DMA instructions each (4 keys x 256 B; lane l: key l / 16, LDS chunk position l % 16)
   //   K_pe      : 2 instructions (8 keys x 128 B; lane l: key l / 8, position l % 8)
   const char* kv_base = reinterpret_cast<const char*>(static_cast<const T*>(a.kv) + (static_cast<int64_t>(kv_start) * a.heads + head) * KVW);
   const char* pe_base = reinterpret_cast<const char*>(static_cast<const T*>(a.kpe) + static_cast<int64_t>(kv_start) * ROPE);
   const int64_t kv_row_bytes = static_cast<int64_t>(a.heads) * KVW * sizeof(T);
+  constexpr int KPW = MPF_KEYS / NW;
   auto stage = [&](int kb, int buf) {
     lds_m* base = smem + buf * MPF_BUF_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kl = wave * 16 + i * 4 + (lane >> 4);
+    for (int i = 0; i < KPW / 4; ++i) {
+      const int kl = wave * KPW + i * 4 + (lane >> 4);
       int key = kb * MPF_KEYS + kl;
       if (key >= kv_hi) key = kv_hi - 1;                 // rows past the end: re-read a valid key, masked later
       const int cp = lane & 15;
@@ -231,21 +241,21 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
       if (ck >= NOPE / 8) ck = NOPE / 8 - 1;
       if (cv >= VD / 8) cv = VD / 8 - 1;
       const char* row = kv_base + static_cast<int64_t>(key) * kv_row_bytes;
-      lds_m* dk = base + (wave * 16 + i * 4) * 256;
-      lds_m* dv = base + MPF_KN_BYTES + MPF_KP_BYTES + (wave * 16 + i * 4) * 256;
+      lds_m* dk = base + (wave * KPW + i * 4) * 256;
+      lds_m* dv = base + MPF_KN_BYTES + MPF_KP_BYTES + (wave * KPW + i * 4) * 256;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + ck * 16),
                                        (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + NOPE * sizeof(T) + cv * 16),
                                        (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kl = wave * 16 + i * 8 + (lane >> 3);
+    for (int i = 0; i < KPW / 8; ++i) {
+      const int kl = wave * KPW + i * 8 + (lane >> 3);
       int key = kb * MPF_KEYS + kl;
       if (key >= kv_hi) key = kv_hi - 1;
       int cr = (lane & 7) ^ ((kl >> 1) & 7);
       if (cr >= ROPE / 8) cr = ROPE / 8 - 1;
-      lds_m* dp = base + MPF_KN_BYTES + (wave * 16 + i * 8) * 128;
+      lds_m* dp = base + MPF_KN_BYTES + (wave * KPW + i * 8) * 128;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pe_base + static_cast<int64_t>(key) * (ROPE * sizeof(T)) + cr * 16),
                                        (__attribute__((address_space(3))) void*)dp, 16, 0, 0);
     }
@@ -264,7 +274,11 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   const float lazy_raw = MPF_LAZY_LOG2 / a.scale_log2;
   const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
   const int tq = l15 >> 2, tp = l15 & 3;
-  const int n_full = min(kv_len, offset + qb * MPF_QPB + 1) / MPF_KEYS;      // key blocks every row sees completely
+  // per wave: key blocks every row of the wave sees completely, and one past the last block any of its rows sees
+  // (rows past the sequence's end are clamped to its last position: computed, never stored)
+  const int wpos_lo = min(qb * QPB + wave * 32, q_len - 1), wpos_hi = min(qb * QPB + wave * 32 + 31, q_len - 1);
+  const int n_full = min(kv_len, offset + wpos_lo + 1) / MPF_KEYS;
+  const int n_mine = min(n_kb, (max(min(kv_len, offset + wpos_hi + 1), 1) + MPF_KEYS - 1) / MPF_KEYS);
 
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,7 +444,12 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   };
   int kb_i = 0;
   for (; kb_i < n_full; ++kb_i) key_block(std::false_type{}, kb_i);
-  for (; kb_i < n_kb; ++kb_i) key_block(std::true_type{}, kb_i);
+  for (; kb_i < n_mine; ++kb_i) key_block(std::true_type{}, kb_i);
+  for (; kb_i < n_kb; ++kb_i) {                           // tiles only later waves need: keep staging and the barrier cadence
+    if (kb_i + 1 < n_kb) stage(kb_i + 1, (kb_i & 1) ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   // ---- finish: row sums over the 4 lane groups (+ the sink's share of the denominator), normalise, store whole rows ----
   constexpr int OROW = 272;                       // (68 dwords: the 16 rows of a write land 4 banks apart; 288 left rows l and l + 8 on one bank pair)
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
     for (int i = 0; i < (32 + RPI - 1) / RPI; ++i) {
       const int row = i * RPI + sub;
       if (sub >= RPI || row >= 32) continue;
-      const int pos = qb * MPF_QPB + wave * 32 + row;
+      const int pos = qb * QPB + wave * 32 + row;
       if (pos >= q_len) continue;
       const V8 v = *reinterpret_cast<const __attribute__((address_space(3))) V8*>(stage_o + row * OROW + ch * 16);
       *reinterpret_cast<V8*>(static_cast<T*>(a.out) + (static_cast<int64_t>(q_start + pos) * a.heads + head) * VD + ch * 8) = v;
@@ -467,15 +486,15 @@ __global__ __launch_bounds__(256, 2) void mla_prefill_kernel(MlaPfArgs a) {
   }
 }
 
-template <typename T, int DKN, int DKR, int DVV>
+template <typename T, int DKN, int DKR, int DVV, int NW>
 static int launch_mla_pf(const MlaPfArgs& a, hipStream_t s) {
-  auto* fn = mla_prefill_kernel<T, DKN, DKR, DVV>;
+  auto* fn = mla_prefill_kernel<T, DKN, DKR, DVV, NW>;
   static std::atomic<uint64_t> attr_set{0};
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, MPF_LDS);
   const int64_t n_zero = a.zero_tail ? ceil_div(a.total_tokens, static_cast<int64_t>(MPF_ZERO_TOKENS)) : 0;
   const int64_t blocks = static_cast<int64_t>(a.n_slots) * 8 * ceil_div(static_cast<int64_t>(a.heads_here) * a.batch, 8) + n_zero;
   MOJO_REQUIRE(blocks < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "mla_prefill: grid limit");
-  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(256), MPF_LDS, s, a);
+  hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), MPF_LDS, s, a);
   MOJO_CHECK_LAUNCH("mla_prefill");
   return MOJO_OK;
 }
@@ -559,15 +578,16 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   a.capacity_rows = static_cast<int>(capacity_rows);
   a.per_seq = static_cast<int>(max_tokens_per_seq > 0 && max_tokens_per_seq < (int64_t{1} << 30) ? max_tokens_per_seq : (int64_t{1} << 30));
   const int64_t mq = (max_q_len > 0 && max_q_len < total_tokens) ? max_q_len : total_tokens;
-  a.n_qb = static_cast<int>(ceil_div(mq, MPF_QPB));
+  constexpr int nw = 4;                                // (8 waves = 256 rows per workgroup: measured 10-20 % slower, see the kernel's header)
+  a.n_qb = static_cast<int>(ceil_div(mq, static_cast<int64_t>(32 * nw)));
   { const char* e = getenv("MOJO_HIP_MLA_PREFILL_ODD_SLOTS"); a.n_slots = (e && e[0] == '0') ? a.n_qb : (a.n_qb | 1); }
   a.total_tokens = total_tokens;
   a.round_scaled = round_scaled_scores ? 1 : 0;
   a.pre_scale = softmax_scale;
   a.scale_log2 = (round_scaled_scores ? 1.0f : softmax_scale) * 1.4426950408889634f;
   a.zero_tail = zero_padding_rows ? 1 : 0;
-#define MPF_LAUNCH(T)                                                                  \
-  (nope == 128 ? launch_mla_pf<T, 4, 2, 4>(a, s) : nope == 64 ? launch_mla_pf<T, 2, 1, 2>(a, s) : launch_mla_pf<T, 3, 1, 4>(a, s))
-  return dtype == MOJO_BF16 ? MPF_LAUNCH(bf16_t) : MPF_LAUNCH(f16_t);
+#define MPF_LAUNCH(T, NW_)                                                             \
+  (nope == 128 ? launch_mla_pf<T, 4, 2, 4, NW_>(a, s) : nope == 64 ? launch_mla_pf<T, 2, 1, 2, NW_>(a, s) : launch_mla_pf<T, 3, 1, 4, NW_>(a, s))
+  return dtype == MOJO_BF16 ? MPF_LAUNCH(bf16_t, nw) : MPF_LAUNCH(f16_t, nw);
 #undef MPF_LAUNCH
 }

@@ -253,3 +253,56 @@ def test_gemm_residual_rmsnorm_fused_equals_the_separate_calls_and_the_oracle(dt
         ref.weight.data.copy_(nw)
         ref_n = ref(a_ref)
     torch.testing.assert_close(to_cpu(normed).float(), ref_n.float(), atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("b,k,hq,hkv,d,page,bias", [(64, 4096, 32, 8, 128, 16, False), (5, 1024, 8, 2, 64, 8, True), (1, 512, 4, 4, 128, 16, True),
+                                                   (33, 256, 16, 1, 32, 4, False),
+                                                   (64, 192, 4, 2, 64, 16, False)])          # K % 128: the projection takes the tile kernel
+def test_qkv_rope_store_fused_equals_the_separate_calls_and_the_oracle(dtype, b, k, hq, hkv, d, page, bias):
+    """`mojo_hip_qkv_rope_store` against dense_gemm -> HIPApplyRoPE -> HIPStorePagedKVCache (same bits, caches included: rows
+    with a negative context length or a missing page stay untouched) and against the oracle's chain."""
+    from hip_utils import hip_cls, torch_cls
+    from mojo_opset_amd.backends.hip.operators.gemm import qkv_rope_store
+    g = torch.Generator().manual_seed(b * 7 + d)
+    n = (hq + 2 * hkv) * d
+    x = torch.randn(b, k, generator=g).to(dtype)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype)
+    bs = torch.randn(n, generator=g).to(dtype) if bias else None
+    cos, sin = torch.randn(b, d, generator=g), torch.randn(b, d, generator=g)
+    pages_per_seq = 6
+    n_blocks = b * pages_per_seq + 3
+    table = torch.randperm(n_blocks, generator=g)[: b * pages_per_seq].view(b, pages_per_seq).to(torch.int32)
+    ctx = torch.randint(0, pages_per_seq * page, (b,), generator=g).to(torch.int32)
+    if b >= 5:
+        ctx[1] = -1                                           # a padded row: nothing stored
+        table[2, int(ctx[2]) // page] = -1                    # a hole in the table: nothing stored
+        ctx[3] = pages_per_seq * page + 2                     # past the table: nothing stored
+    kc0 = torch.randn(n_blocks, hkv, page, d, generator=g).to(dtype)
+    vc0 = torch.randn(n_blocks, hkv, page, d, generator=g).to(dtype)
+    dev = lambda t: None if t is None else t.to(DEV)
+    kc, vc = dev(kc0).clone(), dev(vc0).clone()
+    q_got = qkv_rope_store(dev(x), dev(w), dev(bs), dev(cos), dev(sin), kc, vc, dev(table), dev(ctx), hq, hkv)
+    # the separate calls
+    qkv = dense_gemm(dev(x), dev(w), dev(bs), False)
+    q = qkv[:, : hq * d].reshape(b, hq, d)
+    kk = qkv[:, hq * d: (hq + hkv) * d].reshape(b, hkv, d)
+    v = qkv[:, (hq + hkv) * d:].reshape(b, hkv, d).contiguous()
+    q_r, k_r = hip_cls("MojoApplyRoPE")()(q.unsqueeze(0), kk.unsqueeze(0), dev(cos), dev(sin), head_first=False)
+    kc2, vc2 = dev(kc0).clone(), dev(vc0).clone()
+    hip_cls("MojoStorePagedKVCache")()(k_r.squeeze(0).contiguous(), v, kc2, vc2, dev(table), None, dev(ctx))
+    assert torch.equal(q_got, q_r.squeeze(0))
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    assert not torch.equal(kc, dev(kc0))                      # (something was stored)
+    # the oracle's chain
+    qkv_ref = (x.float() @ w.float().t()).to(dtype)
+    if bias:
+        qkv_ref = (qkv_ref.float() + bs.float()).to(dtype)
+    q_ref, k_ref = torch_cls("MojoApplyRoPE")()(qkv_ref[:, : hq * d].reshape(1, b, hq, d), qkv_ref[:, hq * d: (hq + hkv) * d].reshape(1, b, hkv, d),
+                                                cos, sin, head_first=False)
+    torch.testing.assert_close(to_cpu(q_got).float(), q_ref.squeeze(0).float(), atol=3e-2, rtol=2e-2)
+    live = [i for i in range(b) if 0 <= int(ctx[i]) < pages_per_seq * page and int(table[i, int(ctx[i]) // page]) >= 0]
+    for i in live[:8]:
+        blk, slot = int(table[i, int(ctx[i]) // page]), int(ctx[i]) % page
+        torch.testing.assert_close(to_cpu(kc[blk, :, slot]).float(), k_ref[0, i].float(), atol=3e-2, rtol=2e-2)
+        torch.testing.assert_close(to_cpu(vc[blk, :, slot]).float(), qkv_ref[i, (hq + hkv) * d:].reshape(hkv, d).float(), atol=3e-2, rtol=2e-2)
