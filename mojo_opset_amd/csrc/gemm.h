@@ -43,6 +43,8 @@ struct GemmArgs {
   int splitk = 1;
   void* slab = nullptr;
   int slab_rows = 0;
+  int stagger_ticks = 0;     // 256x256 kernel: the first `stagger_blocks` workgroups start (block / 8 % 8) x this many 10-ns ticks late,
+  int stagger_blocks = 0;    // so that the CUs do not write their tiles out in one burst per round (short-K products; gemm256_core.h)
   int defer_finalize = 0;    // split-K: leave the slabs to the caller's own finalize (launch_gemm_splitk_resnorm)
   int sk_slot = -1;          // decode-sized kernel: >= 0 = combine the K slices inside the launch (splitk_combine.h), ticket slot
 };

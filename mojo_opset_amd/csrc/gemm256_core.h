@@ -194,6 +194,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   const int total = tiles_mn * a.splitk;
   int bid = blockIdx.x;
   if (bid >= total) return;
+  if constexpr (!PERSIST) {
+    // Start stagger (short-K products with many rounds; chosen in gemm256_launch): every tile of such a launch takes the same
+    // time, so the workgroups of a round finish together and the chip alternates between a phase where every CU multiplies
+    // and one where every CU writes its 128 KiB tile.  The first round starts in eight phases; later workgroups inherit the
+    // phase of the slot they take over.  (Whether the gain comes from the write bursts or from the power headroom the idle
+    // phases leave is not settled: the product alone gains 12 %, inside the MLA prefill operator the GEMM gains 2 % and the
+    // attention kernel behind it 5 %.)
+    if (a.stagger_ticks > 0 && bid < a.stagger_blocks) {
+      const unsigned phase = (static_cast<unsigned>(bid) >> 3) & 7u;
+      if (phase) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long d = static_cast<unsigned long long>(phase) * static_cast<unsigned>(a.stagger_ticks);
+        while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(16);
+      }
+    }
+  }
   const int hoff = a.glu ? a.N / 2 : 128;              // column distance between the two W half-tiles
   const int nkt_all = a.K / BK;
   const int lane = threadIdx.x & 63;
@@ -751,9 +767,26 @@ inline int device_cu_count() {
 }
 
 template <typename P, typename Epi, bool ALLOW_PERSISTENT = false>
-inline int gemm256_launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
+inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total, hipStream_t s) {
+  GemmArgs a = a_in;
   const int64_t n_tiles = a.glu ? (a.N / 2) / 128 : ceil_div(a.N, BN);
   const int64_t blocks = (ceil_div(m_total, BM) + a.G) * n_tiles * a.splitk;   // upper bound; surplus blocks exit
+  // Start stagger (see the kernel): ONE-group products of at most 16 K-tiles with at least eight rounds of workgroups — the
+  // MLA decompression GEMM against a long cache.  Measured on one MI355X (10-ns ticks per phase 0 / 60 / 120 / 180 / 240 / 320):
+  //  * the product alone, back to back (scripts/probes/gemm_stagger_ab.py, profiles/r4_gemm_stagger_ab.txt): [2048, 512] x
+  //    [32768, 512]^T 768 / 821 / 858 / 867 / 802 / 707 TF, M = 10240: 757 / 769 / 766-794 / 849-865 / 850-881 / 805-815, K = 1024:
+  //    1048 / 1089 / 1108 / 1088 / 1060 / 1012, K = 4096: 1414 / 1412 / 1394 / 1382 (long-K rounds drift apart by themselves);
+  //  * inside MojoPagedPrefillMLA, where the product alternates with the attention kernel (mla_prefill_stagger_ab.py, A/B in
+  //    one process; kernel traces by scripts/probes/prof_stagger.sh): 4 x 512 + 2048 cached 929 -> 891 us eager, 938 -> 872
+  //    under graph replay (GEMM 378 -> 370 us, attention 526 -> 500 us); 4 x 512 without a cache (4 rounds) 203 -> 202 us with
+  //    the GEMM itself 88 -> 93 us; grouped products with a tile per group (the absorbed route's projections) 104 -> 112 us.
+  //    Hence the restriction to one group and >= 8 rounds.  MOJO_HIP_GEMM_STAGGER=<ticks> forces (0 = off; read per call).
+  if (const char* e = getenv("MOJO_HIP_GEMM_STAGGER")) {
+    a.stagger_ticks = atoi(e);
+  } else if (a.G == 1 && a.K / (KT_BYTES / P::EB) <= 16 && blocks >= 8 * static_cast<int64_t>(device_cu_count())) {
+    a.stagger_ticks = 150;
+  }
+  a.stagger_blocks = device_cu_count();
   MOJO_REQUIRE(blocks < (1LL << 31), MOJO_EUNSUPPORTED, "gemm: grid too large");
   if constexpr (Epi::kRowStaged && ALLOW_PERSISTENT) {
     // persistent form (one workgroup per CU, next tile requested before this tile's epilogue): row-staged 16-bit output,

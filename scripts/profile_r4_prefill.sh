@@ -9,7 +9,7 @@ one() {  # tag, W64 switch, case substring
   rocprofv3 --kernel-trace --pmc $A --output-format csv -d $P/$1_a -- python3 benchmarks/one.py bench_prefill > $P/$1_a.log 2>&1; echo $1 a rc=$?
   rocprofv3 --kernel-trace --pmc $B --output-format csv -d $P/$1_b -- python3 benchmarks/one.py bench_prefill > $P/$1_b.log 2>&1; echo $1 b rc=$?
 }
-for c in ${CASES:-"16k:1x16384 4x2048:4x2048_nocache ragged:16_ragged cached:4x2048_cached2048"}; do
+for c in ${CASES:-16k:1x16384 4x2048:4x2048_nocache ragged:16_ragged cached:4x2048_cached2048}; do
   tag=${c%%:*}; sub=${c##*:}
   for w in ${ARMS:-0 1}; do one pf_${tag}_w$w $w $sub; done
 done
