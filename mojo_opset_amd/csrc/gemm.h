@@ -43,6 +43,8 @@ struct GemmArgs {
   int splitk = 1;
   void* slab = nullptr;
   int slab_rows = 0;
+  int a_k_wrap = 0;          // 256x256 kernel: A's K-tile index wraps after this many K-tiles (0 = never): the MoE router multiplies the SAME
+                             // activations by [w_hi; w_lo] stacked along K in one launch.  No K slice may straddle a multiple of it.
   int stagger_ticks = 0;     // 256x256 kernel: the first `stagger_blocks` workgroups start (block / 8 % 8) x this many 10-ns ticks late,
   int stagger_blocks = 0;    // so that the CUs do not write their tiles out in one burst per round (short-K products; gemm256_core.h)
   int defer_finalize = 0;    // split-K: leave the slabs to the caller's own finalize (launch_gemm_splitk_resnorm)

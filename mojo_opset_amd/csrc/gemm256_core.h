@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
       for (int h = 0; h < 2; ++h) {
         int m = m0 + h * 128 + wave * 16 + row;
         if (m >= m_end) m = m_end - 1;                 // rows past the group: re-read a valid row, never stored
-        srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(kt0) * KT_BYTES;
+        srcA[h] = A + (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda) * EB + chunk * 16 + static_cast<int64_t>(a.a_k_wrap ? kt0 % a.a_k_wrap : kt0) * KT_BYTES;
       }
     }
     if constexpr (!W_NMAJOR) {

@@ -886,19 +886,26 @@ static int gating_mfma(const void* x, const float* w, int32_t* idx, float* gate,
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(moe_gate_split_kernel<T>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, w, hi, lo, hidden, experts, e_pad);
   MOJO_CHECK_LAUNCH("moe_gating(split)");
-  for (int pass = 0; pass < 2; ++pass) {
+  // ONE product over K' = 2 * hidden: the activations against [w_hi; w_lo] stacked along K (hi and lo are adjacent in the
+  // workspace), A's K index wrapping at `hidden` (GemmArgs::a_k_wrap).  With an even slice count no K slice straddles the
+  // wrap.  (Round 4: the two products used to be two launches with sk slabs each — 2 x 67 MB of fp32 slabs written and read
+  // again at 8192 tokens x 256 experts, more than the 30 GFLOP of either pass cost; one launch writes half of them and pays
+  // the per-tile prologue / epilogue once.)  The slices still sum hi parts first, then lo parts, in index order.
+  const int sk2 = sk < 2 ? 2 : ((sk + 1) & ~1);
+  {
     GemmArgs a;
-    a.A = x; a.W = pass ? lo : hi; a.bias = nullptr;
-    a.C = logits + static_cast<int64_t>(pass) * sk * slab;
+    a.A = x; a.W = hi; a.bias = nullptr;
+    a.C = logits;
     a.lda = hidden; a.ldc = e_pad; a.w_group = 0; a.w_k = e_pad; a.w_n = 1;          // [K, N] weights
-    a.K = hidden; a.N = e_pad; a.G = 1;
+    a.K = 2 * hidden; a.N = e_pad; a.G = 1;
+    a.a_k_wrap = hidden / 64;
     a.uniform_rows = static_cast<int>(tokens);
-    if (sk > 1) { a.splitk = sk; a.slab = a.C; a.slab_rows = static_cast<int>(tokens); }
+    a.splitk = sk2; a.slab = a.C; a.slab_rows = static_cast<int>(tokens);
     const int rc = launch_gemm_mfma256_f32out(a, dtype, 0, tokens, s);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(moe_gate_select_kernel, dim3(static_cast<unsigned>(ceil_div(tokens, 4))), dim3(256), 0, s, logits, slab,
-                     2 * sk, e_pad, idx, gate, tokens, experts, top_k);
+                     sk2, e_pad, idx, gate, tokens, experts, top_k);
   MOJO_CHECK_LAUNCH("moe_gating(select)");
   return MOJO_OK;
 }
