@@ -258,6 +258,80 @@ def test_decoder_layer_as_one_graph_matches_the_oracle_chain():
         assert int(changed.any(-1).sum()) <= b
 
 
+def test_decoder_layer_with_the_decode_fusions_replays_bit_identical_to_the_separate_calls():
+    """The layer of the test above through `qkv_rope_store`, `dense_gemm_residual_rmsnorm` (output projection) and
+    `dense_gemm_swiglu`, captured as ONE graph and replayed on new inputs: the same bits as the separate operators run
+    eagerly on the same inputs — outputs, residual and the K / V caches (the parity of those against the oracle is the test
+    above).  Shapes chosen so that the projections take the K split (slabs summed by the fused finalizes)."""
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm, dense_gemm_residual_rmsnorm, dense_gemm_swiglu, qkv_rope_store
+
+    torch.manual_seed(11)
+    # (inter: more than 256 column tiles, so the separate gate|up projection runs unsplit like the fused one, which never cuts K)
+    b, hq, hkv, d, page, hidden, inter, max_len = 16, 8, 2, 128, 16, 2048, 8448, 256
+    dt = torch.bfloat16
+    pages = max_len // page
+    n_blocks = b * pages + 3
+    table = torch.randperm(n_blocks, dtype=torch.int32)[: b * pages].view(b, pages).to(DEV)
+    w = {"qkv": torch.randn((hq + 2 * hkv) * d, hidden) * hidden ** -0.5, "o": torch.randn(hidden, hq * d) * (hq * d) ** -0.5,
+         "gu": torch.randn(2 * inter, hidden) * hidden ** -0.5, "dn": torch.randn(hidden, inter) * inter ** -0.5}
+    w = {k: v.to(dt).to(DEV) for k, v in w.items()}
+    n1 = hip_cls("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=DEV)
+    n2 = hip_cls("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=DEV)
+    with torch.no_grad():
+        n1.weight.copy_(1 + 0.1 * torch.randn(hidden))
+        n2.weight.copy_(1 + 0.1 * torch.randn(hidden))
+    rope, store, attn, act = hip_cls("MojoApplyRoPE")(), hip_cls("MojoStorePagedKVCache")(), hip_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout="AABB"), hip_cls("MojoSwiGLU")()
+    k_cache0 = torch.randn(n_blocks, hkv, page, d).to(dt).to(DEV)
+    v_cache0 = torch.randn(n_blocks, hkv, page, d).to(dt).to(DEV)
+
+    def separate(x, resid, cos, sin, k_cache, v_cache, ctx, total):
+        h, r1 = n1(x, resid)
+        qkv = dense_gemm(h, w["qkv"], None, False)
+        q = qkv[:, : hq * d].reshape(b, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].reshape(b, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].reshape(b, hkv, d).contiguous()
+        q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
+        store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, None, ctx)
+        o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, total, table)
+        h2, r2 = n2(dense_gemm(o.reshape(b, hq * d), w["o"], None, False), r1)
+        gu = dense_gemm(h2, w["gu"], None, False)
+        return dense_gemm(act(gu[:, :inter], gu[:, inter:]), w["dn"], None, False), r2
+
+    def fused(x, resid, cos, sin, k_cache, v_cache, ctx, total):
+        h, r1 = n1(x, resid)
+        q_r = qkv_rope_store(h, w["qkv"], None, cos, sin, k_cache, v_cache, table, ctx, hq, hkv)
+        o = attn(q_r, k_cache, v_cache, total, table)
+        h2, r2 = dense_gemm_residual_rmsnorm(o.reshape(b, hq * d), w["o"], None, r1, n2.weight, 1e-5)
+        return dense_gemm(dense_gemm_swiglu(h2, w["gu"]), w["dn"], None, False), r2
+
+    x = torch.zeros(b, hidden, dtype=dt, device=DEV)
+    resid = torch.zeros_like(x)
+    cos, sin = torch.zeros(b, d, device=DEV), torch.zeros(b, d, device=DEV)
+    ctx = torch.zeros(b, dtype=torch.int32, device=DEV)
+    total = torch.ones(b, dtype=torch.int32, device=DEV)
+    k_cache, v_cache = k_cache0.clone(), v_cache0.clone()
+    graph, static_out = _capture(lambda: fused(x, resid, cos, sin, k_cache, v_cache, ctx, total))
+    for i in range(3):
+        g = torch.Generator().manual_seed(70 + i)
+        ang = torch.rand(b, d, generator=g) * 6.28
+        lens = torch.randint(1, max_len - 1, (b,), generator=g).to(torch.int32)
+        if i == 1:
+            lens[3] = -1                                    # a padded row: its K / V are not stored (and its output is don't-care)
+        for dst, src in ((x, torch.randn(b, hidden, generator=g)), (resid, torch.randn(b, hidden, generator=g)), (cos, torch.cos(ang)),
+                         (sin, torch.sin(ang)), (ctx, lens), (total, lens.clamp(min=0) + 1)):
+            dst.copy_(src)
+        k_cache.copy_(k_cache0)
+        v_cache.copy_(v_cache0)
+        graph.replay()
+        torch.cuda.synchronize()
+        got_out, got_res = static_out[0].clone(), static_out[1].clone()
+        kc, vc = k_cache0.clone(), v_cache0.clone()
+        want_out, want_res = separate(x, resid, cos, sin, kc, vc, ctx, total)
+        live = (lens >= 0).to(DEV)
+        assert torch.equal(k_cache, kc) and torch.equal(v_cache, vc), i
+        assert torch.equal(got_res[live], want_res[live]) and torch.equal(got_out[live], want_out[live]), i
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Graph-captured PREFILL (the reference's test_paged_prefill_gqa_with_graph,
 # mojo_opset/tests/accuracy/operators/test_attention.py:584-760): bucket-padded static buffers sized by
