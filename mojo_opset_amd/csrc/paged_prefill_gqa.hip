@@ -150,10 +150,32 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   // full the blocks behind it wait although other engines are empty (measured on 16 ragged sequences: 272 workgroups
   // resident for the first 25 us of a 150 us launch, 91 CUs idle).  The sequence coordinate is therefore rotated by
   // one per query-block level, so a sequence's blocks walk over the engines.
-  const int kvh = rem % a.hkv, b = (rem / a.hkv + a.skew * (wg / inner)) % a.batch;
-  const int q_start = a.cu_q[b];
-  const int q_len = a.cu_q[b + 1] - q_start;
-  const int kv_len = a.cu_kv ? a.cu_kv[b + 1] - a.cu_kv[b] : q_len;
+  const int kvh = rem % a.hkv, b = __builtin_amdgcn_readfirstlane((rem / a.hkv + a.skew * (wg / inner)) % a.batch);
+  // The prologue is a chain of dependent memory round trips (1.5-2 us each on a busy chip) in front of a workgroup that may
+  // own only a handful of tiles.  Round 4: it is TWO of them — {sequence bounds, page-id window} then {Q fragments, first
+  // tile} — where it was three or four (bounds, cached-length bounds, {Q, page ids}, first tile): the bounds are scalar loads
+  // issued together, and the page-id window depends on nothing but the sequence index, so its loads are requested in front of
+  // the wait for the bounds.
+  const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
+  int ids[PF_TABLE / 256];
+#pragma unroll
+  for (int j = 0; j < PF_TABLE / 256; ++j) {
+    const int i = threadIdx.x + j * 256;
+    ids[j] = i < a.max_pages ? __builtin_nontemporal_load(table + i) : -1;
+  }
+  // (asm scalar loads: left to hipcc the four bounds are vector loads, the cached-length pair behind a branch and a wait each)
+  const int32_t* pq = a.cu_q + b;
+  const int32_t* pk = (a.cu_kv ? a.cu_kv : a.cu_q) + b;
+  int q_start, q_end, kv_lo, kv_end;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(q_start) : "s"(pq) : "memory");
+  asm volatile("s_load_dword %0, %1, 0x4" : "=s"(q_end) : "s"(pq) : "memory");
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(kv_lo) : "s"(pk) : "memory");
+  asm volatile("s_load_dword %0, %1, 0x4" : "=s"(kv_end) : "s"(pk) : "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q_start), "+s"(q_end), "+s"(kv_lo), "+s"(kv_end) : : "memory");
+#pragma unroll
+  for (int j = 0; j < PF_TABLE / 256; ++j) asm volatile("" : "+v"(ids[j]));      // (the window's loads are requested up there, not where hipcc finds their first use)
+  const int q_len = q_end - q_start;
+  const int kv_len = a.cu_kv ? kv_end - kv_lo : q_len;
   // rows [pos0, pos1) of this sequence, the G heads of this kv-head, written as zeros
   auto zero_rows = [&](int pos0, int pos1) {
     typedef typename vec_of<T, 8>::type V8;
@@ -188,7 +210,6 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = lane >> 4, l15 = lane & 15;
-  const int32_t* table = a.tables + static_cast<int64_t>(b) * a.table_stride;
 
   const int pos_hi = min(q_len, (qb + 1) * QPB) - 1;    // last query position of this block
   int kv_hi = min(kv_len, offset + pos_hi + 1);          // keys [0, kv_hi) are visible to some row
@@ -213,8 +234,6 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
   const int kb_lo = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * ks / eff) : 0;
   const int n_kb = SPLIT ? static_cast<int>(static_cast<int64_t>(n_kb_all) * (ks + 1) / eff) : n_kb_all;
 
-  // The prologue is a chain of dependent memory round trips (1.5-2 us each on a busy chip) in front of a workgroup that
-  // may own only a handful of tiles, so it is kept to two: {Q fragments, page-id window} together, then the first tile.
   // ---- this wave's rows: two 16-row tiles; row -> (head g, query position) -------------------------------
   int row_pos[2], row_head[2];
   const T* qptr[2];
@@ -232,14 +251,7 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-    for (int ks = 0; ks < DK; ++ks) {
-      frag f = *reinterpret_cast<const frag*>(qptr[qt] + ks * 32 + grp * 8);
-      // q * scale * log2(e), rounded once to the storage type: the scores leave the MFMA chain in log2 units
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = static_cast<T>(static_cast<float>(f[e]) * a.scale_log2);
-      qf[qt][ks] = f;
-    }
-
+    for (int ks = 0; ks < DK; ++ks) qf[qt][ks] = *reinterpret_cast<const frag*>(qptr[qt] + ks * 32 + grp * 8);   // (scaled below, behind the first tile's requests)
 
   // A window of PF_TABLE page ids of this sequence lives in LDS (refilled when the key loop walks past it), so the
   // staging code never issues a dependent global load in front of its LDS-DMA — and never a FLAT load, which hipcc
@@ -257,22 +269,20 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
     int p1 = (kv_hi + a.page - 1) / a.page;
     int fn = 0x7fffffff;
     if (p1 > a.max_pages) { fn = a.max_pages; p1 = a.max_pages; }
+    // (`ids` were loaded at the top of the kernel.  The two barriers are raw s_barrier + LDS waits: __syncthreads() carries a
+    // vmcnt(0) that would wait for the Q fragments here, i.e. put the first tile's requests a round trip behind them.)
     int* s_fn = s_table + PF_TABLE;
     if (threadIdx.x == 0) *s_fn = 0x7fffffff;
-    int ids[PF_TABLE / 256];
-#pragma unroll
-    for (int j = 0; j < PF_TABLE / 256; ++j) {
-      const int i = threadIdx.x + j * 256;
-      ids[j] = i < a.max_pages ? table[i] : -1;
-    }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int j = 0; j < PF_TABLE / 256; ++j) {
       const int i = threadIdx.x + j * 256;
       s_table[i] = ids[j];
       if (ids[j] < 0 && i < p1) atomicMin(s_fn, i);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     const int wfn = *s_fn;
     if (wfn != 0x7fffffff) {
       fn = wfn;
@@ -413,6 +423,16 @@ __global__ __launch_bounds__(256, 2) void prefill_kernel(PrefillArgs a) {
 
   if (kb_lo < n_kb) stage(kb_lo, kb_lo & 1);
   int phys_next = a.fast_stage ? page_of_tile(kb_lo + 1) : 0;    // page id for the NEXT stage, loaded a tile ahead
+  // q * scale * log2(e), rounded once to the storage type: the scores leave the MFMA chain in log2 units
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+      frag f = qf[qt][ks];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = static_cast<T>(static_cast<float>(f[e]) * a.scale_log2);
+      qf[qt][ks] = f;
+    }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   PF_WG_MARK(0);
