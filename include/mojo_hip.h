@@ -417,6 +417,12 @@ int mojo_hip_peer_export(void* ptr, void* handle_out);
 int mojo_hip_peer_open(const void* handle, void** ptr_out);
 int mojo_hip_peer_close(void* ptr);
 int mojo_hip_peer_error(void* local_flags, int clear, int32_t* error_out);
+/*      Captured mode (HIP-graph replay).  Every exchange step below takes the call's epoch; epoch 0 means "the epoch
+ *      word of this rank's control area", which mojo_hip_peer_begin advances once per call after waiting (bounded) until
+ *      every peer has raised flag kind 2 ("finished reading this rank's data") for the previous call.  A captured call is
+ *      begin -> steps with epoch 0 on ONE data area (no parity halves) -> mojo_hip_peer_signal(kind 2, chunk 0, epoch 0).  */
+int mojo_hip_peer_begin(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
+                        mojo_stream_t stream);
 /* set-up check: `bytes` of a peer's buffer (opened mapping) copied to host memory by the runtime; synchronises */
 int mojo_hip_peer_peek(const void* peer_ptr, void* host_out, int64_t bytes);
 int mojo_hip_peer_signal(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mojo_hip_peer_close": (c_int, [_P]),
     "mojo_hip_peer_error": (c_int, [_P, c_int, _P]),
     "mojo_hip_peer_peek": (c_int, [_P, _P, _I]),
+    "mojo_hip_peer_begin": (c_int, [_P, _P, _I, _I, _P]),
     "mojo_hip_peer_signal": (c_int, [_P, _P, _I, _I, c_int, _I, ctypes.c_uint32, _P]),
     "mojo_hip_peer_reduce": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint32, _I, _I, _I, _P, _I, c_int, c_int, _P]),
     "mojo_hip_peer_gather": (c_int, [_P, _P, _I, _I, _I, ctypes.c_uint32, _I, _I, _I, _P, _I, c_int, _P]),

@@ -37,9 +37,15 @@ def _ptr_array(ptrs: List[int]):
 
 
 class PeerExchange:
-    """Symmetric data + control areas of one process group, and the per-call bookkeeping (epoch, parity)."""
+    """Symmetric data + control areas of one process group, and the per-call bookkeeping (epoch, parity).
 
-    def __init__(self, group, capacity_bytes: int):
+    ``captured=True`` builds the twin that HIP-graph capture uses: ONE data area (no parity halves), the epoch in the control
+    area on the device (csrc/peer_comm.hip, "captured mode"): its calls bake no host-side counter into a launch."""
+
+    def __init__(self, group, capacity_bytes: int, captured: bool = False):
+        self.captured = bool(captured)
+        self.halves = 1 if captured else 2
+        self.twin: Optional["PeerExchange"] = None
         self.group = group
         self.ws = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -50,7 +56,7 @@ class PeerExchange:
         self.ctrl_bytes = int(lib.mojo_hip_peer_ctrl_bytes())
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.max_chunks = int(lib.mojo_hip_peer_max_chunks())
-        total = 2 * self.capacity + 4096 + self.ctrl_bytes
+        total = self.halves * self.capacity + 4096 + self.ctrl_bytes
         self._local = ctypes.c_void_p()
         self._opened: List[ctypes.c_void_p] = []
         uncached = os.environ.get("MOJO_HIP_PEER_UNCACHED", "1") != "0"
@@ -98,10 +104,10 @@ class PeerExchange:
         if any(failures):
             self.close()
             raise RuntimeError(f"peer buffers: a rank could not open a peer's buffer (per rank: {failures})")
-        self._flag_off = 2 * self.capacity + 4096
+        self._flag_off = self.halves * self.capacity + 4096
         self._data = _ptr_array(self._bases)
         self._flags = _ptr_array([b + self._flag_off for b in self._bases])
-        self._alias = torch.as_tensor(_DeviceBytes(self._local.value, 2 * self.capacity), device=self.device)
+        self._alias = torch.as_tensor(_DeviceBytes(self._local.value, self.halves * self.capacity), device=self.device)
         self.epoch = 0
         self.side = torch.cuda.Stream(device=self.device)
         dist.barrier(group=group)               # every rank has opened every buffer (and cleared its own) before first use
@@ -134,9 +140,21 @@ class PeerExchange:
 
     # ---- per-call state -----------------------------------------------------------------------------------------
     def begin_call(self) -> Tuple[int, int]:
-        """(epoch, byte offset of this call's half of the data area).  Every rank makes the same sequence of calls."""
+        """(epoch, byte offset of this call's half of the data area).  Every rank makes the same sequence of calls.
+        Captured twin: enqueues the begin step (wait for the peers' "done reading" flags of the previous call, advance the
+        device-resident epoch) on the current stream and returns (0, 0): epoch 0 = "read it from the control area"."""
+        if self.captured:
+            L.check(L.load().mojo_hip_peer_begin(self._data, self._flags, self.ws, self.rank,
+                                                 ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "peer begin")
+            return 0, 0
         self.epoch += 1
         return self.epoch & 0xFFFFFFFF, (self.epoch & 1) * self.capacity
+
+    def end_call(self) -> None:
+        """Captured twin: tell every peer that this rank has finished reading their data of this call (flag kind 2), on the
+        current stream, which by now waits for the side stream's pulls.  Eager exchange: nothing (parity halves)."""
+        if self.captured:
+            self.signal(2, 0, 0, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
 
     def local_view(self, byte_offset: int, rows: int, cols: int, dtype: torch.dtype) -> torch.Tensor:
         n = rows * cols * torch.empty((), dtype=dtype).element_size()
@@ -169,6 +187,9 @@ class PeerExchange:
                                "affected outputs were filled with NaN")
 
     def close(self) -> None:
+        if self.twin is not None:
+            self.twin.close()
+            self.twin = None
         lib = L.load()
         for p in self._opened:
             lib.mojo_hip_peer_close(p)
@@ -178,21 +199,39 @@ class PeerExchange:
             self._local = ctypes.c_void_p()
 
 
+def captured_ready(group, need_bytes: int) -> bool:
+    """True when a captured twin of at least ``need_bytes`` exists for the group (it is built together with the eager
+    exchange, i.e. by any eager call of a direct operator at this size or larger: warm the step up before capturing it)."""
+    key = getattr(group, "group_name", None) or id(group)
+    with _LOCK:
+        return any(k == key and cap >= need_bytes and ex.twin is not None for (k, cap), ex in _CACHE.items())
+
+
 def get_exchange(group, need_bytes: int) -> PeerExchange:
     """The group's exchange with at least ``need_bytes`` per parity half; (re)built collectively when it must grow, so every
-    rank has to ask with the same sizes in the same order (they do: the ops are SPMD)."""
+    rank has to ask with the same sizes in the same order (they do: the ops are SPMD).  Under HIP-graph capture the
+    captured twin is returned; it cannot be built there (allocation, collectives): NotImplementedError when it is missing."""
     # (the group's name identifies it for its lifetime; `id()` of a collected group object could be reused)
     key = getattr(group, "group_name", None) or id(group)
+    capturing = torch.cuda.is_current_stream_capturing()
     with _LOCK:
         for (k, cap), ex in list(_CACHE.items()):
             if k == key and cap >= need_bytes:
-                return ex
+                if not capturing:
+                    return ex
+                if ex.twin is not None:
+                    return ex.twin
+        if capturing:
+            raise NotImplementedError("direct peer exchange under graph capture: no captured buffer of this size yet — run the "
+                                      "operator once eagerly at this size (or larger) before capturing")
         for (k, cap) in [kc for kc in _CACHE if kc[0] == key]:
             torch.cuda.synchronize()
             dist.barrier(group=group)           # nobody may still be reading the buffer that is about to go away
             _CACHE.pop((k, cap)).close()
         cap = max(int(need_bytes), int(os.environ.get("MOJO_HIP_PEER_MIN_BYTES", str(64 << 20))))
         ex = PeerExchange(group, cap)
+        if os.environ.get("MOJO_HIP_PEER_CAPTURE_TWIN", "1") != "0":
+            ex.twin = PeerExchange(group, cap, captured=True)       # the graph-capturable twin, built while building is allowed
         _CACHE[(key, ex.capacity)] = ex
         return ex
 
@@ -247,6 +286,7 @@ def gemm_all_reduce_direct(engine, x2: torch.Tensor, weight, bias, trans_weight:
         ex.reduce(c, epoch, off + r0 * n * es, r1 - r0, n, out[lo + r0: lo + r1], True, _side_ptr(ex))
         ex.gather(c, epoch, off, rows, n, out[lo:hi], _side_ptr(ex))
     main.wait_stream(ex.side)
+    ex.end_call()
     return out
 
 
@@ -276,6 +316,7 @@ def gemm_reduce_scatter_direct(engine, x2: torch.Tensor, weight, bias, trans_wei
         ex.side.wait_stream(main)
         ex.reduce(c, epoch, off + rank * rc * n * es, rc, n, out[lo:hi], False, _side_ptr(ex))
     main.wait_stream(ex.side)
+    ex.end_call()
     return out
 
 
@@ -309,4 +350,5 @@ def all_gather_gemm_direct(engine, x2: torch.Tensor, weight, bias, trans_weight:
     for (lo, hi), (buf, ev) in zip(chunks, stages):
         main.wait_event(ev)
         engine(buf, weight, bias, trans_weight, out=out, rows=buf.shape[0], c_map=(hi - lo, ml, lo))
+    ex.end_call()                                           # (main has waited for the last pull's event: every pull is done)
     return out

@@ -16,7 +16,9 @@ device.  So nothing is assumed:
     2. both paths are TIMED on the caller's own operands (one warm-up, ``TIMED`` calls each, HIP events, MAX over ranks) and
        the faster one is cached.
   Every rank takes the same decisions because every number that decides is reduced over the group first.
-* Under HIP-graph capture the choice is "rccl" (the direct exchange keeps its epoch on the host).
+* Under HIP-graph capture nothing can be tested or timed: the direct exchange is taken only where it was forced or chosen
+  BEFORE the capture and its graph-capturable twin exists (device-resident epoch, one data area guarded by "done reading"
+  flags: comm/peer.py, csrc/peer_comm.hip); otherwise "rccl".
 
 ``report()`` returns what was decided and why (bench.py puts it on the result line).
 """
@@ -150,13 +152,18 @@ def choose(group, op: str, payload_bytes: int, x: torch.Tensor, run_direct: Call
     with the same arguments in the same order (the operators are SPMD)."""
     if group is None or not x.is_cuda or dist.get_world_size(group) <= 1:
         return "rccl"
-    if torch.cuda.is_current_stream_capturing():
-        return "rccl"
     f = forced()
-    if f is not None:
-        return f
     key = (_key(group), op, bucket(payload_bytes))
     rec = _CHOICE.get(key)
+    if torch.cuda.is_current_stream_capturing():
+        # nothing can be tested or timed under capture: the direct exchange only where it was forced or chosen BEFORE the
+        # capture and its graph-capturable twin (device-resident epoch, comm/peer.py) exists at this size
+        from . import peer
+
+        want = f if f is not None else (rec["algorithm"] if rec is not None else "rccl")
+        return "direct" if want == "direct" and peer.captured_ready(group, payload_bytes) else "rccl"
+    if f is not None:
+        return f
     if rec is not None:
         return rec["algorithm"]
     ok, why = self_test(group, x.device)

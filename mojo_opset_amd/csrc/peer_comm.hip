@@ -21,6 +21,14 @@
 // epoch parity, which is enough because a rank can only be one call ahead of its slowest peer (every call waits for
 // every peer's flags of that call).
 //
+// Captured mode (HIP-graph replay; round 4): a captured launch has its arguments baked in, so neither an epoch that grows on
+// the host nor a data offset that alternates with its parity can be replayed.  A captured call therefore passes epoch 0 =
+// "take the epoch from the control area": `mojo_hip_peer_begin` opens the call by incrementing a device-resident epoch word
+// (every later kernel of the call reads it), and instead of the parity halves there is ONE data area guarded by a third flag
+// kind: at the end of a call a rank tells every peer "I have finished reading your data of this call" (kind 2), and the
+// begin step of the next call waits for those flags before the GEMM overwrites the area.  Eager and captured calls use
+// separate exchange objects (comm/peer.py), so the two epoch sequences never meet.
+//
 // Liveness: every wait is bounded (wall-clock ticks of the 100 MHz constant counter).  On expiry — or when the sticky
 // error word is already set — the waiter stops waiting, poisons what it would have produced with NaN, still raises its
 // own flags (so peers do not time out in cascade) and the grid drains.  The host reads the error word when it next looks.
@@ -34,10 +42,11 @@ namespace mojo {
 
 constexpr int PEER_MAX = 16;              // ranks of one node
 constexpr int PEER_MAX_CHUNKS = 64;       // row chunks of one operator call
-constexpr int PEER_FLAG_KINDS = 2;        // 0: partial product of (rank, chunk) is in memory; 1: reduced share is
+constexpr int PEER_FLAG_KINDS = 3;        // 0: partial product of (rank, chunk) is in memory; 1: reduced share is; 2: rank has finished READING the call's data (captured mode, chunk 0)
 constexpr int PEER_FLAG_WORDS = PEER_FLAG_KINDS * PEER_MAX * PEER_MAX_CHUNKS;
 // words behind the flags: [0] sticky error, [1..] one arrival counter per chunk for the "last workgroup signals" step
 constexpr int PEER_ERR_WORD = PEER_FLAG_WORDS;
+constexpr int PEER_EPOCH_WORD = PEER_FLAG_WORDS + 1;   // captured mode: the epoch of the call in flight (0 before the first)
 constexpr int PEER_CNT_WORD = PEER_FLAG_WORDS + 16;
 constexpr int PEER_CTRL_WORDS = PEER_CNT_WORD + PEER_MAX_CHUNKS;
 
@@ -65,10 +74,30 @@ __device__ bool wait_flag(uint32_t* f, uint32_t epoch, uint32_t* err, long long 
   }
 }
 
+// epoch argument 0 = captured mode: the call's epoch lives in this rank's control area (written by peer_begin_kernel)
+__device__ __forceinline__ uint32_t resolve_epoch(uint32_t* my_flags, uint32_t epoch) {
+  return epoch ? epoch : __hip_atomic_load(my_flags + PEER_EPOCH_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- begin (captured mode): wait until every peer has finished reading the previous call's data, then open the next epoch --
+__global__ __launch_bounds__(64) void peer_begin_kernel(PeerPtrs pp, int ws, int rank, long long timeout_ticks) {
+  uint32_t* my = pp.flags[rank];
+  const uint32_t cur = __hip_atomic_load(my + PEER_EPOCH_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int p = threadIdx.x;
+  if (p < ws && p != rank && cur != 0) (void)wait_flag(flag_word(my, 2, p, 0), cur, my + PEER_ERR_WORD, timeout_ticks);
+  __syncthreads();
+  if (p == 0) {
+    uint32_t nxt = cur + 1;
+    if (nxt == 0) nxt = 1;                                                  // 0 is "take it from here" in the other kernels
+    __hip_atomic_store(my + PEER_EPOCH_WORD, nxt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- signal: "my partial product of this chunk is in memory" (kind 0) ------------------------------------------
 __global__ __launch_bounds__(64) void peer_signal_kernel(PeerPtrs pp, int ws, int rank, int kind, int chunk, uint32_t epoch) {
   const int p = threadIdx.x;
   if (p >= ws) return;
+  epoch = resolve_epoch(pp.flags[rank], epoch);
   __atomic_thread_fence(__ATOMIC_SEQ_CST);                                  // (system scope: the default of the builtin)
   __hip_atomic_store(flag_word(pp.flags[p], kind, rank, chunk), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -86,6 +115,7 @@ __global__ __launch_bounds__(256) void peer_reduce_kernel(PeerPtrs pp, int ws, i
   __shared__ int s_ok;
   uint32_t* my_flags = pp.flags[rank];
   uint32_t* err = my_flags + PEER_ERR_WORD;
+  epoch = resolve_epoch(my_flags, epoch);
   if (threadIdx.x == 0) s_ok = 1;
   __syncthreads();
   if (threadIdx.x < ws && threadIdx.x != rank) {
@@ -150,6 +180,7 @@ __global__ __launch_bounds__(256) void peer_gather_kernel(PeerPtrs pp, int ws, i
   __shared__ int s_ok;
   const int p = (rank + 1 + blockIdx.y) % ws;                               // start with the next rank: links are used evenly
   uint32_t* my_flags = pp.flags[rank];
+  epoch = resolve_epoch(my_flags, epoch);
   const long long r0 = rows * p / ws, r1 = rows * (p + 1) / ws;
   if (r1 == r0) return;                                                     // rank p owns no row of this chunk: nothing to wait for
   if (threadIdx.x == 0) s_ok = wait_flag(flag_word(my_flags, 1, p, chunk), epoch, my_flags + PEER_ERR_WORD, timeout_ticks) ? 1 : 0;
@@ -182,6 +213,7 @@ __global__ __launch_bounds__(256) void peer_pull_kernel(PeerPtrs pp, int ws, int
   __shared__ int s_ok;
   const int p = (rank + first + blockIdx.y) % ws;
   uint32_t* my_flags = pp.flags[rank];
+  epoch = resolve_epoch(my_flags, epoch);
   if (threadIdx.x == 0)
     s_ok = (p == rank || wait_flag(flag_word(my_flags, kind, p, flag_chunk), epoch, my_flags + PEER_ERR_WORD, timeout_ticks)) ? 1 : 0;
   __syncthreads();
@@ -322,6 +354,17 @@ extern "C" int mojo_hip_peer_error(void* local_flags, int clear, int32_t* error_
 }
 
 // ---- exchange steps (enqueue only: no allocation, no host sync) -----------------------------------------------------
+// Every step takes the call's epoch; 0 = captured mode (see the header of this file).
+extern "C" int mojo_hip_peer_begin(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank, mojo_stream_t stream) {
+  MOJO_REQUIRE(world >= 1 && world <= PEER_MAX && rank >= 0 && rank < world, MOJO_EINVAL, "peer_begin: bad arguments");
+  PeerPtrs pp;
+  MOJO_REQUIRE(fill_ptrs(pp, peer_data, peer_flags, static_cast<int>(world)) == MOJO_OK, MOJO_EINVAL, "peer_begin: null peer pointer");
+  hipLaunchKernelGGL(peer_begin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), pp, static_cast<int>(world),
+                     static_cast<int>(rank), timeout_ticks());
+  MOJO_CHECK_LAUNCH("peer_begin");
+  return MOJO_OK;
+}
+
 extern "C" int mojo_hip_peer_signal(void* const* peer_data, void* const* peer_flags, int64_t world, int64_t rank,
                                     int kind, int64_t chunk, uint32_t epoch, mojo_stream_t stream) {
   MOJO_REQUIRE(world >= 1 && world <= PEER_MAX && rank >= 0 && rank < world && chunk >= 0 && chunk < PEER_MAX_CHUNKS &&

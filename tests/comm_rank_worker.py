@@ -349,6 +349,66 @@ def check_auto_selection(rank, ws, group):
     _report(rank, selection=rep)
 
 
+def check_captured_direct(rank, ws, group):
+    """The direct exchange under HIP-graph capture (device-resident epoch, one data area guarded by "done reading" flags:
+    csrc/peer_comm.hip captured mode, comm/peer.py twin): GemmAllReduce -> GemmReduceScatter -> AllGatherGemm captured as ONE
+    graph after an eager warm-up (which builds the twin), replayed on new inputs several times and compared, bit for bit,
+    with the same operators run eagerly over the direct exchange on the same inputs.  Five replays: the single data area is
+    reused every call, so a missing "done reading" wait shows up as a torn result."""
+    from hip_utils import hip_cls
+    from mojo_opset_amd.comm import peer
+
+    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+    os.environ["MOJO_HIP_COMM_CHUNKS"] = "2"
+    dtype = torch.bfloat16
+    m, k, n = 64, 512, 1024                                   # decode-sized rows: the case graphs exist for
+    torch.manual_seed(7 + rank)
+    w1 = (torch.randn(k, n) * 0.05).to(dtype).to(DEV)
+    w2 = (torch.randn(n, k) * 0.05).to(dtype).to(DEV)
+    w3 = (torch.randn(k, n) * 0.05).to(dtype).to(DEV)
+    ar = hip_cls("MojoGemmAllReduce")(weight=w1, bias=None, trans_weight=True, process_group=group)
+    rs = hip_cls("MojoGemmReduceScatter")(weight=w2, bias=None, trans_weight=True, process_group=group)
+    ag = hip_cls("MojoAllGatherGemm")(weight=w3, bias=None, trans_weight=True, process_group=group)
+    x = torch.zeros(m, k, dtype=dtype, device=DEV)
+
+    def step():
+        a = ar(x)                                             # [m, n] on every rank
+        b = rs(a)                                             # [m / ws, k]
+        return ag(b)                                          # [m, n]
+
+    def load(i):
+        g = torch.Generator().manual_seed(1000 * i + rank)
+        x.copy_(torch.randn(m, k, generator=g).to(dtype))
+
+    load(0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                               # eager warm-up: builds the exchange and its captured twin
+        step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    assert all(ex.twin is not None for ex in peer._CACHE.values()) and peer._CACHE
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    for i in range(1, 6):
+        load(i)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        want = step()                                         # eager, over the (non-captured) direct exchange
+        torch.cuda.synchronize()
+        assert torch.isfinite(got.float()).all(), f"replay {i}: poisoned output"
+        assert torch.equal(got, want), f"replay {i}: captured and eager direct exchange disagree (max diff {(got.float() - want.float()).abs().max().item()})"
+    for ex in peer._CACHE.values():
+        ex.check()
+        ex.twin.check()
+    _report(rank, check="captured:direct_exchange:5_replays", ok=True)
+    os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+
+
 def main():
     import faulthandler
 
@@ -375,6 +435,10 @@ def main():
             if mode == "timeout":
                 _report(rank, mode=mode)
                 check_timeout_path(rank, ws, group)
+                continue
+            if mode == "captured":
+                _report(rank, mode=mode)
+                check_captured_direct(rank, ws, group)
                 continue
             if mode == "tiny":
                 _report(rank, mode=mode)
