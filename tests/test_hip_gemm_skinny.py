@@ -306,3 +306,59 @@ def test_qkv_rope_store_fused_equals_the_separate_calls_and_the_oracle(dtype, b,
         blk, slot = int(table[i, int(ctx[i]) // page]), int(ctx[i]) % page
         torch.testing.assert_close(to_cpu(kc[blk, :, slot]).float(), k_ref[0, i].float(), atol=3e-2, rtol=2e-2)
         torch.testing.assert_close(to_cpu(vc[blk, :, slot]).float(), qkv_ref[i, (hq + hkv) * d:].reshape(hkv, d).float(), atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_decode_fusions_random_shapes_equal_the_separate_calls(seed):
+    """Seeded random shapes (further seeds with MOJO_FUZZ_OFFSET): every fused form against its row of separate calls."""
+    import os
+    import random
+
+    from hip_utils import hip_cls
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_residual_rmsnorm, dense_gemm_swiglu, qkv_rope_store
+    rnd = random.Random(9000 + seed + 1000 * int(os.environ.get("MOJO_FUZZ_OFFSET", "0")))
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    g = torch.Generator().manual_seed(seed)
+    # gemm + swiglu (m <= 64 takes the fused kernel when K % 128 == 0; anything else the two-launch route)
+    m, k, inter = rnd.randint(1, 80), rnd.choice([128, 256, 384, 1024, 200]), 8 * rnd.randint(1, 300)
+    x = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(2 * inter, k, generator=g) / k ** 0.5).to(dtype).to(DEV)
+    got = dense_gemm_swiglu(x, w)
+    chain = _swiglu_chain(x, w)
+    if L.load().mojo_hip_gemm_workspace_bytes(m, k, 2 * inter) <= 64:
+        assert torch.equal(got, chain), (m, k, inter)
+    else:
+        assert max_ulp_bf16ish(to_cpu(got), to_cpu(chain), atol=2e-3) <= 2, (m, k, inter)
+    # gemm + residual rmsnorm
+    m, k, n = rnd.randint(1, 140), 128 * rnd.randint(1, 64), 64 * rnd.randint(1, 96)
+    x = torch.randn(m, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(DEV)
+    r = torch.randn(m, n, generator=g).to(dtype).to(DEV)
+    nw = (1 + 0.1 * torch.randn(n, generator=g)).to(dtype).to(DEV)
+    normed, summed = dense_gemm_residual_rmsnorm(x, w, None, r, nw, 1e-5)
+    op = hip_cls("MojoResidualAddRMSNorm")(n, 1e-5, "pre", dtype=dtype, device=DEV)
+    op.weight.data.copy_(nw)
+    want_n, want_s = op(dense_gemm(x, w, None, False), r)
+    assert torch.equal(summed, want_s) and torch.equal(normed, want_n), (m, k, n)
+    # qkv + rope + store
+    b, hkv, grp, d, page = rnd.randint(1, 70), rnd.choice([1, 2, 4, 8]), rnd.choice([1, 2, 4, 8]), rnd.choice([32, 64, 128]), rnd.choice([4, 8, 16, 32])
+    hq, k = hkv * grp, 128 * rnd.randint(1, 24)
+    n = (hq + 2 * hkv) * d
+    x = torch.randn(b, k, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dtype).to(DEV)
+    cos, sin = torch.randn(b, d, generator=g).to(DEV), torch.randn(b, d, generator=g).to(DEV)
+    pages = 5
+    n_blocks = b * pages + 2
+    table = torch.randperm(n_blocks, generator=g)[: b * pages].view(b, pages).to(torch.int32)
+    ctx = torch.randint(-1, pages * page + 2, (b,), generator=g).to(torch.int32)
+    table[rnd.randrange(b), rnd.randrange(pages)] = -1
+    table, ctx = table.to(DEV), ctx.to(DEV)
+    kc0 = torch.randn(n_blocks, hkv, page, d, generator=g).to(dtype).to(DEV)
+    vc0 = torch.randn(n_blocks, hkv, page, d, generator=g).to(dtype).to(DEV)
+    kc, vc = kc0.clone(), vc0.clone()
+    q_got = qkv_rope_store(x, w, None, cos, sin, kc, vc, table, ctx, hq, hkv)
+    qkv = dense_gemm(x, w, None, False)
+    q_r, k_r = hip_cls("MojoApplyRoPE")()(qkv[:, : hq * d].reshape(1, b, hq, d), qkv[:, hq * d: (hq + hkv) * d].reshape(1, b, hkv, d), cos, sin, head_first=False)
+    kc2, vc2 = kc0.clone(), vc0.clone()
+    hip_cls("MojoStorePagedKVCache")()(k_r.squeeze(0).contiguous(), qkv[:, (hq + hkv) * d:].reshape(b, hkv, d).contiguous(), kc2, vc2, table, None, ctx)
+    assert torch.equal(q_got, q_r.squeeze(0)) and torch.equal(kc, kc2) and torch.equal(vc, vc2), (b, hq, hkv, d, page, k)
