@@ -63,6 +63,9 @@ struct DecodeArgs {
   float scale_log2;
   int abab;
   int leave_empty;                // rows with seq_len <= 0: 1 = leave the output row untouched (graph replay contract), 0 = zeros
+  int fuse_group = 0;             // > 0: GROUPED form — workgroups of this many waves each own that many consecutive chunks of a row,
+                                  // merge them in LDS and leave ONE partial per workgroup (slot = workgroup index along x) for the
+                                  // merge launch; a row whose chunks fit one workgroup is finished there
 };
 
 // Chunking is PER SEQUENCE: a sequence of `len` tokens is cut into n_chunks equal pieces (whole tiles, at least 128 tokens,
@@ -473,7 +476,8 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a, int G) 
   const int g = blockIdx.y;
   const int seq_len = decode_seq_len(a, b);
   const int chunk_tokens = decode_seq_chunk(a, seq_len);
-  const int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + chunk_tokens - 1) / chunk_tokens;   // <= a.n_chunks by construction
+  int n_chunks_seq = seq_len <= 0 ? 0 : (seq_len + chunk_tokens - 1) / chunk_tokens;   // <= a.n_chunks by construction
+  if (a.fuse_group > 0) n_chunks_seq = (n_chunks_seq + a.fuse_group - 1) / a.fuse_group;   // grouped form: one partial per workgroup
   if (n_chunks_seq == 1) return;                         // (workgroup-uniform)
   const int h = decode_head(a, kvh, g, G);
   const int cl = threadIdx.x >> 5, dt = threadIdx.x & 31;
@@ -520,7 +524,23 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a, int G) 
   *reinterpret_cast<V4*>(dst) = o;
 }
 
-static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len) {
+// The grouped form (DecodeArgs::fuse_group; matrix-core kernel only: the same conditions as decode_use_mfma, which the
+// workspace sizing cannot call) — MOJO_HIP_DECODE_GROUPED=0/1, read per call.
+static bool decode_grouped(int64_t G, int64_t head_dim, int64_t page) {
+  // Measured (scripts/probes/decode_grouped_ab.py, profiles/r4_decode_grouped_ab.txt; split + merge form -> grouped form, graph
+  // replay): 8 q / 1 kv heads B 64 ctx 4096 (Llama-3-70B under TP 8) 33.6 -> 28.1 us, B 16 ctx 16384 38.2 -> 29.8 us; 32 / 8 heads
+  // B 8 ctx 4096 31.3 -> 27.5 us; 64 / 8 heads B 8 ctx 8192 56.1 -> 49.8 us; head_dim 64 B 8 ctx 8192 33.7 -> 28.6 us.
+  const char* e = getenv("MOJO_HIP_DECODE_GROUPED");
+  if (e && e[0] == '0') return false;
+  const bool pow2 = page > 0 && (page & (page - 1)) == 0;
+  if (!pow2 || page < 16 || (head_dim != 64 && head_dim != 128) || G > 16) return false;
+  const char* m = getenv("MOJO_HIP_DECODE_MFMA");
+  if (m && m[0] == '0') return false;
+  if (m && m[0] == '1') return true;
+  return G >= 4 || head_dim == 64 || (G != 1 && G != 2);
+}
+
+static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len, bool grouped = false) {
   if (const char* env = getenv("MOJO_HIP_DECODE_CHUNK")) {     // tuning override
     const int v = atoi(env);
     if (v >= DEC_TILE) return (v / DEC_TILE) * DEC_TILE;
@@ -540,7 +560,9 @@ static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len)
   // matrix-core kernel: 8 q / 1 kv heads B 64 ctx 4096 39.8 -> 34.3 us, B 16 ctx 16384 52.1 -> 38.9 us, 64 / 8 heads B 8 ctx 8192
   // 64.2 -> 57.4 us, 32 / 8 heads B 8 ctx 4096 36.8 -> 32.6 us; 512 waves: 1.5-2 x slower) - but never fewer than 8 chunks.
   if (ceil_div(len, chunk) > 8) {
-    int64_t s2 = 1024 / units;
+    // (grouped form: the partials are merged in LDS eight at a time, so the 2 048 waves that fill the chip cost no more partials
+    // than 256 single-wave workgroups per row would)
+    int64_t s2 = (grouped ? 2048 : 1024) / units;
     if (s2 < 8) s2 = 8;
     chunk = ceil_div(len, s2);
     if (chunk < 128) chunk = 128;
@@ -594,6 +616,16 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
     if (a.n_chunks <= 8 && !no_fuse) {
       launch_decode_mfma<T, NT, DEC_FUSED>(a, dim3(1, static_cast<unsigned>(batch * a.hkv)), dim3(static_cast<unsigned>(64 * a.n_chunks)), G, s);
       MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, fused)");
+      return MOJO_OK;
+    }
+    if (a.fuse_group > 0 && !no_fuse) {
+      // small grids (few (sequence, kv-head) rows, many chunks each): eight-wave workgroups merge their chunks in LDS and leave
+      // one partial each, so the launch keeps two waves per SIMD busy and the merge reads n_chunks / 8 partials per row
+      const unsigned n_sub = static_cast<unsigned>((a.n_chunks + a.fuse_group - 1) / a.fuse_group);
+      launch_decode_mfma<T, NT, DEC_FUSED>(a, dim3(n_sub, static_cast<unsigned>(batch * a.hkv)), dim3(static_cast<unsigned>(64 * a.fuse_group)), G, s);
+      MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, grouped)");
+      hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv), G), dim3(256), 0, s, a, G);
+      MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
       return MOJO_OK;
     }
     launch_decode_mfma<T, NT, DEC_SPLIT>(a, dim3(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv)), dim3(64), G, s);
@@ -666,7 +698,7 @@ extern "C" int64_t mojo_hip_paged_decode_gqa_workspace_bytes(int64_t batch, int6
   // whichever form cuts the sequences finer)
   int64_t slots = 0;
   for (int64_t mult = 1; mult <= (q_heads / kv_heads == 8 ? 2 : 1); ++mult) {
-    const int chunk = decode_chunk_tokens(batch, kv_heads * mult, max_len);
+    const int chunk = decode_chunk_tokens(batch, kv_heads * mult, max_len, decode_grouped(q_heads / (kv_heads * mult), head_dim, block_size));
     const int64_t n_chunks = ceil_div(max_len > 0 ? max_len : 1, chunk);
     const int64_t sl = batch * kv_heads * n_chunks * (q_heads / kv_heads);
     if (sl > slots) slots = sl;
@@ -718,8 +750,10 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
     const char* e = getenv("MOJO_HIP_DECODE_G8_HALVES");
     if (e && e[0] == '1') { a.hshift = 1; a.hkv *= 2; G = 4; }
   }
-  a.chunk_tokens = decode_chunk_tokens(batch, a.hkv, max_len);
+  const bool grouped = decode_grouped(G, head_dim, block_size);
+  a.chunk_tokens = decode_chunk_tokens(batch, a.hkv, max_len, grouped);
   a.n_chunks = static_cast<int>(ceil_div(max_len > 0 ? max_len : 1, a.chunk_tokens));
+  a.fuse_group = grouped && a.n_chunks > 8 ? 8 : 0;
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.abab = layout_abab ? 1 : 0;
   a.leave_empty = leave_empty_rows ? 1 : 0;

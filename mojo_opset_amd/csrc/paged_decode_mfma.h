@@ -72,7 +72,8 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
   const int lane = threadIdx.x & 63;
   const int tl = lane & 15, g4 = lane >> 4;             // K / V loads: token tl of the tile, dim chunk g4 of each k-step
   const int wave_id = FUSED ? __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)) : 0;
-  int chunk = FUSED ? wave_id : static_cast<int>(blockIdx.x);
+  // (grouped form, DecodeArgs::fuse_group: workgroup x of a row owns chunks [x * waves, (x + 1) * waves) of it)
+  int chunk = FUSED ? static_cast<int>(blockIdx.x) * static_cast<int>(blockDim.x >> 6) + wave_id : static_cast<int>(blockIdx.x);
   int b = blockIdx.y / a.hkv;
   const int kvh = blockIdx.y % a.hkv;
 
@@ -352,7 +353,16 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
       } else {
         ub = b; ulen = seq_len; uchunk = chunk_tokens; slot0 = 0; uwaves = static_cast<int>(blockDim.x >> 6);
       }
-      const int n_chunks_seq = ulen <= 0 ? 0 : min((ulen + uchunk - 1) / uchunk, uwaves);
+      int n_chunks_seq = ulen <= 0 ? 0 : min((ulen + uchunk - 1) / uchunk, uwaves);
+      bool partial = false;                                // grouped form: this workgroup's chunks are not the whole row
+      if constexpr (!PAIRED) {
+        if (a.fuse_group > 0) {
+          const int total = ulen <= 0 ? 0 : (ulen + uchunk - 1) / uchunk;
+          partial = total > uwaves;
+          n_chunks_seq = min(max(total - static_cast<int>(blockIdx.x) * uwaves, 0), uwaves);
+          if (blockIdx.x > 0 && n_chunks_seq == 0) continue;   // a workgroup past the row's last chunk: nothing to leave
+        }
+      }
       if (n_chunks_seq == 0 && a.leave_empty) continue;
       const int h = decode_head(a, kvh, g, G);
       float mx = -INFINITY;
@@ -364,6 +374,12 @@ __global__ __launch_bounds__(MODE != DEC_SPLIT ? 512 : 64) void decode_mfma_kern
         const float w = exp2f(src[D] - mx);
         den = fmaf(w, src[D + 1], den);
         num += f32x4{src[d0], src[d0 + 1], src[d0 + 2], src[d0 + 3]} * w;
+      }
+      if (partial) {                                         // un-normalised sums against this workgroup's maximum, for the merge launch
+        const int64_t slot = (static_cast<int64_t>(blockIdx.y) * a.n_chunks + blockIdx.x) * G + g;
+        *reinterpret_cast<f32x4*>(a.ws_acc + slot * D + d0) = num;
+        if (d0 == 0) { a.ws_ml[slot * 2 + 0] = mx; a.ws_ml[slot * 2 + 1] = den; }
+        continue;
       }
       const float inv = n_chunks_seq > 0 ? 1.0f / den : 0.f;
       V4 ov;
