@@ -373,6 +373,47 @@ __global__ __launch_bounds__(512) void mla_merge_kernel(MlaArgs a, int R) {
   const bool live = d0 < R;
   // prefill: tokens no sequence owns were skipped by the attention launch (no partials written); their rows stay zero
   if (a.cu_q && (tile < a.cu_q[0] || tile >= a.cu_q[a.batch])) return;          // (workgroup-uniform)
+  if (nl == 1 && a.n_splits <= 4) {
+    // few splits (the decode batch: two): every load of the item is requested before the first is used — the general loop below
+    // is three dependent round trips (maxima, then per split its statistics and, behind a branch, its partial).  Same
+    // arithmetic in the same order.
+    float ms[4], ls[4];
+    f32x4 po[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t slot = (static_cast<int64_t>(tile) * a.n_splits + min(i, a.n_splits - 1)) * a.heads + head;
+      ms[i] = a.part_ml[slot * 2];
+      ls[i] = a.part_ml[slot * 2 + 1];
+      po[i] = live ? *reinterpret_cast<const f32x4*>(a.part_o + slot * R + d0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float M1 = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < a.n_splits) M1 = fmaxf(M1, ms[i]);
+    float sk1 = 0.f;
+    if (a.sink) {
+      sk1 = a.sink[head] * 1.4426950408889634f;
+      M1 = fmaxf(M1, sk1);
+    }
+    f32x4 num1 = {0.f, 0.f, 0.f, 0.f};
+    float den1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= a.n_splits || ms[i] == -INFINITY) continue;
+      const float w = exp2f(ms[i] - M1);
+      den1 = fmaf(w, ls[i], den1);
+      if (live) num1 += po[i] * w;
+    }
+    if (!live) return;
+    den1 = (a.sink ? exp2f(sk1 - M1) : 0.f) + den1;
+    const float inv1 = den1 > 0.f ? 1.0f / den1 : 0.f;
+    typedef typename vec_of<T, 4>::type V4;
+    V4 ov;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[e] = static_cast<T>(num1[e] * inv1);
+    *reinterpret_cast<V4*>(static_cast<T*>(a.o_lat) + (static_cast<int64_t>(tile) * a.heads + head) * R + d0) = ov;
+    return;
+  }
   float M = -INFINITY;
   for (int sp = sl; sp < a.n_splits; sp += nl) M = fmaxf(M, a.part_ml[((static_cast<int64_t>(tile) * a.n_splits + sp) * a.heads + head) * 2]);
   if (dt == 0) s_m[sl] = M;
