@@ -80,19 +80,27 @@ __global__ __launch_bounds__(256) void quant_finalize_kernel(const ACC* __restri
 //   * grid = (N/64) x splitk with ~256 workgroups (each keeps 48 KiB of weights in flight); split-K slices write raw
 //     accumulators to their own slab, summed in slice order by quant_finalize_kernel (deterministic).
 // Algorithmic bytes: K*N (+ M*K + 4*M*N*splitk*2 of slab traffic when split).
-template <typename TO, bool FP8, int MT, bool NT /* weights read once: non-temporal loads */>
-__global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
+// NW = waves per workgroup (16 columns each; round 4): chosen with the K split so that the wave units divide evenly over the CUs
+// (quant_skinny_plan) — the stream is per-CU bound, and N = 7168 in 64-column workgroups is 112 tiles x 2 slices = 224
+// workgroups on 256 CUs.  A wave past the last column tile streams the last one again and stores nothing.
+template <typename TO, bool FP8, int MT, bool NT /* weights read once: non-temporal loads */, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void quant_skinny_kernel(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                            const float* __restrict__ rs, const bf16_t* __restrict__ cs,
                                                            TO* __restrict__ C, void* __restrict__ slab, int M, int K, int N,
                                                            int splitk, int sk_slot) {
   typedef typename std::conditional<FP8, f32x4, i32x4>::type acc_t;
   constexpr int ROW = 272;                                   // padded LDS row of a 256-byte K block
+  constexpr int NTH = NW * 64;                               // threads
+  constexpr int AP = (MT * 256 + NTH - 1) / NTH;             // activation chunks per thread and K block
+  constexpr bool A_EVEN = (MT * 256) % NTH == 0;
   __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MT * 16 * ROW];
-  __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * ROW];        // per wave: its 16 weight rows of a K block
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[NW][2][16 * ROW];       // per wave: its 16 weight rows of a K block
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 64 + wave * 16;
+  const int unit_raw = static_cast<int>(blockIdx.x) * NW + wave;
+  const bool unit_live = unit_raw < N / 16;
+  const int n0 = (unit_live ? unit_raw : N / 16 - 1) * 16;
   const int slice = blockIdx.y;
   const int m0 = blockIdx.z * (MT * 16);                     // row block (grid.z > 1: more than MT * 16 rows)
   const int nkb = K / 256;
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
   const int rot = nb > 0 ? static_cast<int>(blockIdx.x % nb) : 0;
   auto block_at = [&](int i) { const int j = i + rot; return kb0 + (j >= nb ? j - nb : j); };
   constexpr int DEPTH = 3;                                   // weight blocks in flight ahead of the multiply
-  u32x4 wreg[DEPTH + 1][4], areg[2][MT];                     // activations: two blocks ahead in registers, one in LDS
+  u32x4 wreg[DEPTH + 1][4], areg[2][AP];                     // activations: two blocks ahead in registers, one in LDS
   auto load_w = [&](int i, u32x4 (&wr)[4]) {
     const uint8_t* wp = wrow + static_cast<int64_t>(block_at(i)) * 256;
 #pragma unroll
@@ -127,20 +135,20 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
     for (int sx = 0; sx < 4; ++sx)
       *reinterpret_cast<u32x4*>(&s_w[wave][buf][(4 * sx + (lane >> 4)) * ROW + (lane & 15) * 16]) = wr[sx];
   };
-  auto load_a = [&](int i, u32x4 (&ar)[MT]) {
+  auto load_a = [&](int i, u32x4 (&ar)[AP]) {
     const int64_t k0 = static_cast<int64_t>(block_at(i)) * 256;
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      const int idx = threadIdx.x + 256 * p;                 // 16-byte chunk of the activation block
+    for (int p = 0; p < AP; ++p) {
+      const int idx = min(static_cast<int>(threadIdx.x) + NTH * p, MT * 256 - 1);   // 16-byte chunk of the activation block
       const int row = min(m0 + (idx >> 4), M - 1);
       ar[p] = *reinterpret_cast<const u32x4*>(A + static_cast<int64_t>(row) * K + k0 + (idx & 15) * 16);
     }
   };
-  auto store_a = [&](int buf, const u32x4 (&ar)[MT]) {
+  auto store_a = [&](int buf, const u32x4 (&ar)[AP]) {
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
-      const int idx = threadIdx.x + 256 * p;
-      *reinterpret_cast<u32x4*>(&s_a[buf][(idx >> 4) * ROW + (idx & 15) * 16]) = ar[p];
+    for (int p = 0; p < AP; ++p) {
+      const int idx = threadIdx.x + NTH * p;
+      if (A_EVEN || idx < MT * 256) *reinterpret_cast<u32x4*>(&s_a[buf][(idx >> 4) * ROW + (idx & 15) * 16]) = ar[p];
     }
   };
   if (nb > 0) {
@@ -198,6 +206,7 @@ __global__ __launch_bounds__(256) void quant_skinny_kernel(const uint8_t* __rest
       constexpr int r = decltype(RC)::value;
       if (i0 + r < nb) body(i0 + r, RC, std::true_type{});
     });
+  if (!unit_live) return;
   // lane holds rows m = mt*16 + l15, columns n0 + 4g .. +3
   const int n = n0 + 4 * g;
   auto emit = [&](int m, acc_t v) {
@@ -382,40 +391,79 @@ static bool quant_skinny_ok(int64_t m, const GemmArgs& a) {
          aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
 }
 
-static int quant_skinny_splitk(int k, int n, int64_t m) {
-  if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return v; }
-  const int nkb = k / 256, tiles = (n / 64) * (m > 64 ? 2 : 1);
-  // A CU's rate does not grow with a second workgroup on it (measured, N = 7168: 3 slices = 336 workgroups, 1.3 per CU,
-  // 33-35 us; 2 slices = 224 and 4 = 448 workgroups 29.5 us), so the time goes as (workgroups on the fullest CU) x
-  // (work per workgroup) = ceil(tiles * sk / 256) / sk.  Take the smallest sk (least slab traffic) with the least of that,
-  // among splits of at most two workgroups per CU and at least four K blocks per slice.
-  int best = 1;
-  double best_cost = static_cast<double>((tiles + 255) / 256);
-  for (int sk = 2; sk <= 64 && sk <= nkb / 4 && tiles * sk <= 512; ++sk) {
-    const double cost = static_cast<double>((tiles * sk + 255) / 256) / sk;
-    if (cost < best_cost * 0.999) { best_cost = cost; best = sk; }
+// K split AND waves per workgroup of the decode-sized kernel.  A CU's rate does not grow with a second workgroup on it
+// (measured, N = 7168: 3 slices = 336 workgroups, 1.3 per CU, 33-35 us; 2 slices = 224 and 4 = 448 workgroups 29.5 us), so the
+// time goes as the wave units (16 columns x one K slice) on the fullest CU.  Round 4: four-wave workgroups alone leave e.g.
+// N = 7168 at 224 or 448 workgroups (0.875 of the chip); with 4..8 waves per workgroup 64 column groups of 7 waves x 4 slices
+// are exactly one per CU.  Candidates: splits of at least four K blocks per slice, at most two four-wave (one larger)
+// workgroups per CU; least (units on the fullest CU) x (K share), then fewest slices (slab traffic), then fewest waves.
+struct QuantSkinnyPlan { int sk, nw; double cost; };
+static QuantSkinnyPlan quant_skinny_plan_for(int k, int n, int64_t m, int nw_lo, int nw_hi) {
+  QuantSkinnyPlan p{1, 4, -1.0};
+  const int nkb = k / 256, units = n / 16, rb = m > 64 ? 2 : 1;
+  for (int sk = 1; sk <= 64 && (sk == 1 || sk <= nkb / 4); ++sk) {
+    for (int nw = nw_lo; nw <= nw_hi; ++nw) {
+      if (nw < 4 || nw > 8 || nw == 5) continue;
+      const int64_t wgs = static_cast<int64_t>((units + nw - 1) / nw) * sk * rb;
+      if (sk > 1 && wgs > (nw == 4 ? 512 : 256)) continue;       // (an unsplit launch may take several rounds of workgroups)
+      const double cost = static_cast<double>((wgs + 255) / 256) * nw / sk;
+      if (p.cost < 0.0 || cost < p.cost * 0.999) { p.cost = cost; p.sk = sk; p.nw = nw; }
+    }
   }
-  return best;
+  return p;
+}
+// The wide plans are taken where they measured faster (scripts/probes/qg_waves_ab.py, profiles/r4_qgemm_waves_ab.txt, int8, graph
+// replay, cold weights, four-wave rule -> balanced plan): 64 x 7168 x 18432 40.8 -> 30.5 us (288 unsplit tiles were 1.1 rounds of
+// workgroups), 128 x 18432 x 7168 51.3 -> 45.0 us (two row blocks: fewer column groups re-read the activations); NOT where the
+// four-wave plan already covers 7/8 of the chip with few rows (32 x 18432 x 7168 27.3 -> 29.2 us, 16 x 4096 x 7168 10.5 -> 11.6 us:
+// twice the slices for 12 % better balance).  Hence: more than 64 rows, or a balance gain of at least a quarter.
+static QuantSkinnyPlan quant_skinny_plan(int k, int n, int64_t m, bool wide = true /* 6 / 7 / 8 waves instantiated (bf16 output) */) {
+  if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return QuantSkinnyPlan{v, 4, 0.0}; }
+  if (const char* wv = getenv("MOJO_HIP_QGEMM_WAVES")) {                  // measurement: forced waves per workgroup (4 = the round-3 rule)
+    const int w = atoi(wv);
+    return quant_skinny_plan_for(k, n, m, wide ? w : 4, wide ? w : 4);
+  }
+  const QuantSkinnyPlan narrow = quant_skinny_plan_for(k, n, m, 4, 4);
+  if (!wide) return narrow;
+  const QuantSkinnyPlan any = quant_skinny_plan_for(k, n, m, 4, 8);
+  if (any.nw != 4 && (any.cost <= 0.75 * narrow.cost || (m > 64 && any.cost < 0.999 * narrow.cost))) return any;
+  return narrow;
+}
+static int quant_skinny_splitk(int k, int n, int64_t m) {            // (workspace sizing: the larger of the two plans' splits)
+  const int a = quant_skinny_plan(k, n, m, true).sk, b = quant_skinny_plan(k, n, m, false).sk;
+  return a > b ? a : b;
 }
 
 template <typename TO, bool FP8>
 static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t* cs, int64_t m, void* slab_ws, hipStream_t s) {
-  const int sk = quant_skinny_splitk(a.K, a.N, m);
+  constexpr bool kWide = std::is_same<TO, bf16_t>::value;   // (other output types: four-wave workgroups only — compile time)
+  const QuantSkinnyPlan plan = quant_skinny_plan(a.K, a.N, m, kWide);
+  const int sk = plan.sk;
   // More than 64 rows run as two row blocks of 64 (grid.z): a 128-row workgroup needs 104 KiB of LDS (one workgroup of four
   // waves per CU) and reads its activation fragments from LDS eight times per weight byte; two 64-row workgroups fit a CU
   // together, and the second reads the weight lines the first just pulled into L2.
-  const dim3 grid(static_cast<unsigned>(a.N / 64), static_cast<unsigned>(sk), m > 64 ? 2u : 1u);
+  const dim3 grid(static_cast<unsigned>((a.N / 16 + plan.nw - 1) / plan.nw), static_cast<unsigned>(sk), m > 64 ? 2u : 1u);
   const uint8_t* A = static_cast<const uint8_t*>(a.A);
   const uint8_t* W = static_cast<const uint8_t*>(a.W);
   TO* C = static_cast<TO*>(a.C);
   const int M = static_cast<int>(m);
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
-  const int slot = sk > 1 ? splitk_take_slot(static_cast<int64_t>(grid.x) * grid.z) : -1;   // K slices combined inside the launch
+  const int slot = sk > 1 && plan.nw == 4 ? splitk_take_slot(static_cast<int64_t>(grid.x) * grid.z) : -1;   // K slices combined inside the launch
 #else
   const int slot = -1;
 #endif
-#define SKINNY(MT_, NT_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_, NT_>), grid, dim3(256), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk, slot)
-  if (m <= 16) SKINNY(1, true); else if (m <= 32) SKINNY(2, true); else if (m <= 64) SKINNY(4, true); else SKINNY(4, false);
+#define SKINNY(MT_, NT_, NW_) hipLaunchKernelGGL((quant_skinny_kernel<TO, FP8, MT_, NT_, NW_>), grid, dim3(NW_ * 64), 0, s, A, W, rs, cs, C, slab_ws, M, a.K, a.N, sk, slot)
+#define SKINNY_NW(MT_, NT_)                                                                                   \
+  do {                                                                                                        \
+    if constexpr (kWide) {                                                                                    \
+      switch (plan.nw) { case 6: SKINNY(MT_, NT_, 6); break; case 7: SKINNY(MT_, NT_, 7); break;               \
+                         case 8: SKINNY(MT_, NT_, 8); break; default: SKINNY(MT_, NT_, 4); break; }            \
+    } else {                                                                                                  \
+      SKINNY(MT_, NT_, 4);                                                                                    \
+    }                                                                                                         \
+  } while (0)
+  if (m <= 16) SKINNY_NW(1, true); else if (m <= 32) SKINNY_NW(2, true); else if (m <= 64) SKINNY_NW(4, true); else SKINNY_NW(4, false);
+#undef SKINNY_NW
 #undef SKINNY
   MOJO_CHECK_LAUNCH("quant_gemm(skinny)");
   if (sk > 1 && slot < 0) {
