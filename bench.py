@@ -98,15 +98,19 @@ def decode_algorithmic_bytes(lens, max_blocks):
 
 
 def _headline_kernel():
-    """Name of the kernel the headline op call launches (the switches are the library's, read per call)."""
-    env = os.environ.get
-    form = ("paired> (one launch per op call: 8-wave workgroups own a length-ranked pair of sequences, their chunk partials "
-            "are merged in LDS)" if env("MOJO_HIP_DECODE_FUSE", "1") != "0" and env("MOJO_HIP_DECODE_PAIR", "1") != "0" else
-            "fused> (MOJO_HIP_DECODE_PAIR=0)" if env("MOJO_HIP_DECODE_FUSE", "1") != "0" else
-            "split> + mojo::decode_merge_kernel (MOJO_HIP_DECODE_FUSE=0)")
-    if env("MOJO_HIP_DECODE_MFMA", "") == "0":
-        return "mojo::decode_split_kernel<bf16,4,nt," + form + " [vector-unit kernel: MOJO_HIP_DECODE_MFMA=0]"
-    return "mojo::decode_mfma_kernel<bf16,head_dim 128,nt," + form
+    """The kernel form the headline op call launched, as the LIBRARY reports it (`mojo_hip_last_launch`, called right after
+    the timed region) — not a guess from the environment: the switches are latched inside the library."""
+    from mojo_opset_amd.backends.hip import lib
+
+    form = lib.last_launch()                      # e.g. "decode_mfma:paired:nt"
+    kernel, _, rest = form.partition(":")
+    names = {"decode_mfma": "mojo::decode_mfma_kernel<bf16, head_dim 128>", "decode_valu": "mojo::decode_split_kernel<bf16, 4 heads>"}
+    shape = {"paired": "one launch per op call: 8-wave workgroups own a length-ranked pair of sequences, their chunk partials are merged in LDS",
+             "fused": "one launch per op call: a (sequence, kv-head)'s chunks are the waves of one workgroup, merged in LDS",
+             "grouped+merge": "eight-wave workgroups leave one partial each + mojo::decode_merge_kernel",
+             "split+merge": "one partial per chunk + mojo::decode_merge_kernel"}
+    what = rest.split(":")[0]
+    return f"{names.get(kernel, kernel)} [{form}: {shape.get(what, what)}]"
 
 
 def _profiled(name, key):

@@ -354,11 +354,14 @@ def bench_mla_prefill(device):
         flops_absorbed = 2.0 * h * vis * (2 * r + rope) + 2.0 * sum(q_lens) * h * r * (nope + vd)
         res = _mfma(t, flops)
         res["absorbed_form_equivalent_tflops"] = flops_absorbed / t / 1e12
+        from mojo_opset_amd import switches
         os.environ["MOJO_HIP_MLA_PREFILL"] = "absorbed"
+        switches.reload()                               # (switches are latched at first use)
         try:
             t_abs = _time(lambda: op(q, ckv, kpe, cu_q, table, cu_total_seq_lens=cu_kv), 3, 1)
         finally:
             os.environ.pop("MOJO_HIP_MLA_PREFILL", None)
+            switches.reload()
         res["absorbed_route_us"] = t_abs * 1e6
         out[name] = res
     return out
@@ -453,12 +456,16 @@ def bench_compute_comm(device, world, rank):
     def timed(fn):
         return _time(fn, 5, 2, settle_n=12)             # a fixed call count: every rank must issue the same collectives
 
+    from mojo_opset_amd import switches
+    from mojo_opset_amd.backends.hip import lib as L
+
     def with_direct(flag, fn):
         old = os.environ.get("MOJO_HIP_COMM_DIRECT")
-        if flag is None:                                # auto: comm/select.py decides (self-test + timing, cached per payload)
+        if flag is None:                                # auto: what comm/select.py decided in warm() (self-test + timing per payload)
             os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
         else:
             os.environ["MOJO_HIP_COMM_DIRECT"] = flag
+        switches.reload()                               # (switches are latched at first use)
         try:
             return fn()
         finally:
@@ -466,12 +473,25 @@ def bench_compute_comm(device, world, rank):
                 os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
             else:
                 os.environ["MOJO_HIP_COMM_DIRECT"] = old
+            switches.reload()
 
     # The direct exchange has run on 2 ranks of one GPU only.  Its flag waits are bounded; a short bound here keeps a broken
     # fabric path from eating the extras' deadline, and once ANY rank has seen it fail every rank stops timing it (the ranks
     # agree through a max-reduce, so they keep making the same collective calls).
-    os.environ.setdefault("MOJO_HIP_PEER_TIMEOUT_MS", "3000")
+    if "MOJO_HIP_PEER_TIMEOUT_MS" not in os.environ:
+        L.load().mojo_hip_peer_set_timeout_ms(3000)
     direct_state = {"off": False}
+    if world > 1:
+        # what a serving engine does at start-up: decide the exchange for the shapes it will run, OUTSIDE any step
+        # (comm/select.py warm(): self-test of the direct exchange once per group, both paths timed per payload)
+        from mojo_opset_amd.comm import select
+        import torch.distributed as dist
+        try:
+            with_direct(None, lambda: select.warm(dist.group.WORLD, [
+                (op_, m_, k_ // world, n_, dt) for k_, n_ in ((28672, 8192), (8192, 8192)) for m_ in (1024, 4096, 8192)
+                for op_ in ("gemm_all_reduce", "gemm_reduce_scatter")], device))
+        except Exception as e:
+            out["warm_error"] = repr(e)
 
     def direct_variant(fn):
         """(seconds | None, error | None) of one direct-exchange case, identical verdict on every rank."""
@@ -482,8 +502,7 @@ def bench_compute_comm(device, world, rank):
         try:
             t = with_direct("1", fn)
             from mojo_opset_amd.comm import peer
-            for ex in peer._CACHE.values():
-                ex.check()
+            peer.check_all()
         except Exception as e:
             err = repr(e)
         bad = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
@@ -528,7 +547,7 @@ def bench_compute_comm(device, world, rank):
                     elif variant == "auto":            # what a user gets with no switch set: the selector's cached choice
                         from mojo_opset_amd.comm import select
                         if direct_state["off"]:
-                            select._SELF_TEST[select._key(op._group())] = (False, "disabled: the direct exchange failed earlier in this run")
+                            select.disable_direct(op._group(), "disabled: the direct exchange failed earlier in this run")
                         t = with_direct(None, lambda: timed(lambda: op(x)))
                         picks = [r for r in select.report() if r["op"] == {"gemm_allreduce": "gemm_all_reduce", "gemm_reducescatter": "gemm_reduce_scatter"}[name]
                                  and r["payload_bucket_MB"] == select.bucket(payload) / 2 ** 20]

@@ -60,8 +60,12 @@ def _comm_summary(full):
     return out
 
 
-def compact_line(full):
-    """The contract fields of ``full`` and nothing else; raises if the result would not fit the driver's parser."""
+def compact_line(full, strict=False):
+    """The contract fields of ``full`` and nothing else, ALWAYS as a line the driver can parse (a missing field
+    or an oversized block used to raise before anything was printed, i.e. rank 0 died without a result line).  A missing
+    contract field is filled with ``None`` and named under ``"incomplete"``; a line above ``MAX_LINE_BYTES`` drops its
+    optional blocks one by one (``comm``, ``roofline_group_gemm``, ``cpu_baseline``, then long strings) and says so under
+    ``"dropped"``.  ``strict=True`` (the unit tests) raises instead."""
     line = {k: _num(full[k]) for k in CONTRACT_KEYS if k in full}
     if isinstance(line.get("config"), dict):
         line["config"] = {k: _clip(v, 200) for k, v in line["config"].items()}
@@ -78,10 +82,35 @@ def compact_line(full):
         line["extras_file"] = full["extras_file"]
     missing = [k for k in REQUIRED if k not in line]
     if missing:
-        raise ValueError(f"result line lacks contract fields: {missing}")
+        if strict:
+            raise ValueError(f"result line lacks contract fields: {missing}")
+        for k in missing:
+            line[k] = None
+        line["incomplete"] = missing
     text = json.dumps(line, separators=(",", ":"))
     if len(text.encode()) > MAX_LINE_BYTES:
-        raise ValueError(f"result line is {len(text.encode())} bytes; the driver parses at most {MAX_LINE_BYTES}")
+        if strict:
+            raise ValueError(f"result line is {len(text.encode())} bytes; the driver parses at most {MAX_LINE_BYTES}")
+        dropped = []
+        for victim in ("comm", "roofline_group_gemm", "cpu_baseline"):
+            if victim in line and len(text.encode()) > MAX_LINE_BYTES:
+                del line[victim]
+                dropped.append(victim)
+                line["dropped"] = dropped
+                text = json.dumps(line, separators=(",", ":"))
+        clip = 120
+        while len(text.encode()) > MAX_LINE_BYTES and clip >= 15:          # long strings, shorter and shorter
+            keep = ("metric", "unit", "dtype", "data", "scaling")            # what the driver matches on is never clipped
+            line = {k: (v if k in keep else {kk: _clip(vv, clip) for kk, vv in v.items()} if isinstance(v, dict) else _clip(v, clip))
+                    for k, v in line.items()}
+            line["dropped"] = dropped + [f"strings clipped to {clip}"]
+            text = json.dumps(line, separators=(",", ":"))
+            clip //= 2
+        if len(text.encode()) > MAX_LINE_BYTES:                             # last resort: the bare contract scalars
+            line = {k: (line.get(k) if k in ("metric", "unit", "dtype", "data", "scaling") or not isinstance(line.get(k), (dict, list, str))
+                        else _clip(str(line.get(k)), 60)) for k in CONTRACT_KEYS}
+            line["dropped"] = ["everything but the contract scalars"]
+            text = json.dumps(line, separators=(",", ":"))
     return text
 
 
@@ -97,7 +126,7 @@ def emit(full, out=None, extras_path=None):
         full["extras_file"] = os.path.basename(extras_path)
     except OSError as e:                     # a read-only tree must not cost the result line
         full["extras_file"] = f"not written: {e!r}"
-    text = compact_line(full)                # validate BEFORE anything is printed
+    text = compact_line(full)                # (never raises: degrades, see compact_line)
     out.write("EXTRAS " + json.dumps(full, separators=(",", ":")) + "\n")
     out.write(text + "\n")
     out.flush()

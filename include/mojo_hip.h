@@ -39,6 +39,21 @@ enum mojo_status {
 const char* mojo_hip_version(void);
 const char* mojo_hip_last_error(void);
 
+/* ---- Run-time switches (MOJO_HIP_* environment variables; the table is INTEGRATION.md section 5).  The reference reads its
+ *      switches where it uses them (`MOJO_BACKEND` in `MojoOperator.__new__`, core/operator.py:45-47); a native library
+ *      cannot afford getenv() per launch, so every switch is LATCHED the first time a launcher reads it and
+ *      `mojo_hip_reload_env()` drops all latched values (the next call re-reads the environment).  Call it after changing a
+ *      variable, with no operator call in flight.  `mojo_hip_switches()` writes "NAME=value" (space-separated, "NAME=" when
+ *      unset) for every switch read so far into `buf` and returns their count.  `mojo_hip_last_launch()`: a short description
+ *      of the kernel form the calling thread's last operator call launched ("decode_mfma:paired:nt", "gemm256:staged:KN",
+ *      ...) — a debug / test query with which an A/B test proves that its two legs took different forms;
+ *      `mojo_hip_launch_history(clear)`: the same notes of every launch of this thread since the last clear, '|'-separated
+ *      (a composite operator — absorb projection, latent attention, output projection — leaves several).               */
+void mojo_hip_reload_env(void);
+int64_t mojo_hip_switches(char* buf, int64_t capacity);
+const char* mojo_hip_last_launch(void);
+const char* mojo_hip_launch_history(int clear);
+
 /* ---- MojoStorePagedKVCache (core/operators/kv_cache.py:104-171; replaces store_paged_kv(),
  *      backends/ttx/operators/kv_cache.py:40-46).  Bit-exact copy, token-major -> head-major.
  *      plan rows = (src_token_start, dst_block_id, dst_block_offset, chunk_len) int32.          */
@@ -405,12 +420,14 @@ int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decompressed, co
  *      also stores the result over the own block and raises this rank's kind-1 flag at every peer when the launch is done.
  *      gather: for every other rank p, after its kind-1 flag: rows [rows*p/ws, rows*(p+1)/ws) of the [rows, n] chunk at
  *      chunk_offset_bytes of rank p's data area -> the same rows of dst.
- *      Every wait is bounded (MOJO_HIP_PEER_TIMEOUT_MS, default 20 s): on expiry the sticky error word is set, the
+ *      Every wait is bounded (MOJO_HIP_PEER_TIMEOUT_MS, default 20 s; mojo_hip_peer_set_timeout_ms overrides it for the
+ *      steps enqueued afterwards and returns the previous override, 0 = none): on expiry the sticky error word is set, the
  *      affected output is filled with NaN and the grid drains; mojo_hip_peer_error reads (and clears) the word.        */
 int64_t mojo_hip_peer_ctrl_bytes(void);
 int64_t mojo_hip_peer_max_ranks(void);
 int64_t mojo_hip_peer_max_chunks(void);
 int64_t mojo_hip_peer_handle_bytes(void);
+int64_t mojo_hip_peer_set_timeout_ms(int64_t milliseconds);
 int mojo_hip_peer_alloc(void** ptr_out, int64_t bytes, int uncached);
 int mojo_hip_peer_free(void* ptr);
 int mojo_hip_peer_export(void* ptr, void* handle_out);

@@ -31,6 +31,10 @@ _I64x3 = c_int64 * 3
 SIGNATURES = {
     "mojo_hip_version": (c_char_p, []),
     "mojo_hip_last_error": (c_char_p, []),
+    "mojo_hip_reload_env": (None, []),
+    "mojo_hip_switches": (c_int64, [c_char_p, _I]),
+    "mojo_hip_last_launch": (c_char_p, []),
+    "mojo_hip_launch_history": (c_char_p, [c_int]),
     "mojo_hip_store_paged_kv_plan": (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mojo_hip_store_paged_kv_layout": (c_int, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I,
                                                _I, _I, _I, _P]),
@@ -80,6 +84,7 @@ SIGNATURES = {
     "mojo_hip_peer_max_ranks": (c_int64, []),
     "mojo_hip_peer_max_chunks": (c_int64, []),
     "mojo_hip_peer_handle_bytes": (c_int64, []),
+    "mojo_hip_peer_set_timeout_ms": (c_int64, [_I]),
     "mojo_hip_peer_alloc": (c_int, [_P, _I, c_int]),
     "mojo_hip_peer_free": (c_int, [_P]),
     "mojo_hip_peer_export": (c_int, [_P, _P]),
@@ -133,6 +138,32 @@ def load():
         _check_source_hash(handle, path)
         _lib = handle
     return _lib
+
+
+def reload_env() -> None:
+    """Make the library re-read its MOJO_HIP_* switches (they are latched at first use: include/mojo_hip.h)."""
+    load().mojo_hip_reload_env()
+
+
+def last_launch() -> str:
+    """The kernel form this thread's last operator call launched (debug / A-B tests)."""
+    return load().mojo_hip_last_launch().decode()
+
+
+def launch_history(clear: bool = False) -> str:
+    """'|'-separated kernel forms of this thread's launches since the last clear (debug / A-B tests)."""
+    return load().mojo_hip_launch_history(1 if clear else 0).decode()
+
+
+def switches() -> dict:
+    """{name: value or None} of every switch the library has read so far."""
+    buf = ctypes.create_string_buffer(4096)
+    load().mojo_hip_switches(buf, len(buf))
+    out = {}
+    for item in buf.value.decode().split():
+        name, _, val = item.partition("=")
+        out[name] = int(val) if val else None
+    return out
 
 
 def built_with_experiments() -> bool:

@@ -1,12 +1,12 @@
 """HIP<Op> classes of the paged attention family."""
 import math
-import os
 from typing import Optional
 
 import torch
 
 from ....core.operators.attention import (MojoPagedDecodeGQA, MojoPagedPrefillGQA, assert_paged_decode_contract,
                                           assert_paged_prefill_contract)
+from .... import switches
 from .. import lib as L
 
 _ROCM = ["rocm"]
@@ -19,7 +19,7 @@ def _validate_tables() -> bool:
     a row is computed over zero K/V (the kernel's treatment of every negative page id).  The same switch checks the
     ``max_total_seq_len`` / ``max_q_len`` hints against the device-side lengths (a length above its hint is truncated
     to the hint by the kernels)."""
-    return os.environ.get("MOJO_HIP_VALIDATE", "0") == "1"
+    return switches.get("MOJO_HIP_VALIDATE", "0") == "1"
 
 
 def _capturing(t: torch.Tensor) -> bool:

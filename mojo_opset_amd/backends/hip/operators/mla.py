@@ -1,12 +1,12 @@
 """HIP<Op> classes of the paged MLA pair (weight-absorbed formulation, see csrc/mla_attn.hip)."""
 import math
-import os
 from typing import Optional
 
 import torch
 
 from ....core.operators.attention import assert_paged_decode_contract, assert_paged_prefill_contract
 from ....core.operators.mla import MojoPagedDecodeMLA, MojoPagedPrefillMLA
+from .... import switches
 from .. import lib as L
 
 _ROCM = ["rocm"]
@@ -41,7 +41,7 @@ def _absorbed_k_major(op, proj: torch.Tensor, heads: int, nope: int, vdim: int, 
         w = proj.view(heads, nope + vdim, r)[:, :nope, :].transpose(1, 2).contiguous()
         cached = (key, w)
         op._hip_w_kn_t = cached
-    elif os.environ.get("MOJO_HIP_VALIDATE", "0") == "1":
+    elif switches.get("MOJO_HIP_VALIDATE", "0") == "1":
         live = proj.view(heads, nope + vdim, r)[:, :nope, :].transpose(1, 2)
         if not torch.equal(cached[1], live):
             raise RuntimeError("HIP MLA: kv_b_proj changed without a version bump (e.g. through .data); call "
@@ -149,14 +149,14 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     nope, rope, vdim, r = op.qk_nope_head_dim, op.qk_rope_head_dim, op.v_head_dim, op.kv_lora_rank
     if not lib.mojo_hip_mla_prefill_supported(nope, rope, vdim, L.dtype_code(query.dtype)):
         return None
-    if os.environ.get("MOJO_HIP_MLA_PREFILL", "decompress") == "absorbed":
+    if switches.get("MOJO_HIP_MLA_PREFILL", "decompress") == "absorbed":
         return None
     dev, dt = query.device, query.dtype
     batch, width = block_tables.shape
     page = ckv_cache.shape[2]
     es = query.element_size()
     kv_cols = heads * (nope + vdim)
-    budget = int(os.environ.get("MOJO_HIP_MLA_PREFILL_BYTES", str(1 << 30)))
+    budget = switches.get_int("MOJO_HIP_MLA_PREFILL_BYTES", 1 << 30)
     # host-side bound of one sequence's keys (lengths stay on the device: no sync)
     per_seq = width * page
     if max_total_seq_len is not None:
@@ -184,7 +184,7 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     cap = seqs_per_slice * per_seq
     if cu_total_seq_lens is None:
         cap = min(cap, tq)
-    if os.environ.get("MOJO_HIP_VALIDATE", "0") == "1" and not torch.cuda.is_current_stream_capturing():
+    if switches.get("MOJO_HIP_VALIDATE", "0") == "1" and not torch.cuda.is_current_stream_capturing():
         cu = (cu_q if cu_kv is None else cu_kv).to(torch.int64)
         longest = int((cu[1:] - cu[:-1]).max()) if batch > 0 else 0
         if longest > per_seq:
@@ -194,11 +194,11 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     kpe_flat = torch.empty(cap, rope, dtype=dt, device=dev)
     kv = torch.empty(cap, kv_cols, dtype=dt, device=dev)
     count = torch.empty(1, dtype=torch.int32, device=dev)
-    # Head groups (opt-in, MOJO_HIP_MLA_PREFILL_GROUPS; measured slower by default, see _head_groups): the decompression of
+    # Head groups (opt-in, `op.prefill_head_groups`; measured slower by default, see _head_groups): the decompression of
     # group g + 1 runs on a side stream beside the attention of group g.  Each group's GEMM fills its own
     # columns of the image (`group_gemm_strided`, output row stride = the whole row), the attention launch covers the
     # group's heads only.
-    groups = _head_groups(heads, cap)
+    groups = _head_groups(heads, getattr(op, "prefill_head_groups", None))
     cols_g = (heads // groups) * (nope + vdim)
     wss = [torch.empty(lib.mojo_hip_group_gemm_workspace_bytes(1), dtype=torch.uint8, device=dev) for _ in range(groups)]
     main = torch.cuda.current_stream(dev)
@@ -258,16 +258,16 @@ def _side_stream(dev):
     return st
 
 
-def _head_groups(heads: int, keys_capacity: int) -> int:
+def _head_groups(heads: int, wanted) -> int:
     """How many head groups the decompression / attention pipeline uses.  Default ONE (a single GEMM, then a single attention
     launch): measured on an MI355X at DeepSeek-V3 dims (scripts/probes/mla_prefill_groups_ab.py, round 4; same bits for every
     group count): 4 x 512 211 us as one group, 237 us as two, 235-246 us as four; + 2048 cached 1 000 / 971 / 1 007 us.  The
     two kernels do not share the chip — the GEMM's 256 x 256 tiles occupy every CU, a half-width GEMM runs at the same
     tiles per second — so the side stream buys at most 3 % on the long case and costs 12 % on the short one.
-    ``MOJO_HIP_MLA_PREFILL_GROUPS=<n>`` selects the pipeline."""
-    env = os.environ.get("MOJO_HIP_MLA_PREFILL_GROUPS")
-    if env:
-        g = max(1, int(env))
+    ``op.prefill_head_groups = <n>`` selects the pipeline (an attribute, not an environment switch: an experiment kept for
+    its test, not a tuning knob)."""
+    if wanted:
+        g = max(1, int(wanted))
         while g > 1 and heads % g:
             g -= 1
         return g
@@ -300,12 +300,12 @@ class HIPPagedDecodeMLA(_AbsorbedWeightCache, MojoPagedDecodeMLA):
         """``max_total_seq_len`` (extension, kw-only host int): upper bound of any sequence's length; only the
         golden-rounding route uses it (it sizes the decompressed K/V image)."""
         assert_paged_decode_contract(block_tables, total_seq_lens)
-        route = getattr(self, "decode_route", None) or os.environ.get("MOJO_HIP_MLA_DECODE", "absorbed")
+        route = getattr(self, "decode_route", None) or switches.get("MOJO_HIP_MLA_DECODE", "absorbed")
         if route == "golden" and query.shape[0] > 0 and query.is_cuda \
                 and self.kv_b_proj.dtype == query.dtype == compressed_kv_cache.dtype == k_pe_cache.dtype \
                 and compressed_kv_cache.stride(3) == 1 and k_pe_cache.stride(3) == 1:
             L.require_cuda(query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables, self.kv_b_proj)
-            if os.environ.get("MOJO_HIP_VALIDATE", "0") == "1" and block_tables.shape[1] > 0 \
+            if switches.get("MOJO_HIP_VALIDATE", "0") == "1" and block_tables.shape[1] > 0 \
                     and bool(((total_seq_lens > 0) & (block_tables[:, 0] < 0)).any()):
                 raise ValueError("Paged decode requires a valid block table for rows with kv lens > 0.")
             out = _decode_decompressed(self, query, compressed_kv_cache, k_pe_cache, total_seq_lens, block_tables,

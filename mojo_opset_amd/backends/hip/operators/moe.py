@@ -1,10 +1,10 @@
 """HIP<Op> classes of the MoE routing ops: gating, dispatch, experts, combine.
 No host synchronisation anywhere: token counts stay on the device and feed the grouped GEMM as they are."""
-import os
 
 import torch
 
 from ....core.operators.moe import MojoExperts, MojoMoE, MojoMoECombine, MojoMoEDispatch, MojoMoEGating
+from .... import switches
 from .. import lib as L
 
 _ROCM = ["rocm"]
@@ -106,13 +106,13 @@ class HIPExperts(MojoExperts):
     def _fused_up_swiglu(self, x, w, counts, act, inter) -> bool:
         """First projection with the SwiGLU applied to the accumulators (same rounding points as the two-kernel path: the
         [M, 2I] product never goes to HBM).  False when the shape is outside the fused kernel's preconditions."""
-        if os.environ.get("MOJO_HIP_EXPERTS_FUSED", "1") == "0" or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[0] == 0:
+        if switches.get("MOJO_HIP_EXPERTS_FUSED", "1") == "0" or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[0] == 0:
             return False
         # A decode step (at most 64 rows per expert on average): the projections are weight streams, and the grouped GEMM
         # has a 64-row streaming form for ragged groups (csrc/gemm_skinny.hip, RAGGED) that the fused 256-row tile kernel
         # cannot use; the [M, 2I] round trip of the two-kernel path is a few hundred KB there.
         if (x.shape[0] <= 64 * w.shape[0] and x.shape[1] % 128 == 0 and w.shape[1] % 64 == 0 and w.shape[0] >= 2
-                and os.environ.get("MOJO_HIP_GEMM_SKINNY_RAGGED", "1") != "0"):
+                and switches.get_int("MOJO_HIP_GEMM_SKINNY", 31) & 2):        # (bit 2 = the ragged skinny form, csrc/gemm.h)
             return False
         lib = L.load()
         groups = w.shape[0]

@@ -18,10 +18,15 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from .. import switches
 from ..backends.hip import lib as L
 
 _LOCK = threading.RLock()
 _CACHE: Dict[Tuple[object, int], "PeerExchange"] = {}
+# Captured twins that a graph may hold (they were handed out under capture) and whose eager exchange has since been
+# replaced by a larger one: kept alive — and checked — until release_all().  A captured launch has the twin's raw peer
+# pointers baked in; freeing it would make the next replay read and write freed or re-mapped IPC memory on every rank.
+_RETIRED_TWINS: List["PeerExchange"] = []
 
 
 class _DeviceBytes:
@@ -45,6 +50,7 @@ class PeerExchange:
     def __init__(self, group, capacity_bytes: int, captured: bool = False):
         self.captured = bool(captured)
         self.halves = 1 if captured else 2
+        self.handed_out_under_capture = False               # (twins) a graph may hold this exchange's pointers
         self.twin: Optional["PeerExchange"] = None
         self.group = group
         self.ws = dist.get_world_size(group)
@@ -59,7 +65,7 @@ class PeerExchange:
         total = self.halves * self.capacity + 4096 + self.ctrl_bytes
         self._local = ctypes.c_void_p()
         self._opened: List[ctypes.c_void_p] = []
-        uncached = os.environ.get("MOJO_HIP_PEER_UNCACHED", "1") != "0"
+        uncached = True                                     # (falls back to plain hipMalloc when the uncached form cannot be exported)
         handle = (ctypes.c_char * int(lib.mojo_hip_peer_handle_bytes()))()
         setup_error = None
         try:
@@ -178,17 +184,23 @@ class PeerExchange:
                                             nbytes, L.ptr(dst), dst_stride_bytes, 1 if include_self else 0, stream), "peer pull")
 
     def check(self, clear: bool = True) -> None:
-        """Raise if a wait of an earlier call timed out (its outputs were poisoned with NaN).  Synchronises."""
+        """Raise if a wait of an earlier call — eager, or a replay of a graph captured over the twin — timed out (its outputs
+        were poisoned with NaN).  Synchronises."""
+        if self.twin is not None:
+            self.twin.check(clear)
         err = ctypes.c_int32(0)
         L.check(L.load().mojo_hip_peer_error(ctypes.c_void_p(self._local.value + self._flag_off), 1 if clear else 0,
                                              ctypes.byref(err)), "peer error word")
         if err.value:
-            raise RuntimeError("direct peer exchange: a wait for a peer's flag timed out (MOJO_HIP_PEER_TIMEOUT_MS); the "
-                               "affected outputs were filled with NaN")
+            raise RuntimeError(f"direct peer exchange ({'captured twin' if self.captured else 'eager'}): a wait for a peer's flag "
+                               "timed out (MOJO_HIP_PEER_TIMEOUT_MS); the affected outputs were filled with NaN")
 
     def close(self) -> None:
         if self.twin is not None:
-            self.twin.close()
+            if self.twin.handed_out_under_capture:
+                _RETIRED_TWINS.append(self.twin)            # a graph may replay over it: keep it mapped (see _RETIRED_TWINS)
+            else:
+                self.twin.close()
             self.twin = None
         lib = L.load()
         for p in self._opened:
@@ -207,6 +219,23 @@ def captured_ready(group, need_bytes: int) -> bool:
         return any(k == key and cap >= need_bytes and ex.twin is not None for (k, cap), ex in _CACHE.items())
 
 
+def check_all(group=None, clear: bool = True) -> None:
+    """Raise if any exchange of ``group`` (every group when None) recorded a timed-out wait: the eager exchanges, their
+    captured twins and the retired twins old graphs may still replay over.  Call it after a graph replay (or any step) whose
+    outputs matter: a timed-out wait poisons its outputs with NaN and makes every later wait of that exchange give up at
+    once, so one unnoticed timeout would otherwise turn every later replay into silent NaN.  Synchronises."""
+    with _LOCK:
+        exs = [ex for ex in list(_CACHE.values()) + list(_RETIRED_TWINS) if group is None or ex.group is group]
+    first = None
+    for ex in exs:
+        try:
+            ex.check(clear)
+        except RuntimeError as e:                            # read (and clear) them all before reporting the first
+            first = first or e
+    if first is not None:
+        raise first
+
+
 def get_exchange(group, need_bytes: int) -> PeerExchange:
     """The group's exchange with at least ``need_bytes`` per parity half; (re)built collectively when it must grow, so every
     rank has to ask with the same sizes in the same order (they do: the ops are SPMD).  Under HIP-graph capture the
@@ -220,6 +249,7 @@ def get_exchange(group, need_bytes: int) -> PeerExchange:
                 if not capturing:
                     return ex
                 if ex.twin is not None:
+                    ex.twin.handed_out_under_capture = True
                     return ex.twin
         if capturing:
             raise NotImplementedError("direct peer exchange under graph capture: no captured buffer of this size yet — run the "
@@ -228,19 +258,24 @@ def get_exchange(group, need_bytes: int) -> PeerExchange:
             torch.cuda.synchronize()
             dist.barrier(group=group)           # nobody may still be reading the buffer that is about to go away
             _CACHE.pop((k, cap)).close()
-        cap = max(int(need_bytes), int(os.environ.get("MOJO_HIP_PEER_MIN_BYTES", str(64 << 20))))
+        cap = max(int(need_bytes), switches.get_int("MOJO_HIP_PEER_MIN_BYTES", 64 << 20))
         ex = PeerExchange(group, cap)
-        if os.environ.get("MOJO_HIP_PEER_CAPTURE_TWIN", "1") != "0":
-            ex.twin = PeerExchange(group, cap, captured=True)       # the graph-capturable twin, built while building is allowed
+        ex.twin = PeerExchange(group, cap, captured=True)           # the graph-capturable twin, built while building is allowed
         _CACHE[(key, ex.capacity)] = ex
         return ex
 
 
 def release_all() -> None:
+    """Free every exchange, INCLUDING twins that captured graphs may hold: destroy those graphs first."""
     with _LOCK:
         for ex in _CACHE.values():
+            if ex.twin is not None:
+                ex.twin.handed_out_under_capture = False
             ex.close()
         _CACHE.clear()
+        for tw in _RETIRED_TWINS:
+            tw.close()
+        _RETIRED_TWINS.clear()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -273,9 +308,9 @@ def gemm_all_reduce_direct(engine, x2: torch.Tensor, weight, bias, trans_weight:
     epoch, base = ex.begin_call()
     out = torch.empty(m, n, dtype=x2.dtype, device=x2.device)
     main = torch.cuda.current_stream(x2.device)
-    chunks = plan_row_chunks(m)
-    assert len(chunks) <= ex.max_chunks
     ws, rank = ex.ws, ex.rank
+    chunks = plan_row_chunks(m, n, ws, 1, es)
+    assert len(chunks) <= ex.max_chunks
     for c, (lo, hi) in enumerate(chunks):
         off = base + lo * n * es
         rows = hi - lo
@@ -306,7 +341,7 @@ def gemm_reduce_scatter_direct(engine, x2: torch.Tensor, weight, bias, trans_wei
     epoch, base = ex.begin_call()
     out = torch.empty(ml, n, dtype=x2.dtype, device=x2.device)
     main = torch.cuda.current_stream(x2.device)
-    chunks = plan_row_chunks(ml)
+    chunks = plan_row_chunks(ml, n, ws, ws, es)
     assert len(chunks) <= ex.max_chunks
     for c, (lo, hi) in enumerate(chunks):
         rc = hi - lo
@@ -337,7 +372,7 @@ def all_gather_gemm_direct(engine, x2: torch.Tensor, weight, bias, trans_weight:
     ex.local_view(base, ml, k, x2.dtype).copy_(x2)
     ex.signal(0, 0, epoch, L.stream_of(x2))
     out = torch.empty(ws * ml, n, dtype=x2.dtype, device=x2.device)
-    chunks = plan_row_chunks(ml)
+    chunks = plan_row_chunks(ml, n, ws, ws, es, link_cols=k)
     ex.side.wait_stream(main)
     stages = []
     for lo, hi in chunks:

@@ -18,11 +18,15 @@ xGMI transfer of chunk c overlaps the matrix work of chunk c+1:
 The pipelines only orchestrate; the matrix product is delegated to a `GemmEngine` (the hip backend passes
 the C-ABI GEMM; the multi-process CPU tests pass a torch engine over gloo).
 """
-import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+from .. import switches
+
+CHIP_TILE_SLOTS = 256          # workgroups of the 256 x 256 GEMM tile kernel resident at once on an MI355X (one per CU)
+MAX_CHUNKS = 8
 
 
 class GemmEngine:
@@ -43,14 +47,40 @@ class GemmEngine:
         return weight.shape[1] if trans_weight else weight.shape[0]
 
 
-def plan_row_chunks(rows: int, max_chunks: Optional[int] = None, min_rows: int = 512) -> List[Tuple[int, int]]:
-    """Split ``rows`` into at most ``max_chunks`` contiguous ranges of >= ``min_rows`` rows (multiples of 256 so
-    every chunk is whole GEMM tiles); ``MOJO_HIP_COMM_CHUNKS`` overrides the chunk count."""
+def chunk_count(rows: int, n_cols: int, world: int = 1, gemm_rows_per_row: int = 1, elt_bytes: int = 2,
+                link_cols: Optional[int] = None) -> int:
+    """How many row chunks a pipeline cuts ``rows`` into — a function of the payload and the world size (round 5; it was
+    the constant 4).  Two floors on the rows of a chunk, then as many chunks as fit (at most ``MAX_CHUNKS``):
+
+    * MATRIX WORK: a chunk's GEMM is its own launch, and a launch of the 256 x 256 tile kernel takes one round of the chip
+      whether it has 64 tiles or 256 (one workgroup per CU).  Four chunks of 1024 rows at N = 8192 are four rounds of 128
+      tiles where two chunks of 2048 rows are two full rounds: chunking finer than one full round DOUBLES the matrix time it
+      is meant to hide the exchange behind.  ``gemm_rows_per_row`` = GEMM rows per planned row (reduce-scatter, all-gather
+      and all-to-all plan over the M / ws rows one rank keeps, and a chunk's GEMM covers that sub-chunk of EVERY rank).
+    * EXCHANGE: the message one rank moves to / from ONE peer for a chunk (the ring's step, the direct exchange's pull) is
+      the chunk's payload / ws; below ~512 KiB a transfer is latency-, not bandwidth-bound on xGMI.  ``link_cols`` = columns
+      of the tensor that travels when that is not the GEMM's output (all-gather moves the [rows, K] input).
+    """
+    if rows <= 0:
+        return 0
+    tiles_per_256_rows = max(1, gemm_rows_per_row) * max(1, -(-n_cols // 256))
+    rows_round = -(-CHIP_TILE_SLOTS // tiles_per_256_rows) * 256
+    rows_link = -(-(512 << 10) * max(1, world) // max(1, gemm_rows_per_row * (link_cols or n_cols) * elt_bytes))
+    floor_rows = max(256, rows_round, -(-rows_link // 256) * 256)
+    return max(1, min(MAX_CHUNKS, rows // floor_rows))
+
+
+def plan_row_chunks(rows: int, n_cols: int = 0, world: int = 1, gemm_rows_per_row: int = 1, elt_bytes: int = 2,
+                    link_cols: Optional[int] = None) -> List[Tuple[int, int]]:
+    """Split ``rows`` into contiguous ranges of whole GEMM tiles (multiples of 256 rows); the count is ``chunk_count`` of the
+    payload and world size, ``MOJO_HIP_COMM_CHUNKS=<n>`` forces it (still at least 512 rows per chunk unless n = 1)."""
     if rows <= 0:
         return []
-    env = os.environ.get("MOJO_HIP_COMM_CHUNKS")
-    want = int(env) if env else (4 if max_chunks is None else max_chunks)
-    want = max(1, min(want, rows // min_rows if rows >= min_rows else 1))
+    forced = switches.get_int("MOJO_HIP_COMM_CHUNKS", 0)
+    if forced > 0:
+        want = max(1, min(forced, rows // 512 if rows >= 512 else 1))
+    else:
+        want = chunk_count(rows, n_cols if n_cols > 0 else 8192, world, gemm_rows_per_row, elt_bytes, link_cols)
     step = -(-rows // want)
     step = -(-step // 256) * 256 if rows >= 256 else step
     out, lo = [], 0
@@ -93,11 +123,14 @@ def _host_staged(group, t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
+STAGED_ASYNC = True            # (module attribute, not an environment switch: only the single-GPU multi-rank tests take this route)
+
+
 def _staged_async() -> bool:
     """On the host-staged route the collective itself is still asynchronous by default (gloo's own threads reduce chunk c
     while the GEMM of chunk c + 1 runs on the device, several chunks in flight, waited for in order at the end — the same
-    issue / wait ordering the RCCL route has).  ``MOJO_HIP_COMM_GLOO_ASYNC=0`` makes it synchronous."""
-    return os.environ.get("MOJO_HIP_COMM_GLOO_ASYNC", "1") != "0"
+    issue / wait ordering the RCCL route has).  ``pipelines.STAGED_ASYNC = False`` makes it synchronous."""
+    return STAGED_ASYNC
 
 
 def _all_reduce(t, group):
@@ -156,7 +189,8 @@ def gemm_all_reduce(engine: GemmEngine, x, weight, bias, trans_weight, group) ->
         engine(x2, weight, bias, trans_weight, out=out)
         return out.reshape(*x.shape[:-1], n)
     works = []
-    for lo, hi in plan_row_chunks(m):
+    ws, _ = _group_info(group)
+    for lo, hi in plan_row_chunks(m, n, ws, 1, x.element_size()):
         engine(x2[lo:hi], weight, bias, trans_weight, out=out[lo:hi])
         works.append(_all_reduce(out[lo:hi], group))
     for w in works:
@@ -186,7 +220,7 @@ def gemm_reduce_scatter(engine: GemmEngine, x, weight, bias, trans_weight, group
     ml = m // ws                                   # rows every rank keeps
     out = torch.empty(ml, n, dtype=x.dtype, device=x.device)
     works, keep = [], []
-    for lo, hi in plan_row_chunks(ml):
+    for lo, hi in plan_row_chunks(ml, n, ws, ws, x.element_size()):
         rc = hi - lo
         buf = torch.empty(ws * rc, n, dtype=x.dtype, device=x.device)   # [dest rank][rc rows]
         engine(x2, weight, bias, trans_weight, out=buf, rows=ws * rc, a_map=(rc, ml, lo))
@@ -213,7 +247,7 @@ def all_gather_gemm(engine: GemmEngine, x, weight, bias, trans_weight, group, ga
     x2 = _flatten(x)
     ml, k = x2.shape
     out = torch.empty(ws * ml, n, dtype=x.dtype, device=x.device)
-    chunks = plan_row_chunks(ml)
+    chunks = plan_row_chunks(ml, n, ws, ws, x.element_size(), link_cols=k)
     stages = []
     for lo, hi in chunks:                          # enqueue every gather first: they run back to back on the comm stream
         buf = torch.empty(ws * (hi - lo), k, dtype=x.dtype, device=x.device)
@@ -275,7 +309,7 @@ def gemm_all2all(engine: GemmEngine, x, weight, bias, trans_weight, group, scatt
     ml = m // ws                                   # rows of the flattened product every destination receives from this rank
     recv = torch.empty(m, n, dtype=x.dtype, device=x.device)          # [source rank][ml rows]
     works, keep = [], []
-    for lo, hi in plan_row_chunks(ml):
+    for lo, hi in plan_row_chunks(ml, n, ws, ws, x.element_size()):
         rc = hi - lo
         buf = torch.empty(ws * rc, n, dtype=x.dtype, device=x.device)  # [dest rank][rc rows]
         engine(x2, weight, bias, trans_weight, out=buf, rows=ws * rc, a_map=(rc, ml, lo))

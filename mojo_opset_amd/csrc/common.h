@@ -63,6 +63,38 @@ void set_error(const char* fmt, ...);
     }                                                                                   \
   } while (0)
 
+// run-time switches -----------------------------------------------------------------------
+// ONE semantics for every MOJO_HIP_* switch the library reads (round 5): a call site takes its value
+// from the environment the first time it runs and LATCHES it; `mojo_hip_reload_env()` drops every latched value, so the
+// next call of every site reads the environment again.  A launcher therefore costs one relaxed atomic load per switch, no
+// launcher ever calls getenv() concurrently with a setenv() of the host program (reload when no operator call is in
+// flight), and a value can still be changed between two calls of one process (tests, A/B probes: set the variable, reload).
+// Values are decimal integers — or a short word (MOJO_HIP_MLA_KERNEL=ps), read as its first four characters packed into an
+// integer (`switch_word("ps")`); an unset or empty variable means "the default".  `mojo_hip_switches()` lists what was read.
+struct EnvSwitch {
+  const char* name;
+  std::atomic<uint64_t> state{0};          // bits 63..33 generation the value was read at (0 = never), 32 present, 31..0 value
+  EnvSwitch* next = nullptr;               // registration list (for mojo_hip_switches)
+  explicit EnvSwitch(const char* n);
+};
+extern std::atomic<uint32_t> g_env_generation;
+uint64_t env_refresh(EnvSwitch& s);
+inline long long env_get(EnvSwitch& s, long long def) {
+  uint64_t st = s.state.load(std::memory_order_relaxed);
+  if (static_cast<uint32_t>(st >> 33) != g_env_generation.load(std::memory_order_relaxed)) st = env_refresh(s);
+  return ((st >> 32) & 1) ? static_cast<long long>(static_cast<int32_t>(static_cast<uint32_t>(st))) : def;
+}
+constexpr long long switch_word(const char* w) {
+  long long v = 0;
+  for (int i = 0; i < 4 && w[i]; ++i) v |= static_cast<long long>(static_cast<unsigned char>(w[i])) << (8 * i);
+  return v;
+}
+#define MOJO_SWITCH(NAME, DEF) (::mojo::env_get(*[] { static ::mojo::EnvSwitch sw_(NAME); return &sw_; }(), (DEF)))
+
+// What the last operator call of this thread launched ("decode_mfma:paired", "gemm256:staged", ...): a debug / test query
+// (`mojo_hip_last_launch()`), so that an A/B test can assert that its two legs really took two different forms.
+void note_launch(const char* fmt, ...);
+
 static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Threads per row of the RMSNorm kernels (rmsnorm.hip, and the split-K finalize that norms in gemm_skinny.hip: both must cut a
@@ -187,10 +219,9 @@ __device__ __forceinline__ void store_vec(T* p, typename vec_of<T, N>::type v) {
 // loads and stores (round 3: SwiGLU bf16 65536 x 4096 291 -> 263 us, 5.5 -> 6.1 TB/s; fp32 32768 x 4096 289 -> 261 us; tensors
 // that fit the caches measured equal or slightly worse, so small calls keep the default policy).  MOJO_HIP_STREAM_NT=0/1 forces.
 inline bool stream_nt(long long bytes_moved) {
-  if (const char* e = getenv("MOJO_HIP_STREAM_NT")) {
-    if (e[0] == '0') return false;
-    if (e[0] == '1') return true;
-  }
+  const long long f = MOJO_SWITCH("MOJO_HIP_STREAM_NT", -1);
+  if (f == 0) return false;
+  if (f == 1) return true;
   return bytes_moved >= (256LL << 20);
 }
 // streaming forms: data read once / written once (no reuse worth a cache line)

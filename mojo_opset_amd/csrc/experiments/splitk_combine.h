@@ -34,7 +34,7 @@ static __device__ unsigned g_splitk_tickets[SK_SLOTS * SK_TILES];
 // launch has more tiles than a slot holds: the caller then runs its finalize kernel
 static inline int splitk_take_slot(int64_t tiles) {
   if (tiles > SK_TILES) return -1;
-  { const char* e = getenv("MOJO_HIP_SPLITK_INLAUNCH"); if (!e || e[0] != '1') return -1; }
+  if (MOJO_SWITCH("MOJO_HIP_SPLITK_INLAUNCH", 0) != 1) return -1;
   static std::atomic<unsigned> next{0};
   return static_cast<int>(next.fetch_add(1, std::memory_order_relaxed) % SK_SLOTS);
 }

@@ -88,6 +88,16 @@ struct GemmTail {
 int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
                         int32_t* tile_start, hipStream_t s, GemmTail tail = GemmTail());
 
+// MOJO_HIP_GEMM_SKINNY: bit mask of the decode-sized (weight-stream) GEMM forms that may be taken; default all.  Without a
+// form's bit its products run on the general kernels (256 x 256 tiles / separate finalize, norm and activation launches):
+// the A/B switch of the tests that compare a fused or skinny form with the general path.
+enum : int { SKINNY_UNIFORM = 1,   // gemm_skinny_kernel: <= 128 rows per equal-sized group, [N,K] weights (also QuantGemm's 5..128-row kernel)
+             SKINNY_RAGGED = 2,    // ragged groups of <= 64 rows on average (the experts of a decode step)
+             SKINNY_GLU = 4,       // SwiGLU in the skinny kernel's epilogue (mojo_hip_gemm_swiglu)
+             SKINNY_RESNORM = 8,   // split-K slabs summed by the residual RMSNorm kernel (mojo_hip_gemm_residual_rmsnorm)
+             SKINNY_GEMV = 16 };   // QuantGemm M <= 4: v_dot4 GEMV
+inline int gemm_skinny_mask() { return static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_SKINNY", 31)); }
+
 // fast MFMA path (256x256x64 tiles); returns MOJO_EUNSUPPORTED when its preconditions do not hold
 int launch_gemm_mfma256(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
 bool gemm_mfma256_glu_ok(const GemmArgs& a, int dtype);

@@ -780,9 +780,9 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
   //    one process; kernel traces by scripts/probes/prof_stagger.sh): 4 x 512 + 2048 cached 929 -> 891 us eager, 938 -> 872
   //    under graph replay (GEMM 378 -> 370 us, attention 526 -> 500 us); 4 x 512 without a cache (4 rounds) 203 -> 202 us with
   //    the GEMM itself 88 -> 93 us; grouped products with a tile per group (the absorbed route's projections) 104 -> 112 us.
-  //    Hence the restriction to one group and >= 8 rounds.  MOJO_HIP_GEMM_STAGGER=<ticks> forces (0 = off; read per call).
-  if (const char* e = getenv("MOJO_HIP_GEMM_STAGGER")) {
-    a.stagger_ticks = atoi(e);
+  //    Hence the restriction to one group and >= 8 rounds.  MOJO_HIP_GEMM_STAGGER=<ticks> forces (0 = off).
+  if (const long long e = MOJO_SWITCH("MOJO_HIP_GEMM_STAGGER", -1); e >= 0) {
+    a.stagger_ticks = static_cast<int>(e);
   } else if (a.G == 1 && a.K / (KT_BYTES / P::EB) <= 16 && blocks >= 8 * static_cast<int64_t>(device_cu_count())) {
     a.stagger_ticks = 150;
   }
@@ -796,7 +796,7 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
     // 1001-1008, reference case 1050-1068 -> 1070-1094, K = 512 (MLA decompression) 741-755 -> 748-804: inside the run-to-run
     // spread except at short K.  The hardware's own workgroup hand-over already hides most of what the loop was meant to
     // hide, and hipcc builds the loop body with 19-20 SGPR spills; results are identical (all GEMM tests pass with it on).
-    static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_PERSIST"); return !(e && e[0] == '1'); }();
+    const bool off = MOJO_SWITCH("MOJO_HIP_GEMM_PERSIST", 0) != 1;
     const int cus = device_cu_count();
     if (!off && a.stage_rows && !a.glu && a.splitk == 1 && !epi.has_bias() && !a.ablate && blocks >= 2 * cus) {
       constexpr int LDS_P = LDS_BYTES + PERSIST_STAGE_BYTES;
@@ -812,6 +812,7 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
         hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(cus)), dim3(512), LDS_P, s, a, epi);
       }
       MOJO_CHECK_LAUNCH("gemm256(persistent)");
+      note_launch("gemm256:persistent");
       return MOJO_OK;
     }
   }
@@ -827,6 +828,8 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
     hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
   }
   MOJO_CHECK_LAUNCH("gemm256");
+  note_launch("gemm256:%s:%s%s%s", a.stage_rows ? "staged" : "direct", a.w_n == 1 ? "KN" : "NK", a.splitk > 1 ? ":splitk" : "",
+              a.stagger_ticks ? ":stagger" : "");
   return MOJO_OK;
 }
 

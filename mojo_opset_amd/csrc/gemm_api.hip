@@ -6,9 +6,10 @@
 namespace mojo {
 
 static int run_gemm(GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
-  static const int abl = [] { const char* e = getenv("MOJO_HIP_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-  a.ablate = abl;
-  { const char* e = getenv("MOJO_HIP_GEMM_ORDER"); a.tile_order = e ? atoi(e) : 0; }
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS              // timing-only ablations and the round-3 tile-order experiment (DESIGN Appendix A 7)
+  a.ablate = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_ABLATE", 0));
+  a.tile_order = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_ORDER", 0));
+#endif
   if (gemm_skinny_ok(a, dtype)) return launch_gemm_skinny(a, dtype, s);      // <= 128 rows per (equal-sized) group, [N,K] weights
   if (gemm_skinny_ragged_ok(a, dtype, m_total)) return launch_gemm_skinny_ragged(a, dtype, m_total, s);   // ragged, <= 64 rows per group on average
   if (gemm_mfma256_ok(a, dtype)) return launch_gemm_mfma256(a, dtype, m_total, s);
@@ -107,12 +108,11 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
 // against a 4096..8192-wide projection: 16-64 tiles on 256 CUs): every tile walked the whole K and the launch took the
 // same 68 us (K = 4096) from 129 to 2048 rows, 2-4 x the vendor library's time.  K is cut so that ~256 workgroups run; the
 // slices go to fp32 slabs and launch_gemm_splitk_finalize sums them in slice order (deterministic).
-// MOJO_HIP_GEMM_SPLITK256=<n> forces the split (1 = off; read per call).
+// MOJO_HIP_GEMM_SPLITK=<n> forces the split (1 = off).
 static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n) {
   if (m <= 128 || n % 4 != 0 || k % 64 != 0) return 1;
   const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), nkt = k / 64;
-  if (const char* e = getenv("MOJO_HIP_GEMM_SPLITK256")) {
-    int64_t sk = atoi(e);
+  if (int64_t sk = MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0); sk > 0) {
     if (sk > nkt / 8) sk = nkt / 8;
     return sk < 1 ? 1 : static_cast<int>(sk);
   }

@@ -158,6 +158,7 @@ int launch_gemm_generic(const GemmArgs& a, int dtype, int64_t m_total, hipStream
     default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "gemm: dtype %d not supported", dtype);
   }
   MOJO_CHECK_LAUNCH("gemm_generic");
+  note_launch("gemm_generic");
   return MOJO_OK;
 }
 

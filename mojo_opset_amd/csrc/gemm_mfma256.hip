@@ -42,13 +42,14 @@ bool gemm_mfma256_glu_ok(const GemmArgs& a, int dtype) {
 int launch_gemm_mfma256(const GemmArgs& a_in, int dtype, int64_t m_total, hipStream_t s) {
   GemmArgs a = a_in;
   MOJO_REQUIRE(gemm_mfma256_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: preconditions not met");
-  static const bool no_stage = [] { const char* e = getenv("MOJO_HIP_GEMM_STAGE_ROWS"); return e && e[0] == '0'; }();
+  const bool no_stage = MOJO_SWITCH("MOJO_HIP_GEMM_STAGE_ROWS", 1) == 0;
   a.stage_rows = (!no_stage && a.splitk == 1 && a.ldc % 8 == 0 && aligned_to(a.C, 16)) ? 1 : 0;
   MOJO_REQUIRE(!a.glu || gemm_mfma256_glu_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm_mfma256: fused SwiGLU needs I %% 128 == 0");
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
-  {  // experiments build only, MOJO_HIP_GEMM_W128=1 (read per call): four waves of 128x128 (experiments/gemm_w128.h), [N,K] weights
-    const char* e = getenv("MOJO_HIP_GEMM_W128");
-    if (e && e[0] >= '1' && e[0] <= '5' && dtype == MOJO_BF16 && a.w_k == 1 && !a.glu && a.splitk == 1 && a.K % 32 == 0 && a.K >= 128) {
+  {  // experiments build only, MOJO_HIP_GEMM_W128=1: four waves of 128x128 (experiments/gemm_w128.h), [N,K] weights
+    const long long w128 = MOJO_SWITCH("MOJO_HIP_GEMM_W128", 0);
+    const char e[2] = {static_cast<char>('0' + (w128 >= 0 && w128 <= 9 ? w128 : 0)), 0};
+    if (e[0] >= '1' && e[0] <= '5' && dtype == MOJO_BF16 && a.w_k == 1 && !a.glu && a.splitk == 1 && a.K % 32 == 0 && a.K >= 128) {
       g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias)};
       if (e[0] == '2') return w128::gemm_w128_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, 1>(a, epi, m_total, s);   // 2-4: timing-only ablations
       if (e[0] == '3') return w128::gemm_w128_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, 2>(a, epi, m_total, s);

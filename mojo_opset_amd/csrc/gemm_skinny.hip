@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_resnorm_kernel(GemmArgs a, in
 
 bool gemm_splitk_resnorm_ok(const GemmArgs& a, int dtype, const void* residual, const void* norm_w, const void* normed, const void* summed) {
   if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
-  if (const char* e = getenv("MOJO_HIP_GEMM_RESNORM")) { if (e[0] == '0') return false; }
+  if (!(gemm_skinny_mask() & SKINNY_RESNORM)) return false;
   return a.splitk > 1 && a.slab && a.N % 8 == 0 && a.N <= 16384 && a.c_rc == 0 && aligned_to(norm_w, 16) && aligned_to(normed, 16) &&
          (!residual || aligned_to(residual, 16)) && (!summed || aligned_to(summed, 16)) && (!a.bias || aligned_to(a.bias, 16)) &&
          (!a.C || aligned_to(a.C, 16));
@@ -386,19 +386,19 @@ int launch_gemm_splitk_resnorm(const GemmArgs& a, int dtype, int64_t m_total, co
 #undef RESNORM_T
 #undef RESNORM
   MOJO_CHECK_LAUNCH("gemm(split-K -> residual RMSNorm)");
+  note_launch("gemm_skinny:splitk->resnorm");
   return MOJO_OK;
 }
 
 // Cut K so that the weight stream covers the chip: two workgroups fit a CU (70 KiB of LDS each), so up to 512 are resident;
 // the cost of a split is (rounds of 256 workgroups) / slices, and the smallest split with the least cost wins (fewer
 // partial slabs to write and sum) — the rule of quant_skinny_splitk.  Measured against every forced split
-// (scripts/probes/skinny_split_sweep.py, MOJO_HIP_GEMM_SKINNY_SPLITK=<n>, read per call): within 5 % of the best split on
+// (scripts/probes/skinny_split_sweep.py, MOJO_HIP_GEMM_SPLITK=<n>): within 5 % of the best split on
 // the decode shapes of a Llama-3-8B layer; all splits between 2 and 8 lie within ~10 % of each other.
 int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups) {
   if (groups != 1 || m > 128 || k % 128 != 0 || n % 64 != 0) return 1;
   const int64_t tiles = n / 64, nkb = k / 128;
-  const char* e = getenv("MOJO_HIP_GEMM_SKINNY_SPLITK");
-  const int forced = e ? atoi(e) : 0;
+  const int forced = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0));
   if (forced > 0) return static_cast<int>(forced > nkb ? nkb : forced);
   int64_t best = 1;
   double best_cost = static_cast<double>((tiles + 255) / 256);
@@ -411,8 +411,7 @@ int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups) {
 
 bool gemm_skinny_ok(const GemmArgs& a, int dtype) {
   if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
-  static const bool off = [] { const char* e = getenv("MOJO_HIP_GEMM_SKINNY"); return e && e[0] == '0'; }();
-  if (off) return false;
+  if (!(gemm_skinny_mask() & SKINNY_UNIFORM)) return false;
   return a.uniform_rows > 0 && a.uniform_rows <= 128 && a.w_k == 1 && a.K % 128 == 0 && a.N % 64 == 0 && a.lda % 8 == 0 &&
          a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && (a.splitk == 1 || (a.G == 1 && a.slab)) && aligned_to(a.A, 16) && aligned_to(a.W, 16) &&
          aligned_to(a.C, 8);
@@ -420,10 +419,10 @@ bool gemm_skinny_ok(const GemmArgs& a, int dtype) {
 
 // Ragged groups whose rows average at most 64 per group (the experts of a decode step): the product is the weight stream of
 // the groups that have rows, which the 256-row tile kernel reads at ~4 TB/s (it pads every group to 256 rows; measured 500 us
-// for 40 experts x 50 MB).  Needs prefix arrays built for tile height 64.  MOJO_HIP_GEMM_SKINNY_RAGGED=0 disables (per call).
+// for 40 experts x 50 MB).  Needs prefix arrays built for tile height 64.  MOJO_HIP_GEMM_SKINNY without bit 2 disables.
 bool gemm_skinny_ragged_ok(const GemmArgs& a, int dtype, int64_t m_total) {
   if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
-  if (const char* e = getenv("MOJO_HIP_GEMM_SKINNY_RAGGED")) { if (e[0] == '0') return false; }
+  if (!(gemm_skinny_mask() & SKINNY_RAGGED)) return false;
   return a.uniform_rows == 0 && a.G >= 2 && m_total > 0 && m_total <= static_cast<int64_t>(64) * a.G && a.w_k == 1 && a.K % 128 == 0 &&
          a.N % 64 == 0 && a.lda % 8 == 0 && a.w_n % 8 == 0 && a.w_group % 8 == 0 && a.ldc % 4 == 0 && a.splitk == 1 && !a.glu &&
          a.a_rc == 0 && a.c_rc == 0 && !a.bias && aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
@@ -436,6 +435,7 @@ int launch_gemm_skinny_ragged(const GemmArgs& a, int dtype, int64_t m_total, hip
   if (dtype == MOJO_BF16) hipLaunchKernelGGL((gemm_skinny_kernel<bf16_t, 4, 1, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_skinny_kernel<f16_t, 4, 1, true>), grid, dim3(256), 0, s, a);
   MOJO_CHECK_LAUNCH("gemm_skinny(ragged)");
+  note_launch("gemm_skinny:ragged");
   return MOJO_OK;
 }
 
@@ -458,6 +458,7 @@ int launch_gemm_skinny(const GemmArgs& a_in, int dtype, hipStream_t s) {
 #undef SKINNY_MT
 #undef SKINNY
   MOJO_CHECK_LAUNCH("gemm_skinny");
+  note_launch("gemm_skinny:uniform:splitk%d", a.splitk);
   if (a.splitk > 1 && a.sk_slot < 0 && !a.defer_finalize) return launch_gemm_splitk_finalize(a, dtype, a.uniform_rows, s);
   return MOJO_OK;
 }
@@ -465,7 +466,7 @@ int launch_gemm_skinny(const GemmArgs& a_in, int dtype, hipStream_t s) {
 // ---- dense GEMM + SwiGLU in one launch (decode-sized M, [2 I, K] weights) --------------------------------------------------
 bool gemm_skinny_glu_ok(const GemmArgs& a, int dtype) {
   if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
-  if (const char* e = getenv("MOJO_HIP_GEMM_SKINNY_GLU")) { if (e[0] == '0') return false; }
+  if (!(gemm_skinny_mask() & SKINNY_GLU)) return false;
   return a.G == 1 && a.uniform_rows > 0 && a.uniform_rows <= 64 && a.w_k == 1 && a.K % 128 == 0 && a.N % 16 == 0 && a.lda % 8 == 0 &&
          a.w_n % 8 == 0 && a.ldc % 4 == 0 && a.splitk == 1 && !a.bias && aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8);
 }
@@ -473,7 +474,7 @@ bool gemm_skinny_glu_ok(const GemmArgs& a, int dtype) {
 // Waves per workgroup: the count whose workgroups deal the wave units (8 + 8 weight rows each) most evenly over 256 CUs —
 // the stream is per-CU bound, so the launch takes as long as the CU with the most units.  Ties: fewer waves.
 int gemm_skinny_glu_waves(int64_t inter) {
-  if (const char* e = getenv("MOJO_HIP_GEMM_GLU_WAVES")) { const int v = atoi(e); if (v >= 4 && v <= 8) return v; }
+  if (const int v = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_WAVES", 0)); v >= 4 && v <= 8) return v;
   const int64_t units = inter / 8;
   int best = 4;
   int64_t best_cost = -1;
@@ -502,6 +503,7 @@ int launch_gemm_skinny_glu(const GemmArgs& a, int dtype, hipStream_t s) {
 #undef GLU_NW
 #undef GLU_K
   MOJO_CHECK_LAUNCH("gemm_skinny(glu)");
+  note_launch("gemm_skinny:glu:waves%d", nw);
   return MOJO_OK;
 }
 

@@ -458,6 +458,7 @@ static int launch_mla(const MlaArgs& a, hipStream_t s) {
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, GE::LDS_BYTES);
   hipLaunchKernelGGL(fn, dim3(a.n_tiles, a.n_splits), dim3(512 / NQ), GE::LDS_BYTES, s, a);
   MOJO_CHECK_LAUNCH("mla_latent");
+  note_launch("mla_latent:r%d:splits%d", R, a.n_splits);
   if (a.n_splits > 1) {
     hipLaunchKernelGGL(mla_merge_kernel<T>, dim3(a.n_tiles, a.heads), dim3(a.n_splits <= 4 ? 128 : 512), 0, s, a, R);
     MOJO_CHECK_LAUNCH("mla_merge");
@@ -471,15 +472,15 @@ static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
     const int head_blocks = (a.heads + 63) / 64;
     // MOJO_HIP_MLA_KERNEL: "ps" specialised waves (default), "oct" two waves per SIMD in lock-step on 64-key tiles (the
     // kernel for pages below 16 tokens); an experiments build adds "pp" (ping-pong) and "pair" (one wave per SIMD)
-    int which = [] {                                     // read per call: the tests switch kernels inside one process
-      const char* e = getenv("MOJO_HIP_MLA_KERNEL");
-      if (!e) return MLA512_DEFAULT_KERNEL;
-      if (e[0] == 'p' && e[1] == 's') return 3;
+    int which = [] {
+      const long long e = MOJO_SWITCH("MOJO_HIP_MLA_KERNEL", -1);
+      if (e < 0) return MLA512_DEFAULT_KERNEL;
+      if (e == switch_word("ps")) return 3;
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
-      if (e[0] == 'p' && e[1] == 'a') return 1;
-      if (e[0] == 'p') return 2;
+      if (e == switch_word("pair")) return 1;
+      if (e == switch_word("pp")) return 2;
 #endif
-      return 0;
+      return 0;                                          // "oct"
     }();
     if (which == 3 && a.page_shift < 4) which = 0;       // a loader's 16 rows must share one page id: pages of >= 16 tokens
     if (which == 3) {
@@ -502,6 +503,7 @@ static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
       hipLaunchKernelGGL(fn, dim3(a.n_tiles * head_blocks, a.n_splits), dim3(512), MLA512_OCT_LDS, s, a);
     }
     MOJO_CHECK_LAUNCH("mla512");
+    note_launch("mla512:%s:splits%d", which == 3 ? "ps" : which == 1 ? "pair" : which == 2 ? "pp" : "oct", a.n_splits);
     if (a.n_splits > 1) {
       hipLaunchKernelGGL(mla_merge_kernel<T>, dim3(a.n_tiles, a.heads), dim3(a.n_splits <= 4 ? 128 : 512), 0, s, a, 512);
       MOJO_CHECK_LAUNCH("mla_merge");
@@ -516,7 +518,7 @@ static int dispatch_mla(const MlaArgs& a, int r, int rope, hipStream_t s) {
 }
 
 static int mla_splits(int64_t tiles, int64_t max_len) {
-  if (const char* e = getenv("MOJO_HIP_MLA_SPLITS")) { const int v = atoi(e); if (v >= 1) return v; }
+  if (const int v = static_cast<int>(MOJO_SWITCH("MOJO_HIP_MLA_SPLITS", 0)); v >= 1) return v;
   int64_t sp = 256 / (tiles > 0 ? tiles : 1);
   const int64_t cap = ceil_div(max_len > 0 ? max_len : 1, 256);
   if (sp > cap) sp = cap;
@@ -582,9 +584,12 @@ extern "C" int mojo_hip_mla_latent_attn(const void* q_lat, int64_t q_lat_stride,
   a.n_splits = mla_splits(q_tokens * ((kv_lora_rank == 512 && rope_dim == 64) ? (heads + 63) / 64 : 1), max_len);
   a.split_keys = static_cast<int>(ceil_div(ceil_div(max_len > 0 ? max_len : 1, a.n_splits), MLA_KEYS) * MLA_KEYS);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
-  { const char* e = getenv("MOJO_HIP_MLA_PS_DEBUG"); a.ps_debug = e ? atoi(e) : 0; }
-  { const char* e = getenv("MOJO_HIP_MLA_PS_ISSUERS"); a.ps_issuers = (e && e[0] == '6') ? 6 : 2; }
-  { const char* e = getenv("MOJO_HIP_MLA_PS_PREFETCH"); a.ps_prefetch = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0; }
+  a.ps_debug = 0; a.ps_issuers = 2; a.ps_prefetch = 0;
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS           // ablation switches of the `ps` kernel
+  a.ps_debug = static_cast<int>(MOJO_SWITCH("MOJO_HIP_MLA_PS_DEBUG", 0));
+  a.ps_issuers = MOJO_SWITCH("MOJO_HIP_MLA_PS_ISSUERS", 2) == 6 ? 6 : 2;
+  { const long long e = MOJO_SWITCH("MOJO_HIP_MLA_PS_PREFETCH", 0); a.ps_prefetch = e == 1 ? 1 : e == 2 ? 2 : 0; }
+#endif
   a.part_o = nullptr; a.part_ml = nullptr;
   if (a.n_splits > 1) {
     const int64_t slots = q_tokens * a.n_splits * heads;

@@ -496,6 +496,7 @@ static int launch_mla_pf(const MlaPfArgs& a, hipStream_t s) {
   MOJO_REQUIRE(blocks < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "mla_prefill: grid limit");
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(NW * 64), MPF_LDS, s, a);
   MOJO_CHECK_LAUNCH("mla_prefill");
+  note_launch("mla_prefill_attn");
   return MOJO_OK;
 }
 
@@ -580,7 +581,10 @@ extern "C" int mojo_hip_mla_prefill_attn(const void* query, const void* kv_decom
   const int64_t mq = (max_q_len > 0 && max_q_len < total_tokens) ? max_q_len : total_tokens;
   constexpr int nw = 4;                                // (8 waves = 256 rows per workgroup: measured 10-20 % slower, see the kernel's header)
   a.n_qb = static_cast<int>(ceil_div(mq, static_cast<int64_t>(32 * nw)));
-  { const char* e = getenv("MOJO_HIP_MLA_PREFILL_ODD_SLOTS"); a.n_slots = (e && e[0] == '0') ? a.n_qb : (a.n_qb | 1); }
+  a.n_slots = a.n_qb | 1;
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS           // placement A/B of the odd slot count
+  if (MOJO_SWITCH("MOJO_HIP_MLA_PREFILL_ODD_SLOTS", 1) == 0) a.n_slots = a.n_qb;
+#endif
   a.total_tokens = total_tokens;
   a.round_scaled = round_scaled_scores ? 1 : 0;
   a.pre_scale = softmax_scale;

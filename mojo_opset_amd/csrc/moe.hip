@@ -799,11 +799,12 @@ template <typename T>
 static int launch_gating(const void* x, const float* w, int32_t* idx, float* gate, int64_t tokens, int hidden, int experts,
                          int top_k, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
-    static const bool no_e8 = [] { const char* e = getenv("MOJO_HIP_GATING_E8"); return e && e[0] == '0'; }();
-    if (experts == 8 && hidden % 512 == 0 && tokens >= 32 && aligned_to(w, 16) && !no_e8) {
+    const long long route = MOJO_SWITCH("MOJO_HIP_GATING", 0);          // 1 = the general streaming kernel (see gate_route)
+    if (experts == 8 && hidden % 512 == 0 && tokens >= 32 && aligned_to(w, 16) && route != 1) {
       hipLaunchKernelGGL((moe_gating_e8_kernel<T>), dim3(static_cast<unsigned>(ceil_div(tokens, static_cast<int64_t>(8)))), dim3(256), 0, s,
                          static_cast<const T*>(x), w, idx, gate, tokens, hidden, top_k);
       MOJO_CHECK_LAUNCH("moe_gating(e8)");
+      note_launch("moe_gating:e8");
       return MOJO_OK;
     }
   }
@@ -831,6 +832,7 @@ static int launch_gating(const void* x, const float* w, int32_t* idx, float* gat
 #undef GATE_EI
 #undef GATE_LAUNCH
   MOJO_CHECK_LAUNCH("moe_gating");
+  note_launch("moe_gating:general");
   return MOJO_OK;
 }
 
@@ -838,9 +840,12 @@ static int launch_gating(const void* x, const float* w, int32_t* idx, float* gat
 
 using namespace mojo;
 
+// MOJO_HIP_GATING forces the router's kernel (0 / unset = by shape): 1 = the general streaming kernel (no E = 8
+// specialisation, no small-batch kernel, no matrix cores), 2 = streaming kernels only (E = 8 specialisation allowed),
+// 3 = the small-batch kernel wherever it applies, 4 = the matrix-core route wherever it applies.
 // The MFMA route pays when the logits are real GEMM work: many experts, many tokens, 16-bit activations.
 static bool gate_use_mfma(int64_t tokens, int64_t hidden, int64_t experts, int dtype) {
-  if (const char* e = getenv("MOJO_HIP_GATING_MFMA")) return atoi(e) != 0 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && hidden % 64 == 0 && hidden >= 64;
+  if (const long long e = MOJO_SWITCH("MOJO_HIP_GATING", 0); e != 0) return e == 4 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && hidden % 64 == 0 && hidden >= 64;
   return (dtype == MOJO_BF16 || dtype == MOJO_F16) && experts >= 32 && tokens >= 512 && hidden % 64 == 0 && hidden >= 64;
 }
 static int64_t gate_e_pad(int64_t experts) { return (experts + 15) / 16 * 16; }
@@ -855,10 +860,10 @@ static int gate_splitk(int64_t tokens, int64_t hidden, int64_t e_pad) {
 
 // Fewer than 512 tokens, and more than the eight experts or fewer than the 32 tokens the streaming kernel covers:
 // moe_gating_small_kernel (any dtype).
-// MOJO_HIP_GATING_SMALL=0/1 forces the choice (read per call).
+// MOJO_HIP_GATING=3 forces it, 1 / 2 / 4 exclude it.
 static bool gate_use_small(int64_t tokens, int64_t hidden, int64_t experts) {
   if (hidden >= (1LL << 30) || tokens >= (1LL << 24)) return false;
-  if (const char* e = getenv("MOJO_HIP_GATING_SMALL")) return e[0] != '0';
+  if (const long long e = MOJO_SWITCH("MOJO_HIP_GATING", 0); e != 0) return e == 3;
   return tokens < 512 && (experts > 8 || tokens < 32);                   // (from 512 tokens and 32 experts on the matrix-core route takes over)
 }
 
@@ -940,6 +945,7 @@ extern "C" int mojo_hip_moe_gating(const void* hidden, const float* gate_weight,
     hipLaunchKernelGGL(moe_gate_reduce_select_kernel, dim3(static_cast<unsigned>(tokens)), dim3(256), static_cast<size_t>(4) * e_pad * sizeof(float), s,
                        slabs, tokens * e_pad, p.slices, e_pad, top_k_indices, top_k_gates, e, k);
     MOJO_CHECK_LAUNCH("moe_gating(select)");
+    note_launch("moe_gating:small");
     return MOJO_OK;
   }
   if (gate_use_mfma(tokens, hidden_size, num_experts, dtype)) {
@@ -947,8 +953,10 @@ extern "C" int mojo_hip_moe_gating(const void* hidden, const float* gate_weight,
                      aligned_to(workspace, 256),
                  MOJO_EWORKSPACE, "moe_gating: workspace too small");
     MOJO_REQUIRE(tokens < (1LL << 31), MOJO_EUNSUPPORTED, "moe_gating: too many tokens");
-    return dtype == MOJO_BF16 ? gating_mfma<bf16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, dtype, workspace, s)
-                              : gating_mfma<f16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, dtype, workspace, s);
+    const int rc = dtype == MOJO_BF16 ? gating_mfma<bf16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, dtype, workspace, s)
+                                      : gating_mfma<f16_t>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, dtype, workspace, s);
+    if (rc == MOJO_OK) note_launch("moe_gating:mfma");
+    return rc;
   }
   switch (dtype) {
     case MOJO_F32: return launch_gating<float>(hidden, gate_weight, top_k_indices, top_k_gates, tokens, h, e, k, s);
@@ -1036,8 +1044,8 @@ extern "C" int mojo_hip_moe_combine(const void* expert_outputs, const float* sor
   int32_t* list = start + tokens + 1;                   // [rows]
   // (zeroed by a kernel, not hipMemsetAsync: a captured graph holding two memset nodes on this buffer between kernel
   // nodes aborted at replay on ROCm 7.0)
-  const char* plan_env = getenv("MOJO_HIP_MOE_PLAN");          // "0": the five-launch plan (the route of > 15 360 tokens), read per call
-  if (tokens <= PLAN_MAX_TOKENS && !(plan_env && plan_env[0] == '0')) {
+  const bool no_plan = MOJO_SWITCH("MOJO_HIP_MOE_PLAN", 1) == 0;   // 0: the five-launch plan (the route of > 15 360 tokens)
+  if (tokens <= PLAN_MAX_TOKENS && !no_plan) {
     hipLaunchKernelGGL(moe_token_plan_kernel, dim3(1), dim3(1024), static_cast<size_t>(tokens) * sizeof(int), s, token_indices, rows,
                        static_cast<int>(tokens), start, list);
     MOJO_CHECK_LAUNCH("moe_combine(plan)");

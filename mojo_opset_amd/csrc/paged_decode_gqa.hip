@@ -525,24 +525,25 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(DecodeArgs a, int G) 
 }
 
 // The grouped form (DecodeArgs::fuse_group; matrix-core kernel only: the same conditions as decode_use_mfma, which the
-// workspace sizing cannot call) — MOJO_HIP_DECODE_GROUPED=0/1, read per call.
+// workspace sizing cannot call) — MOJO_HIP_DECODE_GROUPED=0 restores the split + merge form.
 static bool decode_grouped(int64_t G, int64_t head_dim, int64_t page) {
   // Measured (scripts/probes/decode_grouped_ab.py, profiles/r4_decode_grouped_ab.txt; split + merge form -> grouped form, graph
   // replay): 8 q / 1 kv heads B 64 ctx 4096 (Llama-3-70B under TP 8) 33.6 -> 28.1 us, B 16 ctx 16384 38.2 -> 29.8 us; 32 / 8 heads
   // B 8 ctx 4096 31.3 -> 27.5 us; 64 / 8 heads B 8 ctx 8192 56.1 -> 49.8 us; head_dim 64 B 8 ctx 8192 33.7 -> 28.6 us.
-  const char* e = getenv("MOJO_HIP_DECODE_GROUPED");
-  if (e && e[0] == '0') return false;
+  // (the grouped launch exists in the fused form only: without MOJO_HIP_DECODE_FUSE the chunks are sized, written and merged
+  // one by one — ADVICE r4: the merge kernel divided the chunk count by the group size although every chunk had its partial)
+  if (MOJO_SWITCH("MOJO_HIP_DECODE_GROUPED", 1) == 0 || MOJO_SWITCH("MOJO_HIP_DECODE_FUSE", 1) == 0) return false;
   const bool pow2 = page > 0 && (page & (page - 1)) == 0;
   if (!pow2 || page < 16 || (head_dim != 64 && head_dim != 128) || G > 16) return false;
-  const char* m = getenv("MOJO_HIP_DECODE_MFMA");
-  if (m && m[0] == '0') return false;
-  if (m && m[0] == '1') return true;
+  const long long m = MOJO_SWITCH("MOJO_HIP_DECODE_MFMA", -1);
+  if (m == 0) return false;
+  if (m == 1) return true;
   return G >= 4 || head_dim == 64 || (G != 1 && G != 2);
 }
 
 static int decode_chunk_tokens(int64_t batch, int64_t kv_heads, int64_t max_len, bool grouped = false) {
-  if (const char* env = getenv("MOJO_HIP_DECODE_CHUNK")) {     // tuning override
-    const int v = atoi(env);
+  {                                                            // tuning override
+    const int v = static_cast<int>(MOJO_SWITCH("MOJO_HIP_DECODE_CHUNK", 0));
     if (v >= DEC_TILE) return (v / DEC_TILE) * DEC_TILE;
   }
   // The split kernel holds 2 waves per SIMD (register-ring bound), i.e. 2048 resident waves on 256
@@ -581,12 +582,12 @@ static int64_t decode_max_len(int64_t page, int64_t max_pages, int64_t hint) {
 // groups of 8 heads (Llama-3-70B 64 / 8: 356 -> 170 us; 8 / 1: 79 -> 39 us), head_dim 64 (149 -> 99 us), groups of 4 at
 // head_dim 128 (headline 179 -> 169 us, ctx 1024 51 -> 47 us, ragged 150 -> 139 us; B 8: 34.5 -> 32.6 us with the chunk rule
 // of decode_chunk_tokens), and the group sizes the vector-unit kernel has no instance for.  Groups of 1 and 2 heads at head_dim 128
-// stay on the vector-unit kernel (163 vs 168 us, 167 vs 169 us).  1 = wherever it applies, 0 = never (read per call).
+// stay on the vector-unit kernel (163 vs 168 us, 167 vs 169 us).  1 = wherever it applies, 0 = never.
 static bool decode_use_mfma(const DecodeArgs& a, int G) {
   if (a.page_shift < 4 || (a.dim != 64 && a.dim != 128) || G > 16) return false;
-  const char* e = getenv("MOJO_HIP_DECODE_MFMA");
-  if (e && e[0] == '0') return false;
-  if (e && e[0] == '1') return true;
+  const long long e = MOJO_SWITCH("MOJO_HIP_DECODE_MFMA", -1);
+  if (e == 0) return false;
+  if (e == 1) return true;
   return G >= 4 || a.dim == 64 || (G != 1 && G != 2);
 }
 
@@ -605,17 +606,20 @@ static void launch_decode_mfma(const DecodeArgs& a, dim3 grid, dim3 block, int G
 
 template <typename T, bool NT>
 static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
-  static const bool no_fuse = [] { const char* e = getenv("MOJO_HIP_DECODE_FUSE"); return e && e[0] == '0'; }();
-  static const bool no_pair = [] { const char* e = getenv("MOJO_HIP_DECODE_PAIR"); return e && e[0] == '0'; }();
+  const bool no_fuse = MOJO_SWITCH("MOJO_HIP_DECODE_FUSE", 1) == 0;
+  const bool no_pair = MOJO_SWITCH("MOJO_HIP_DECODE_PAIR", 1) == 0;
+  const char* nt_tag = NT ? "nt" : "cached";
   if (decode_use_mfma(a, G)) {
     if (a.n_chunks == 4 && batch >= 2 && batch <= 64 && !no_fuse && !no_pair) {
       launch_decode_mfma<T, NT, DEC_PAIRED>(a, dim3(1, static_cast<unsigned>(((batch + 1) / 2) * a.hkv)), dim3(512), G, s);
       MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, paired)");
+      note_launch("decode_mfma:paired:%s", nt_tag);
       return MOJO_OK;
     }
     if (a.n_chunks <= 8 && !no_fuse) {
       launch_decode_mfma<T, NT, DEC_FUSED>(a, dim3(1, static_cast<unsigned>(batch * a.hkv)), dim3(static_cast<unsigned>(64 * a.n_chunks)), G, s);
       MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, fused)");
+      note_launch("decode_mfma:fused:%s", nt_tag);
       return MOJO_OK;
     }
     if (a.fuse_group > 0 && !no_fuse) {
@@ -626,12 +630,14 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
       MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, grouped)");
       hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv), G), dim3(256), 0, s, a, G);
       MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
+      note_launch("decode_mfma:grouped+merge:%s", nt_tag);
       return MOJO_OK;
     }
     launch_decode_mfma<T, NT, DEC_SPLIT>(a, dim3(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv)), dim3(64), G, s);
     MOJO_CHECK_LAUNCH("paged_decode_gqa(mfma, split)");
     hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv), G), dim3(256), 0, s, a, G);
     MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
+    note_launch("decode_mfma:split+merge:%s", nt_tag);
     return MOJO_OK;
   }
   if (a.n_chunks == 4 && batch >= 2 && batch <= 64 && a.dim % 4 == 0 && !no_fuse && !no_pair) {
@@ -646,6 +652,7 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
       default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
     }
     MOJO_CHECK_LAUNCH("paged_decode_gqa(paired)");
+    note_launch("decode_valu:paired:%s", nt_tag);
     return MOJO_OK;
   }
   if (a.n_chunks <= 8 && a.dim % 4 == 0 && !no_fuse) {   // all chunks of a (sequence, kv-head) in one workgroup: merged in LDS
@@ -661,6 +668,7 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
       default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_decode_gqa: group size %d (supported: 1,2,4,8)", G);
     }
     MOJO_CHECK_LAUNCH("paged_decode_gqa(fused)");
+    note_launch("decode_valu:fused:%s", nt_tag);
     return MOJO_OK;
   }
   dim3 grid(static_cast<unsigned>(a.n_chunks), static_cast<unsigned>(batch * a.hkv));
@@ -674,14 +682,16 @@ static int launch_decode_nt(DecodeArgs& a, int64_t batch, int G, hipStream_t s) 
   MOJO_CHECK_LAUNCH("paged_decode_gqa(split)");
   hipLaunchKernelGGL((decode_merge_kernel<T>), dim3(static_cast<unsigned>(batch * a.hkv), G), dim3(256), 0, s, a, G);
   MOJO_CHECK_LAUNCH("paged_decode_gqa(merge)");
+  note_launch("decode_valu:split+merge:%s", nt_tag);
   return MOJO_OK;
 }
 
 template <typename T>
 static int launch_decode(DecodeArgs& a, int64_t batch, int G, hipStream_t s) {
   // K/V are read exactly once: non-temporal loads keep them from displacing the block tables and
-  // partials in L2/MALL (measured on MI355X, B=64 ctx=4096: 204 -> 190 us).  MOJO_HIP_DECODE_NT=0 disables.
-  static const bool nt = [] { const char* e = getenv("MOJO_HIP_DECODE_NT"); return !e || atoi(e) != 0; }();
+  // partials in L2/MALL (measured on MI355X, B=64 ctx=4096: 204 -> 190 us).  MOJO_HIP_STREAM_NT=0 disables (the switch of every
+  // streaming kernel, common.h stream_nt()).
+  const bool nt = MOJO_SWITCH("MOJO_HIP_STREAM_NT", -1) != 0;
   return nt ? launch_decode_nt<T, true>(a, batch, G, s) : launch_decode_nt<T, false>(a, batch, G, s);
 }
 
@@ -743,17 +753,16 @@ extern "C" int mojo_hip_paged_decode_gqa(const void* query, const void* key_cach
   // Groups of 8 query heads per kv head (Llama-3-70B: 64 / 8).  Round 2 ran them as two 4-head halves on twice as many grid
   // heads (twice the K/V bytes: 360 us at B 64, ctx 4096) because the 8-head instance spilled; the instance now walks its heads
   // in blocks of four over a two-tile ring with the query slices parked in LDS (232 registers, no spill) and reads K/V once.
-  // MOJO_HIP_DECODE_G8_HALVES=1 selects the halves again (A/B).
+  // MOJO_HIP_DECODE_G8_HALVES=1 selects the halves again (A/B; experiments build only).
   int G = static_cast<int>(q_heads / kv_heads);
   a.hshift = 0;
-  if (G == 8) {
-    const char* e = getenv("MOJO_HIP_DECODE_G8_HALVES");
-    if (e && e[0] == '1') { a.hshift = 1; a.hkv *= 2; G = 4; }
-  }
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+  if (G == 8 && MOJO_SWITCH("MOJO_HIP_DECODE_G8_HALVES", 0) == 1) { a.hshift = 1; a.hkv *= 2; G = 4; }
+#endif
   const bool grouped = decode_grouped(G, head_dim, block_size);
   a.chunk_tokens = decode_chunk_tokens(batch, a.hkv, max_len, grouped);
   a.n_chunks = static_cast<int>(ceil_div(max_len > 0 ? max_len : 1, a.chunk_tokens));
-  a.fuse_group = grouped && a.n_chunks > 8 ? 8 : 0;
+  a.fuse_group = grouped && decode_use_mfma(a, G) && a.n_chunks > 8 ? 8 : 0;   // (the merge divides by it: set only where the grouped launch is taken)
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.abab = layout_abab ? 1 : 0;
   a.leave_empty = leave_empty_rows ? 1 : 0;

@@ -928,6 +928,7 @@ static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
     default: MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "paged_prefill_gqa: head_dim %d (64, 96, 128)", a.dim);
   }
   MOJO_CHECK_LAUNCH("paged_prefill_gqa");
+  note_launch("prefill:%s:%s:ksplit%d", a.pp ? "pp" : a.w64 ? "w64" : a.m32 ? "m32" : "default", a.fast_stage ? "fast_stage" : "general_stage", a.ksplit);
   return MOJO_OK;
 }
 
@@ -935,8 +936,7 @@ static int dispatch_dk(const PrefillArgs& a, dim3 grid, hipStream_t s) {
 // (head_dim 128, pages of >= 16 keys, unsplit, block tables of <= W64_TABLE - 16 pages) when MOJO_HIP_PREFILL_W64=1.
 static bool prefill_use_w64(int64_t max_q, int64_t batch, int hkv, int G) {
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
-  const char* e = getenv("MOJO_HIP_PREFILL_W64");
-  if (e && e[0] == '1') return true;
+  if (MOJO_SWITCH("MOJO_HIP_PREFILL_W64", 0) == 1) return true;
 #endif
   return false;
 }
@@ -945,16 +945,14 @@ static bool prefill_use_w64(int64_t max_q, int64_t batch, int hkv, int G) {
 // when MOJO_HIP_PREFILL_M32=1.
 static bool prefill_use_m32() {
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
-  const char* e = getenv("MOJO_HIP_PREFILL_M32");
-  if (e && e[0] == '1') return true;
+  if (MOJO_SWITCH("MOJO_HIP_PREFILL_M32", 0) == 1) return true;
 #endif
   return false;
 }
 
 static bool prefill_use_pp(int64_t max_q) {
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS
-  const char* e = getenv("MOJO_HIP_PREFILL_PP");
-  if (e && e[0] == '1') return true;
+  if (MOJO_SWITCH("MOJO_HIP_PREFILL_PP", 0) == 1) return true;
 #endif
   return false;
 }
@@ -973,7 +971,10 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
   MOJO_REQUIRE((n_qb * a.hkv * batch + n_zero) * a.ksplit < (int64_t{1} << 31), MOJO_EUNSUPPORTED, "paged_prefill_gqa: grid limit");
   a.batch = static_cast<int>(batch);
   a.n_qb = static_cast<int>(n_qb);
-  { const char* e = getenv("MOJO_HIP_PREFILL_SKEW"); a.skew = (e && e[0] == '0') ? 0 : 1; }
+  a.skew = 1;
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS           // the sequence rotation per query-block level (placement A/B)
+  a.skew = MOJO_SWITCH("MOJO_HIP_PREFILL_SKEW", 1) == 0 ? 0 : 1;
+#endif
   dim3 grid(static_cast<unsigned>((n_qb * a.hkv * batch + n_zero) * a.ksplit));
   switch (G) {
     case 1: return dispatch_dk<T, 1>(a, grid, s);
@@ -990,7 +991,7 @@ static int dispatch_g(PrefillArgs a, int G, int64_t batch, int64_t max_q, hipStr
 // 1 / 2 / 3 / 4 / 5 / 6 / 8 -> 339 / 197 / 199 / 185 / 223 / 210 / 229 us: a second round of workgroups only adds partials to
 // write and merge) and still leave >= 8 tiles (512 keys) per slice.  MOJO_HIP_PREFILL_KSPLIT=<n> forces (1 = off).
 static int prefill_ksplit(int64_t blocks, int64_t kv_cap) {
-  if (const char* e = getenv("MOJO_HIP_PREFILL_KSPLIT")) { const int v = atoi(e); if (v >= 1) return v > 16 ? 16 : v; }
+  if (const int v = static_cast<int>(MOJO_SWITCH("MOJO_HIP_PREFILL_KSPLIT", 0)); v >= 1) return v > 16 ? 16 : v;
   if (blocks <= 0 || blocks > 256) return 1;
   int64_t ks = 512 / blocks;
   const int64_t by_keys = kv_cap / 512;
@@ -1064,8 +1065,8 @@ extern "C" int mojo_hip_paged_prefill_gqa(const void* query, const void* key_cac
   a.max_pages = static_cast<int>(max_blocks_per_seq);
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.abab = layout_abab ? 1 : 0;
-  const char* fs = getenv("MOJO_HIP_PREFILL_FAST_STAGE");                       // "0": general staging everywhere (tests)
-  a.fast_stage = (a.page_shift >= 4 && cache_token_stride * 16 * 2 + 256 < (int64_t{1} << 31) && !(fs && fs[0] == '0')) ? 1 : 0;
+  const bool no_fs = MOJO_SWITCH("MOJO_HIP_PREFILL_FAST_STAGE", 1) == 0;        // 0: general staging everywhere (tests)
+  a.fast_stage = (a.page_shift >= 4 && cache_token_stride * 16 * 2 + 256 < (int64_t{1} << 31) && !no_fs) ? 1 : 0;
   int64_t max_q = (max_q_len_hint > 0 && max_q_len_hint < total_tokens) ? max_q_len_hint : total_tokens;
   const int G = static_cast<int>(q_heads / kv_heads);
   {

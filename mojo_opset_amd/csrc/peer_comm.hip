@@ -239,21 +239,18 @@ static int fill_ptrs(PeerPtrs& pp, void* const* data, void* const* flags, int ws
 }
 
 static int peer_max_blocks() {
-  static const int v = [] {
-    const char* e = getenv("MOJO_HIP_PEER_BLOCKS");
-    const int n = e ? atoi(e) : 64;
-    return n >= 1 ? n : 64;
-  }();
-  return v;
+  const int n = static_cast<int>(MOJO_SWITCH("MOJO_HIP_PEER_BLOCKS", 64));
+  return n >= 1 ? n : 64;
 }
 
+// Bound of every flag wait, in ticks of the 100 MHz constant counter.  `mojo_hip_peer_set_timeout_ms()` (the self-test of
+// comm/select.py shortens the bound for its own calls and restores it) overrides MOJO_HIP_PEER_TIMEOUT_MS (default 20 s).
+// The value is an ARGUMENT of every exchange kernel: a launch — and a captured graph — keeps the bound it was enqueued with.
+static std::atomic<long long> g_peer_timeout_ms{0};
 static long long timeout_ticks() {
-  static const long long t = [] {
-    const char* e = getenv("MOJO_HIP_PEER_TIMEOUT_MS");
-    const long long ms = e ? atoll(e) : 20000;
-    return (ms > 0 ? ms : 20000) * 100000LL;                                // 100 MHz constant counter
-  }();
-  return t;
+  long long ms = g_peer_timeout_ms.load(std::memory_order_relaxed);
+  if (ms <= 0) ms = MOJO_SWITCH("MOJO_HIP_PEER_TIMEOUT_MS", 20000);
+  return (ms > 0 ? ms : 20000) * 100000LL;
 }
 
 }  // namespace mojo
@@ -265,6 +262,12 @@ extern "C" int64_t mojo_hip_peer_ctrl_bytes(void) { return static_cast<int64_t>(
 extern "C" int64_t mojo_hip_peer_max_ranks(void) { return PEER_MAX; }
 extern "C" int64_t mojo_hip_peer_max_chunks(void) { return PEER_MAX_CHUNKS; }
 extern "C" int64_t mojo_hip_peer_handle_bytes(void) { return static_cast<int64_t>(sizeof(hipIpcMemHandle_t)); }
+
+// Sets the bound of the flag waits of every exchange step enqueued from now on (milliseconds; <= 0 = back to
+// MOJO_HIP_PEER_TIMEOUT_MS / 20 s) and returns the previous setting (0 = the environment's).
+extern "C" int64_t mojo_hip_peer_set_timeout_ms(int64_t ms) {
+  return g_peer_timeout_ms.exchange(ms > 0 ? ms : 0, std::memory_order_relaxed);
+}
 
 extern "C" int mojo_hip_peer_alloc(void** ptr_out, int64_t bytes, int uncached) {
   MOJO_REQUIRE(ptr_out && bytes > 0, MOJO_EINVAL, "peer_alloc: bad arguments");

@@ -383,6 +383,7 @@ static int launch_quant_gemv(const GemmArgs& a, const float* rs, const bf16_t* c
   if (mv == 1) GEMV(1); else if (mv == 2) GEMV(2); else GEMV(4);
 #undef GEMV
   MOJO_CHECK_LAUNCH("quant_gemm(gemv)");
+  note_launch("quant_gemv:rows%d", mv);
   return MOJO_OK;
 }
 
@@ -418,11 +419,9 @@ static QuantSkinnyPlan quant_skinny_plan_for(int k, int n, int64_t m, int nw_lo,
 // four-wave plan already covers 7/8 of the chip with few rows (32 x 18432 x 7168 27.3 -> 29.2 us, 16 x 4096 x 7168 10.5 -> 11.6 us:
 // twice the slices for 12 % better balance).  Hence: more than 64 rows, or a balance gain of at least a quarter.
 static QuantSkinnyPlan quant_skinny_plan(int k, int n, int64_t m, bool wide = true /* 6 / 7 / 8 waves instantiated (bf16 output) */) {
-  if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return QuantSkinnyPlan{v, 4, 0.0}; }
-  if (const char* wv = getenv("MOJO_HIP_QGEMM_WAVES")) {                  // measurement: forced waves per workgroup (4 = the round-3 rule)
-    const int w = atoi(wv);
+  if (const int v = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0)); v >= 1) return QuantSkinnyPlan{v, 4, 0.0};
+  if (const int w = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_WAVES", 0)); w >= 4 && w <= 8)     // measurement: forced waves per workgroup (4 = the round-3 rule)
     return quant_skinny_plan_for(k, n, m, wide ? w : 4, wide ? w : 4);
-  }
   const QuantSkinnyPlan narrow = quant_skinny_plan_for(k, n, m, 4, 4);
   if (!wide) return narrow;
   const QuantSkinnyPlan any = quant_skinny_plan_for(k, n, m, 4, 8);
@@ -466,6 +465,7 @@ static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t*
 #undef SKINNY_NW
 #undef SKINNY
   MOJO_CHECK_LAUNCH("quant_gemm(skinny)");
+  note_launch("quant_skinny:waves%d:splitk%d", plan.nw, sk);
   if (sk > 1 && slot < 0) {
     int64_t blocks = ceil_div(m * a.N, 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
@@ -480,7 +480,7 @@ static int launch_quant_skinny(const GemmArgs& a, const float* rs, const bf16_t*
 
 // Few output tiles (decode-sized M): cut K so that ~256 workgroups stream the weight concurrently.
 static int quant_splitk(int64_t m, int k, int n) {
-  if (const char* e = getenv("MOJO_HIP_QGEMM_SPLITK")) { const int v = atoi(e); if (v >= 1) return v; }
+  if (const int v = static_cast<int>(MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0)); v >= 1) return v;
   const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256);
   const int nkt = k / 128;
   if (tiles >= 128 || n % 4 != 0 || nkt < 2) return 1;
@@ -494,10 +494,9 @@ template <typename TO>
 static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, int quant_dtype, void* slab_ws,
                      hipStream_t s) {
   const bool fp8 = quant_dtype == MOJO_F8E4M3;
-  static const bool no_gemv = [] { const char* e = getenv("MOJO_HIP_QGEMM_GEMV"); return e && e[0] == '0'; }();
-  if (quant_gemv_ok(m, a) && !no_gemv)
+  if (quant_gemv_ok(m, a) && (gemm_skinny_mask() & SKINNY_GEMV))
     return fp8 ? launch_quant_gemv<TO, true>(a, rs, cs, m, s) : launch_quant_gemv<TO, false>(a, rs, cs, m, s);
-  if (quant_skinny_ok(m, a))
+  if (quant_skinny_ok(m, a) && (gemm_skinny_mask() & SKINNY_UNIFORM))
     return fp8 ? launch_quant_skinny<TO, true>(a, rs, cs, m, slab_ws, s) : launch_quant_skinny<TO, false>(a, rs, cs, m, slab_ws, s);
   if (g256::gemm256_layout_ok(a, 1)) {
     const int sk = quant_splitk(m, a.K, a.N);
@@ -521,7 +520,7 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
       MOJO_CHECK_LAUNCH("quant_gemm(finalize)");
       return MOJO_OK;
     }
-    static const bool no_stage = [] { const char* e = getenv("MOJO_HIP_GEMM_STAGE_ROWS"); return e && e[0] == '0'; }();
+    const bool no_stage = MOJO_SWITCH("MOJO_HIP_GEMM_STAGE_ROWS", 1) == 0;
     a.stage_rows = (!no_stage && sizeof(TO) == 2 && a.ldc % 8 == 0 && aligned_to(a.C, 16)) ? 1 : 0;   // row-staged stores (gemm256_core.h)
     if (fp8) {
       g256::EpilogueDequant<TO, f32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f};
@@ -541,6 +540,7 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
     hipLaunchKernelGGL((quant_gemm_generic_kernel<TO, false>), dim3(blocks), dim3(256), 0, s, A, W, rs, cs,
                        static_cast<TO*>(a.C), m, a.K, a.N, a.w_k, a.w_n);
   MOJO_CHECK_LAUNCH("quant_gemm_generic");
+  note_launch("quant_generic");
   return MOJO_OK;
 }
 

@@ -536,29 +536,36 @@ def gen_comm():
         ("allgather_bf16", "MojoAllGatherGemm", {"gather_dim": 0}, 12, 64, 40, torch.bfloat16),
         ("reducescatter_bf16", "MojoGemmReduceScatter", {"scatter_dim": 0}, 24, 64, 48, torch.bfloat16),
     ]
-    ws = 2
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_comm_worker, args=(ws, port, spec, ret), nprocs=ws, join=True)
+    # world sizes 2, 4 and 8 (round 5: the reference's own harness runs these operators on 8 ranks,
+    # tests/dist_common.py:38-81; the fixtures used to stop at 2).  Every row count is divisible by 8.
     cases = []
-    for name, op_name, ctor_kw, m, k, n, dtype in spec:
-        cases.append({"name": name, "op": op_name, "ctor_kwargs": ctor_kw, "world_size": ws,
-                      "ranks": [dict(ret[r][name]) for r in range(ws)]})
-    # all-to-all: closed form the reference test builds without communication
-    # (tests/accuracy/operators/test_compute_with_comm.py:226-232)
-    m, k, n = 32, 64, 128
-    ranks = []
-    ys = []
-    for r in range(ws):
-        torch.manual_seed(42 + r)
-        x = torch.randn(m, k)
-        w = torch.randn(k, n) * 0.1
-        ys.append(x @ w)
-        ranks.append({"x": x, "w": w})
-    for r in range(ws):
-        ranks[r]["out"] = torch.cat([ys[src].chunk(ws, dim=0)[r] for src in range(ws)], dim=0)
-    cases.append({"name": "all2all_f32", "op": "MojoGemmAll2All", "ctor_kwargs": {"scatter_dim": 0, "gather_dim": 0},
-                  "world_size": ws, "ranks": ranks})
+    for ws in (2, 4, 8):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_comm_worker, args=(ws, port, spec, ret), nprocs=ws, join=True)
+        tag = "" if ws == 2 else f"_ws{ws}"
+        for name, op_name, ctor_kw, m, k, n, dtype in spec:
+            cases.append({"name": name + tag, "op": op_name, "ctor_kwargs": ctor_kw, "world_size": ws,
+                          "ranks": [dict(ret[r][name]) for r in range(ws)]})
+        # all-to-all: closed form the reference test builds without communication
+        # (tests/accuracy/operators/test_compute_with_comm.py:226-232)
+        m, k, n = 32, 64, 128
+        ranks = []
+        ys = []
+        for r in range(ws):
+            torch.manual_seed(42 + r)
+            x = torch.randn(m, k)
+            w = torch.randn(k, n) * 0.1
+            ys.append(x @ w)
+            ranks.append({"x": x, "w": w})
+        for r in range(ws):
+            ranks[r]["out"] = torch.cat([ys[src].chunk(ws, dim=0)[r] for src in range(ws)], dim=0)
+        cases.append({"name": "all2all_f32" + tag, "op": "MojoGemmAll2All", "ctor_kwargs": {"scatter_dim": 0, "gather_dim": 0},
+                      "world_size": ws, "ranks": ranks})
     return cases
 
 

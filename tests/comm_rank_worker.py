@@ -30,6 +30,18 @@ sys.path.insert(0, HERE)
 DEV = "cuda"
 
 
+def _setenv(**values):
+    """Set (None: unset) MOJO_HIP_* switches and make both layers re-read them (latched at first use)."""
+    from mojo_opset_amd import switches
+
+    for k, v in values.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    switches.reload()
+
+
 def _ulps(got, want):
     from hip_utils import max_ulp_bf16ish
     return max_ulp_bf16ish(got, want, atol=1e-3)
@@ -90,6 +102,12 @@ def check_vectors(rank, ws, group):
 _CACHE = {}
 
 
+def _scales():
+    """Divisors of the reference / config-4 shapes to run: 4 = oracle over the same gloo group at a quarter of every dimension,
+    1 = the golden's definition in fp32 torch on the device at full size.  MOJO_TEST_COMM_SCALES selects (default both)."""
+    return tuple(int(v) for v in os.environ.get("MOJO_TEST_COMM_SCALES", "4,1").split(",") if v)
+
+
 def _cached(key, make):
     if key not in _CACHE:
         _CACHE[key] = make()
@@ -124,7 +142,7 @@ def check_reference_shapes(rank, ws, group):
 
     full = ((4096, 4096, 4096, torch.float16), (2048, 8192, 4096, torch.float16), (8192, 4096, 2048, torch.float16),
             (4096, 4096, 4096, torch.bfloat16))
-    for scale in (4, 1):
+    for scale in _scales():
         for m0, k0, n0, dtype in full:
             m, k, n = m0 // scale, k0 // scale, n0 // scale
             kl = k // ws
@@ -144,7 +162,7 @@ def check_reference_shapes(rank, ws, group):
                 torch.cuda.synchronize()
                 _compare(rank, f"{side}:{name}:{tag}", got, want, 5e-3)
     # AllGatherGemm: :97-103, one seed for all ranks, [N, K] weights, bias in the fp16 cases
-    for scale in (4, 1):
+    for scale in _scales():
         for m0, k0, n0, dtype, use_bias in ((4096, 4096, 4096, torch.float16, True), (2048, 4096, 8192, torch.float16, True),
                                             (8192, 2048, 4096, torch.float16, True), (4096, 4096, 4096, torch.bfloat16, False)):
             m, k, n = m0 // scale, k0 // scale, n0 // scale
@@ -194,7 +212,7 @@ def check_fewer_rows_than_ranks(rank, ws, group):
 
     k, n = 1024, 2048
     for direct in ("1", "0"):
-        os.environ["MOJO_HIP_COMM_DIRECT"] = direct
+        _setenv(MOJO_HIP_COMM_DIRECT=direct)
         for m in (1, 3, 2 * ws, 5):
             for dtype in (torch.bfloat16, torch.float32):
                 want = _device_closed_form(ws, rank, m, k, n, dtype, "MojoGemmAllReduce")
@@ -211,7 +229,7 @@ def check_fewer_rows_than_ranks(rank, ws, group):
             assert peer._CACHE, "MOJO_HIP_COMM_DIRECT=1 but no peer exchange was built"
             for ex in peer._CACHE.values():
                 ex.check()                           # no wait timed out
-    os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+    _setenv(MOJO_HIP_COMM_DIRECT=None)
 
 
 def check_config4_shapes(rank, ws, group):
@@ -222,7 +240,7 @@ def check_config4_shapes(rank, ws, group):
     from hip_utils import hip_cls, torch_cls
 
     dtype = torch.bfloat16
-    for scale in (4, 1):
+    for scale in _scales():
         for m0 in (1024, 4096):
             for k0, n0 in ((28672, 8192), (8192, 8192)):
                 m, k, n = m0 // scale, k0 // scale, n0 // scale
@@ -272,7 +290,7 @@ def check_timeout_path(rank, ws, group):
     from hip_utils import hip_cls
     from mojo_opset_amd.comm import peer
 
-    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+    _setenv(MOJO_HIP_COMM_DIRECT="1")
     torch.manual_seed(rank)
     x = torch.randn(512, 256, dtype=torch.bfloat16).to(DEV)
     w = torch.randn(256, 512, dtype=torch.bfloat16).to(DEV)
@@ -301,52 +319,79 @@ def check_timeout_path(rank, ws, group):
 
 
 def check_auto_selection(rank, ws, group):
-    """comm/select.py with MOJO_HIP_COMM_DIRECT unset: the first call of an operator at a payload runs the group's self-test
-    of the direct exchange (bit-exact on integer data), times both paths and caches the winner; the result of the chosen
-    path equals BOTH forced paths' results (bf16: the direct form rounds the fp32 sum once, the pipeline adds rounded
-    partials — equal at two ranks), and a second payload bucket gets its own decision without a second self-test."""
+    """comm/select.py with MOJO_HIP_COMM_DIRECT unset (round 5 semantics).  (1) A key that was never warmed takes the
+    collective-library pipeline AT ONCE — no self-test, no timing inside a user call — and says so in the report.
+    (2) `select.warm(group, shapes)` runs the group's self-test of the direct exchange (bit-exact on integer data, flag waits
+    bounded through `mojo_hip_peer_set_timeout_ms`, restored afterwards) and times both paths per payload bucket; the direct
+    exchange wins only with a 10 % margin.  (3) Afterwards a user call takes the cached choice: its result equals the forced
+    path of the chosen algorithm bit for bit (and at two ranks both forced paths agree: one addition, order-free).  Every
+    rank reaches the same decisions."""
     from hip_utils import hip_cls
+    from mojo_opset_amd.backends.hip import lib as L
     from mojo_opset_amd.comm import peer, select
 
     select.reset()
+    _setenv(MOJO_HIP_COMM_DIRECT=None, MOJO_HIP_COMM_AUTOTUNE=None)
     torch.manual_seed(7 + rank)
-    w = (torch.randn(512, 1024, dtype=torch.bfloat16) * 0.05).to(DEV)
+    k, n = 512, 1024
+    w = (torch.randn(k, n, dtype=torch.bfloat16) * 0.05).to(DEV)
+    # (1) unwarmed: the pipeline, immediately
+    x = torch.randn(2048, k, dtype=torch.bfloat16).to(DEV)
+    op = hip_cls("MojoGemmAllReduce")(weight=w, bias=None, trans_weight=True, process_group=group)
+    first = op(x)
+    rep = select.report()
+    assert len(rep) == 1 and rep[0]["algorithm"] == "rccl" and rep[0].get("unwarmed") and not peer._CACHE, rep
+    # (2) warm
+    before = L.load().mojo_hip_peer_set_timeout_ms(0)
+    L.load().mojo_hip_peer_set_timeout_ms(before)
+    shapes = [(o, m, k, n, torch.bfloat16) for m in (2048, 8192) for o in ("gemm_all_reduce", "gemm_reduce_scatter", "all_gather_gemm")]
+    rep = select.warm(group, shapes)
+    after = L.load().mojo_hip_peer_set_timeout_ms(before)
+    assert after == before, "the self-test must restore the flag-wait bound it shortened"
+    assert len(rep) >= 5 and all(r["algorithm"] in ("direct", "rccl") and not r.get("unwarmed") for r in rep), rep
+    assert all(r["self_test"].startswith("self-test passed") for r in rep), rep
+    assert all("direct_us" in r and "rccl_us" in r and r["world"] == ws for r in rep), rep
+    assert all(r["algorithm"] == ("direct" if r["direct_us"] < 0.9 * r["rccl_us"] else "rccl") for r in rep), rep      # the margin
+    peer.check_all(group)
+    # (3) user calls follow the cached choice
     outs = {}
     for m in (2048, 8192):
-        x = torch.randn(m, 512, dtype=torch.bfloat16).to(DEV)
-        for name, kw in (("MojoGemmAllReduce", {}), ("MojoGemmReduceScatter", {"scatter_dim": 0})):
+        x = torch.randn(m, k, dtype=torch.bfloat16).to(DEV)
+        for name, key, kw in (("MojoGemmAllReduce", "gemm_all_reduce", {}), ("MojoGemmReduceScatter", "gemm_reduce_scatter", {"scatter_dim": 0})):
             op = hip_cls(name)(weight=w, bias=None, trans_weight=True, process_group=group, **kw)
             auto = op(x)
             torch.cuda.synchronize()
             for flag in ("0", "1"):
-                os.environ["MOJO_HIP_COMM_DIRECT"] = flag
+                _setenv(MOJO_HIP_COMM_DIRECT=flag)
                 outs[flag] = op(x)
                 torch.cuda.synchronize()
-            os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
-            assert torch.equal(outs["0"], outs["1"]), f"{name}: pipeline and direct exchange disagree at two ranks"
-            assert torch.equal(auto, outs["0"]), f"{name}: the selected path's result differs"
+            _setenv(MOJO_HIP_COMM_DIRECT=None)
+            choice = [r for r in select.report() if r["op"] == key and r["payload_bucket_MB"] == select.bucket(m * n * 2) / 2 ** 20]
+            assert len(choice) == 1, (key, m, select.report())
+            assert torch.equal(auto, outs["1" if choice[0]["algorithm"] == "direct" else "0"]), f"{name}: the selected path's result differs"
+            if ws == 2:
+                assert torch.equal(outs["0"], outs["1"]), f"{name}: pipeline and direct exchange disagree at two ranks"
+            else:                                   # different associations of ws storage-type partials: ulps apart, not more
+                assert _ulps(outs["1"].cpu(), outs["0"].cpu()) <= 2 * ws
             _report(rank, check=f"auto:{name}:M{m}")
         xs = x[: m // ws].contiguous()
         op = hip_cls("MojoAllGatherGemm")(weight=w, bias=None, trans_weight=True, gather_dim=0, process_group=group)
         auto = op(xs)
-        os.environ["MOJO_HIP_COMM_DIRECT"] = "0"
+        _setenv(MOJO_HIP_COMM_DIRECT="0")
         want = op(xs)
-        os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+        _setenv(MOJO_HIP_COMM_DIRECT=None)
         torch.cuda.synchronize()
         assert torch.equal(auto, want)
         _report(rank, check=f"auto:MojoAllGatherGemm:M{m}")
-    rep = select.report()
-    assert len(rep) >= 4 and all(r["algorithm"] in ("direct", "rccl") for r in rep), rep
-    assert all(r["self_test"].startswith("self-test passed") for r in rep), rep
-    assert all("direct_us" in r and "rccl_us" in r for r in rep), rep
-    for ex in peer._CACHE.values():
-        ex.check()
+    assert len(select.report()) == len(rep), "a warmed key must not be decided again"
+    peer.check_all(group)
     # every rank reached the same decisions
-    mine = [(r["op"], r["payload_bucket_MB"], r["algorithm"]) for r in rep]
+    mine = [(r["op"], r["payload_bucket_MB"], r["algorithm"]) for r in select.report()]
     everyone = [None] * ws
     dist.all_gather_object(everyone, mine, group=group)
     assert all(e == mine for e in everyone), everyone
-    _report(rank, selection=rep)
+    del first
+    _report(rank, selection=select.report())
 
 
 def check_captured_direct(rank, ws, group):
@@ -358,8 +403,7 @@ def check_captured_direct(rank, ws, group):
     from hip_utils import hip_cls
     from mojo_opset_amd.comm import peer
 
-    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
-    os.environ["MOJO_HIP_COMM_CHUNKS"] = "2"
+    _setenv(MOJO_HIP_COMM_DIRECT="1", MOJO_HIP_COMM_CHUNKS="2", MOJO_HIP_PEER_MIN_BYTES=str(1 << 20))
     dtype = torch.bfloat16
     m, k, n = 64, 512, 1024                                   # decode-sized rows: the case graphs exist for
     torch.manual_seed(7 + rank)
@@ -402,11 +446,26 @@ def check_captured_direct(rank, ws, group):
         torch.cuda.synchronize()
         assert torch.isfinite(got.float()).all(), f"replay {i}: poisoned output"
         assert torch.equal(got, want), f"replay {i}: captured and eager direct exchange disagree (max diff {(got.float() - want.float()).abs().max().item()})"
-    for ex in peer._CACHE.values():
-        ex.check()
-        ex.twin.check()
-    _report(rank, check="captured:direct_exchange:5_replays", ok=True)
-    os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+    peer.check_all(group)                                     # eager exchanges AND their captured twins
+    # a later eager call with a larger payload rebuilds the exchange.  The twin the graph was captured over must
+    # stay mapped (the graph holds its raw peer pointers): it is retired, not freed, and the graph keeps replaying correctly.
+    big = hip_cls("MojoGemmAllReduce")(weight=(torch.randn(k, 4096) * 0.05).to(dtype).to(DEV), bias=None, trans_weight=True, process_group=group)
+    xb = torch.randn(2048, k).to(dtype).to(DEV)               # 16 MiB payload > the 1 MiB the first exchange was built with
+    yb = big(xb)
+    torch.cuda.synchronize()
+    assert torch.isfinite(yb.float()).all()
+    assert len(peer._RETIRED_TWINS) == 1 and peer._RETIRED_TWINS[0].handed_out_under_capture, "the captured twin must be retired, not freed"
+    for i in range(6, 9):
+        load(i)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = out.clone()
+        want = step()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"replay {i} after the exchange grew: captured and eager disagree"
+    peer.check_all(group)
+    _report(rank, check="captured:direct_exchange:5_replays", ok=True, replays_after_growth=3)
+    _setenv(MOJO_HIP_COMM_DIRECT=None, MOJO_HIP_COMM_CHUNKS=None, MOJO_HIP_PEER_MIN_BYTES=None)
 
 
 def main():
@@ -425,11 +484,11 @@ def main():
     try:
         modes = [m for m in os.environ.get("MOJO_TEST_COMM_MODES", "chunks1,chunks4").split(",") if m]
         for mode in modes:
-            os.environ["MOJO_HIP_COMM_DIRECT"] = "0"     # pipeline unless the mode says otherwise ("auto": unset, comm/select.py decides)
+            _setenv(MOJO_HIP_COMM_DIRECT="0")     # pipeline unless the mode says otherwise ("auto": unset, comm/select.py decides)
             if mode == "auto":
                 _report(rank, mode=mode)
-                os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
-                os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+                _setenv(MOJO_HIP_COMM_DIRECT=None)
+                _setenv(MOJO_HIP_COMM_CHUNKS="4")
                 check_auto_selection(rank, ws, group)
                 continue
             if mode == "timeout":
@@ -442,21 +501,24 @@ def main():
                 continue
             if mode == "tiny":
                 _report(rank, mode=mode)
-                os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+                _setenv(MOJO_HIP_COMM_CHUNKS="4")
                 check_fewer_rows_than_ranks(rank, ws, group)
                 continue
             if mode.startswith("config4"):
-                _report(rank, mode=mode)
-                os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+                _report(rank, mode=mode)                 # config4[auto][direct]: "auto" = the pipelines' own chunk count
+                _setenv(MOJO_HIP_COMM_CHUNKS=None if "auto" in mode else "4")
                 if mode.endswith("direct"):
-                    os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
+                    _setenv(MOJO_HIP_COMM_DIRECT="1")
                 check_config4_shapes(rank, ws, group)
+                if mode.endswith("direct"):
+                    from mojo_opset_amd.comm import peer
+                    peer.check_all(group)
                 continue
             if mode.startswith("chunks"):
-                os.environ["MOJO_HIP_COMM_CHUNKS"] = mode[6:]
+                _setenv(MOJO_HIP_COMM_CHUNKS=mode[6:])
             elif mode.startswith("direct"):
-                os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
-                os.environ["MOJO_HIP_COMM_CHUNKS"] = mode[6:] or "4"
+                _setenv(MOJO_HIP_COMM_DIRECT="1")
+                _setenv(MOJO_HIP_COMM_CHUNKS=mode[6:] or "4")
             _report(rank, mode=mode)
             check_vectors(rank, ws, group)
             check_reference_shapes(rank, ws, group)

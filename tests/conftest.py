@@ -48,6 +48,47 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+class _SwitchAwareMonkeyPatch:
+    """pytest's monkeypatch with one addition: after setenv / delenv of a ``MOJO_HIP_*`` variable the latched switches of the
+    Python layer and of libmojo_hip.so are re-read (mojo_opset_amd.switches.reload), and once more when the test ends and the
+    environment is restored.  The switches are latched at first use (include/mojo_hip.h "Run-time switches"): without the
+    reload a test that flips a switch AFTER a first call in the same process silently re-runs the default path (the four
+    vacuous A/B tests of round 4)."""
+
+    def __init__(self, mp):
+        self._mp = mp
+        self.touched = False
+
+    def __getattr__(self, name):
+        return getattr(self._mp, name)
+
+    def _reload(self, name):
+        if str(name).startswith("MOJO_HIP_"):
+            self.touched = True
+            from mojo_opset_amd import switches
+
+            switches.reload()
+
+    def setenv(self, name, value, prepend=None):
+        self._mp.setenv(name, value, prepend)
+        self._reload(name)
+
+    def delenv(self, name, raising=True):
+        self._mp.delenv(name, raising)
+        self._reload(name)
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    wrapped = _SwitchAwareMonkeyPatch(monkeypatch)
+    yield wrapped
+    if wrapped.touched:
+        monkeypatch.undo()                       # restore the environment first, then latch it again
+        from mojo_opset_amd import switches
+
+        switches.reload()
+
+
 def load_golden(name):
     return torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)["cases"]
 

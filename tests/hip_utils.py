@@ -20,6 +20,59 @@ def skip_unless_experiments_build():
         pytest.skip("library built without MOJO_HIP_BUILD_EXPERIMENTS=1")
 
 
+def last_launch() -> str:
+    """The kernel form the last HIP operator call of this thread launched (`mojo_hip_last_launch`): what an A/B test asserts
+    on to prove that its two legs took two different forms."""
+    from mojo_opset_amd.backends.hip import lib
+
+    return lib.last_launch()
+
+
+def launches_of(fn) -> str:
+    """Run ``fn`` and return the '|'-separated kernel forms it launched (`mojo_hip_launch_history`)."""
+    from mojo_opset_amd.backends.hip import lib
+
+    lib.launch_history(clear=True)
+    fn()
+    return lib.launch_history()
+
+
+class switch_env:
+    """``with switch_env(MOJO_HIP_X="1", MOJO_HIP_Y=None): ...`` — set (None: unset) switches and make both layers re-read
+    them (they are latched at first use); restores and reloads on exit.  For loops inside one test, where the `monkeypatch`
+    fixture of conftest.py (which reloads too) is clumsy."""
+
+    def __init__(self, **values):
+        self.values, self.old = values, {}
+
+    def __enter__(self):
+        import os
+
+        from mojo_opset_amd import switches
+
+        for k, v in self.values.items():
+            self.old[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        switches.reload()
+        return self
+
+    def __exit__(self, *exc):
+        import os
+
+        from mojo_opset_amd import switches
+
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        switches.reload()
+        return False
+
+
 def hip_cls(op_name):
     return getattr(mo, op_name).get_backend_impl("hip", strict=True)
 

@@ -95,20 +95,92 @@ def test_integration_md_stub_passes_what_the_header_declares():
     assert calls >= 3
 
 
+def _switch_table(section):
+    """Names in the first column of the table under ``### <section>`` of INTEGRATION.md."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = doc.split(f"### {section}", 1)[1].split("\n### ", 1)[0].split("\nNot environment switches", 1)[0]
+    names = set()
+    for line in body.splitlines():
+        if line.startswith("| `"):
+            names.update(re.findall(r"`(MOJO_[A-Z0-9_]+)`", line.split("|")[1]))
+    return names
+
+
+def test_switches_in_the_binary_are_exactly_the_documented_table():
+    """INTEGRATION.md 5.1 == the MOJO_HIP_* names compiled into libmojo_hip.so (59 switches with two
+    semantics became <= 20 with one).  A switch a maintainer cannot find is a behaviour they cannot reproduce; a documented
+    switch the binary does not read is a lie."""
+    import re
+
+    from mojo_opset_amd.backends.hip import lib
+
+    blob = open(lib.lib_path(), "rb").read()
+    in_binary = {m.decode() for m in re.findall(rb"MOJO_HIP_[A-Z0-9_]+", blob)}
+    table = _switch_table("5.1")
+    experiments = _switch_table("5.3")
+    if lib.built_with_experiments():
+        assert table <= in_binary and in_binary - table <= experiments, (sorted(in_binary - table - experiments), sorted(table - in_binary))
+    else:
+        assert in_binary == table, (sorted(in_binary - table), sorted(table - in_binary))
+        assert len(table) <= 20
+
+
 def test_every_environment_switch_of_the_package_is_documented():
-    """INTEGRATION.md §5 lists every MOJO_HIP_* switch the library or the host side reads (a switch a maintainer cannot find
-    is a behaviour they cannot reproduce)."""
+    """Every MOJO_HIP_* name in the sources is in one of the three tables of INTEGRATION.md section 5: 5.1 (read by the
+    library), 5.2 (read by the Python layer; exactly the names `mojo_opset_amd/**/*.py` reads through `switches.get`), 5.3
+    (build-time and experiments-only)."""
     import glob
     import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = set()
+    names, py_reads = set(), set()
     for pat in ("mojo_opset_amd/csrc/*.hip", "mojo_opset_amd/csrc/*.h", "mojo_opset_amd/csrc/experiments/*.h", "mojo_opset_amd/**/*.py"):
         for path in glob.glob(os.path.join(root, pat), recursive=True):
-            names.update(re.findall(r"MOJO_HIP_[A-Z0-9_]+", open(path).read()))
-    doc = open(os.path.join(root, "INTEGRATION.md")).read()
-    missing = sorted(n for n in names if n not in doc)
+            text = open(path).read()
+            names.update(re.findall(r"MOJO_HIP_[A-Z0-9_]+", text))
+            if path.endswith(".py"):
+                py_reads.update(re.findall(r"(?:switches\.get(?:_int)?|os\.environ\.get)\(\s*\"(MOJO_HIP_[A-Z0-9_]+)\"", text))
+    t1, t2, t3 = _switch_table("5.1"), _switch_table("5.2"), _switch_table("5.3")
+    missing = sorted(n for n in names if n not in t1 | t2 | t3)
     assert len(names) > 30 and not missing, missing
+    assert py_reads - {"MOJO_HIP_BUILD_EXPERIMENTS", "MOJO_HIP_EXTRA_CXXFLAGS"} == t2, (sorted(py_reads - t2), sorted(t2 - py_reads))
+
+
+def test_switches_are_latched_and_reloaded(monkeypatch):
+    """The one semantics of section 5: a value is latched at first use, `switches.reload()` re-reads both layers."""
+    import ctypes as C
+
+    from mojo_opset_amd import switches
+    from mojo_opset_amd.backends.hip import lib
+
+    h = lib.load()
+    monkeypatch.delenv("MOJO_HIP_COMM_CHUNKS", raising=False)
+    assert switches.get_int("MOJO_HIP_COMM_CHUNKS", 0) == 0
+    os.environ["MOJO_HIP_COMM_CHUNKS"] = "3"                   # behind the fixture's back: no reload
+    assert switches.get_int("MOJO_HIP_COMM_CHUNKS", 0) == 0    # still latched
+    switches.reload()
+    assert switches.get_int("MOJO_HIP_COMM_CHUNKS", 0) == 3
+    monkeypatch.delenv("MOJO_HIP_COMM_CHUNKS")
+    assert switches.get_int("MOJO_HIP_COMM_CHUNKS", 0) == 0
+    # the library's side: mojo_hip_paged_decode_gqa_workspace_bytes reads MOJO_HIP_DECODE_CHUNK (no GPU needed)
+    args = (8, 32, 8, 128, 16, 512, 8192)
+    base = h.mojo_hip_paged_decode_gqa_workspace_bytes(*args)
+    os.environ["MOJO_HIP_DECODE_CHUNK"] = "64"
+    try:
+        assert h.mojo_hip_paged_decode_gqa_workspace_bytes(*args) == base          # latched
+        h.mojo_hip_reload_env()
+        assert h.mojo_hip_paged_decode_gqa_workspace_bytes(*args) > base           # 128 chunks of 64 tokens: more partials
+        assert lib.switches().get("MOJO_HIP_DECODE_CHUNK") == 64
+    finally:
+        os.environ.pop("MOJO_HIP_DECODE_CHUNK", None)
+        h.mojo_hip_reload_env()
+    assert h.mojo_hip_paged_decode_gqa_workspace_bytes(*args) == base
+    assert lib.switches().get("MOJO_HIP_DECODE_CHUNK", 0) is None
+    assert isinstance(lib.last_launch(), str) and isinstance(lib.launch_history(clear=True), str)
+    assert h.mojo_hip_peer_set_timeout_ms(1234) == 0 and h.mojo_hip_peer_set_timeout_ms(0) == 1234
 
 
 def test_library_is_stamped_with_the_hash_of_the_tree_and_a_stale_one_is_refused(monkeypatch):

@@ -1,7 +1,8 @@
-"""world_size-2 CPU tests (gloo) of the GEMM + collective pipelines (`mojo_opset_amd.comm`): the same
-orchestration the hip backend runs over RCCL, driven here by a torch GEMM engine, checked against
+"""Multi-process CPU tests (gloo, world sizes 2, 4 and 8) of the GEMM + collective pipelines (`mojo_opset_amd.comm`): the
+same orchestration the hip backend runs over RCCL, driven here by a torch GEMM engine, checked against
 (1) the reference's per-rank vectors (tests/golden/compute_with_comm.pt, captured from the reference running
-over gloo) and (2) the oracle classes running in the same processes."""
+over gloo at 2, 4 and 8 ranks — its own harness is built for 8, `tests/dist_common.py:38-81`) and (2) the oracle classes
+running in the same processes (shapes / seeds of `tests/accuracy/operators/test_compute_with_comm.py:95-247`)."""
 import os
 import socket
 import traceback
@@ -53,6 +54,7 @@ def _worker(rank, ws, port, fn, args, errq):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(max(1, 8 // ws))                # 8 cores here: ws ranks x all-core teams would thrash
         dist.init_process_group("gloo", rank=rank, world_size=ws)
         fn(rank, ws, *args)
         dist.barrier()
@@ -99,7 +101,11 @@ def _check_vectors(rank, ws, cases):
 
     eng = TorchEngine()
     group = dist.group.WORLD
+    seen = 0
     for case in cases:
+        if len(case["ranks"]) != ws:
+            continue
+        seen += 1
         me = case["ranks"][rank]
         x, w, want = me["x"], me["w"], me["out"]
         kw = case["ctor_kwargs"]
@@ -112,7 +118,21 @@ def _check_vectors(rank, ws, cases):
         else:
             got = comm.gemm_all2all(eng, x, w, None, True, group, kw["scatter_dim"], kw["gather_dim"])
         tol = 5e-3 if x.dtype != torch.float32 else 1e-4            # reference bounds: test_compute_with_comm.py:124,164,247
+        if ws > 2 and x.dtype != torch.float32 and case["op"] in ("MojoGemmAllReduce", "MojoGemmReduceScatter"):
+            # More than two 16-bit partials: the golden adds storage-type values in the COLLECTIVE LIBRARY's order (gloo's
+            # ring here, RCCL's on a node), rounding after every addition; any other association differs by up to one unit in
+            # the last place of a partial sum per addition.  One bf16 ulp is 0.4-0.8 % — above the reference's 5e-3 — so the
+            # bound is stated in those units: |got - want| <= (ws - 1) ulps at the magnitude sum_r |y_r| of the element.
+            ys = torch.stack([(c["x"].float() @ c["w"].float()).to(x.dtype).float() for c in case["ranks"]])
+            mag = ys.abs().sum(0)
+            if case["op"] == "MojoGemmReduceScatter":
+                mag = mag.chunk(ws, dim=0)[rank]
+            ulp = torch.pow(2.0, torch.floor(torch.log2(mag.clamp_min(2.0 ** -14))) - 7)
+            excess = (got.float() - want.float()).abs() - (ws - 1) * ulp
+            assert float(excess.max()) <= 0, f"{case['name']}: {float(excess.max())} above (ws - 1) bf16 ulps"
+            continue
         torch.testing.assert_close(got.float(), want.float(), atol=tol, rtol=tol, msg=lambda m: f"{case['name']}: {m}")
+    assert seen == 5, f"expected the five operators' vectors at world size {ws}, found {seen}"
 
 
 def _check_against_oracle(rank, ws, chunks):
@@ -120,11 +140,17 @@ def _check_against_oracle(rank, ws, chunks):
     import oracle  # noqa: F401
     from mojo_opset_amd import comm
 
-    os.environ["MOJO_HIP_COMM_CHUNKS"] = str(chunks)
+    from mojo_opset_amd import switches
+
+    if chunks:
+        os.environ["MOJO_HIP_COMM_CHUNKS"] = str(chunks)
+    else:
+        os.environ.pop("MOJO_HIP_COMM_CHUNKS", None)                   # the payload- and world-size-aware rule
+    switches.reload()
     eng = TorchEngine()
     group = dist.group.WORLD
     torch.manual_seed(42 + rank)
-    m, k, n = 1024 * ws, 96, 80
+    m, k, n = (1024 if ws <= 2 else 512) * ws, 96, 80
     for trans in (True, False):
         for with_bias in (False, True):
             x = torch.randn(m, k)
@@ -143,6 +169,28 @@ def _check_against_oracle(rank, ws, chunks):
                 ref = mo.MojoGemmAll2All.get_backend_impl("torch")(w, b, trans, scatter_dim=sd, gather_dim=gd)(x)
                 got = comm.gemm_all2all(eng, x, w, b, trans, group, sd, gd)
                 torch.testing.assert_close(got, ref, atol=1e-4, rtol=1e-4)
+    # row counts that leave ranks unequal or empty shares of a chunk (ws - 1, ws, 8 ws + 3 rows) through the all-reduce; row
+    # counts the world size does not divide are a ValueError of the scattering operators (golden: chunk() would be ragged)
+    w = torch.randn(k, n) * 0.1
+    for rows in (ws - 1, ws, 8 * ws + 3):
+        x = torch.randn(rows, k)
+        ref = mo.MojoGemmAllReduce.get_backend_impl("torch")(w, None, True)(x)
+        torch.testing.assert_close(comm.gemm_all_reduce(eng, x, w, None, True, group), torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
+        if rows % ws:
+            for bad in (lambda: comm.gemm_reduce_scatter(eng, x, w, None, True, group, 0),
+                        lambda: comm.gemm_all2all(eng, x, w, None, True, group, 0, 1)):
+                try:
+                    bad()
+                except ValueError:
+                    pass
+                else:
+                    raise AssertionError(f"{rows} rows over {ws} ranks must raise ValueError")
+        else:
+            ref = mo.MojoGemmReduceScatter.get_backend_impl("torch")(w, None, True, scatter_dim=0)(x)
+            torch.testing.assert_close(comm.gemm_reduce_scatter(eng, x, w, None, True, group, 0), ref, atol=1e-4, rtol=1e-4)
+        xs = torch.randn(max(rows // ws, 1), k)                       # all-gather: any shard height
+        ref = mo.MojoAllGatherGemm.get_backend_impl("torch")(w, None, True, gather_dim=0)(xs)
+        torch.testing.assert_close(comm.all_gather_gemm(eng, xs, w, None, True, group, 0), torch.as_tensor(ref), atol=1e-4, rtol=1e-4)
     # 3-D input, scatter along a non-leading dimension (fallback path)
     x3 = torch.randn(4, 6 * ws, k)
     w = torch.randn(k, n) * 0.1
@@ -169,7 +217,10 @@ def _check_chunks_in_flight(rank, ws):
     from mojo_opset_amd import comm
     from mojo_opset_amd.comm import pipelines
 
+    from mojo_opset_amd import switches
+
     os.environ["MOJO_HIP_COMM_CHUNKS"] = "4"
+    switches.reload()
     log = []
 
     class Spy:
@@ -243,27 +294,42 @@ def _check_chunks_in_flight(rank, ws):
             setattr(pipelines.dist, name, fn)
 
 
-def test_pipelines_keep_several_chunks_in_flight():
-    run_dist(_check_chunks_in_flight)
+@pytest.mark.parametrize("ws", [2, 4])
+def test_pipelines_keep_several_chunks_in_flight(ws):
+    run_dist(_check_chunks_in_flight, ws=ws)
 
 
-def test_pipelines_reproduce_reference_vectors_over_gloo():
-    run_dist(_check_vectors, load_golden("compute_with_comm"))
+@pytest.mark.parametrize("ws", [2, 4, 8])
+def test_pipelines_reproduce_reference_vectors_over_gloo(ws):
+    run_dist(_check_vectors, load_golden("compute_with_comm"), ws=ws)
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_pipelines_match_oracle_over_gloo(chunks):
-    run_dist(_check_against_oracle, chunks)
+@pytest.mark.parametrize("ws,chunks", [(2, 1), (2, 3), (4, 1), (4, 4), (4, 0), (8, 1), (8, 4)])
+def test_pipelines_match_oracle_over_gloo(ws, chunks):
+    """chunks = 0: the chunk count the pipelines choose themselves (payload- and world-size-aware, comm/pipelines.py)."""
+    run_dist(_check_against_oracle, chunks, ws=ws)
 
 
-def test_plan_row_chunks():
+def test_plan_row_chunks(monkeypatch):
     from mojo_opset_amd.comm import plan_row_chunks
+    from mojo_opset_amd.comm.pipelines import chunk_count
 
+    monkeypatch.delenv("MOJO_HIP_COMM_CHUNKS", raising=False)
     assert plan_row_chunks(0) == []
     assert plan_row_chunks(100) == [(0, 100)]
-    c = plan_row_chunks(4096)
+    c = plan_row_chunks(4096, 8192, 8)
     assert c[0][0] == 0 and c[-1][1] == 4096 and all(a[1] == b[0] for a, b in zip(c, c[1:]))
-    assert all((hi - lo) % 256 == 0 for lo, hi in c[:-1]) and len(c) <= 4
+    assert all((hi - lo) % 256 == 0 for lo, hi in c[:-1])
+    # the count follows the payload and the world size (it was the constant 4): a chunk's GEMM is at least one full round of
+    # the chip's 256 tile slots, and a peer's share of a chunk is at least 512 KiB
+    assert chunk_count(4096, 8192, 8) == 2 and chunk_count(8192, 8192, 8) == 4 and chunk_count(1024, 8192, 8) == 1     # all-reduce, config 4
+    assert chunk_count(512, 8192, 8, gemm_rows_per_row=8) == 2                 # reduce-scatter at tp 8, M 4096: 2 x (8 x 256 rows)
+    assert chunk_count(2048, 8192, 2, gemm_rows_per_row=2) == 2                # ... at tp 2
+    assert chunk_count(65536, 8192, 8) == 8                                    # never more than MAX_CHUNKS
+    assert chunk_count(4096, 256, 8) == 1                                      # a narrow product: one round needs all the rows
+    assert chunk_count(512, 1280, 8, 8, 2, link_cols=8192) == 1                # all-gather feeding a narrow shard
+    monkeypatch.setenv("MOJO_HIP_COMM_CHUNKS", "4")                            # forced (the fixture reloads the switches)
+    assert len(plan_row_chunks(4096, 8192, 8)) == 4 and len(plan_row_chunks(1024, 8192, 8)) == 2
 
 
 def test_identity_without_process_group():
@@ -322,11 +388,18 @@ def _check_selector_host_logic(rank, ws):
     assert select.choose(group, "gemm_all_reduce", 1 << 22, x, lambda: calls.append("d"), lambda: calls.append("r")) == "rccl"
     assert select.choose(None, "gemm_all_reduce", 1 << 22, x, None, None) == "rccl"
     assert not calls and not select.report()                  # nothing timed, nothing cached for host tensors
+    from mojo_opset_amd import switches
+
     os.environ["MOJO_HIP_COMM_DIRECT"] = "1"
-    assert select.forced() == "direct"
+    assert select.forced() is None                            # switches are LATCHED at first use ...
+    switches.reload()
+    assert select.forced() == "direct"                        # ... and re-read on reload()
     os.environ["MOJO_HIP_COMM_DIRECT"] = "0"
+    switches.reload()
     assert select.forced() == "rccl"
     os.environ.pop("MOJO_HIP_COMM_DIRECT", None)
+    switches.reload()
+    assert select.forced() is None
     assert select.bucket(1) == 1 << 20 and select.bucket((1 << 20) + 1) == 1 << 21 and select.bucket(64 << 20) == 64 << 20
     assert select._agree_max(group, "cpu", float(rank), 5.0 - rank) == [float(ws - 1), 5.0]
     # the self-test's row-copy engine honours both row maps
@@ -341,5 +414,6 @@ def _check_selector_host_logic(rank, ws):
     assert pat.abs().max() <= 8 and torch.equal(pat, pat.float().round().to(torch.bfloat16))
 
 
-def test_selector_host_logic():
-    run_dist(_check_selector_host_logic)
+@pytest.mark.parametrize("ws", [2, 4])
+def test_selector_host_logic(ws):
+    run_dist(_check_selector_host_logic, ws=ws)

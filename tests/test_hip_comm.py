@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.distributed as dist
 
-from hip_utils import DEV, hip_cls, max_ulp_bf16ish, to_cpu, torch_cls
+from hip_utils import DEV, hip_cls, max_ulp_bf16ish, switch_env, to_cpu, torch_cls
 
 pytestmark = pytest.mark.gpu
 
@@ -72,13 +72,12 @@ def test_comm_ops_inside_a_single_rank_rccl_group():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV, 0))
     try:
         for chunks in ("1", "4"):
-            os.environ["MOJO_HIP_COMM_CHUNKS"] = chunks
-            _run_all(torch.bfloat16, None)
+            with switch_env(MOJO_HIP_COMM_CHUNKS=chunks):
+                _run_all(torch.bfloat16, None)
         _run_all(torch.float32, 2e-3)
         # fp32 reference shape of the all-to-all test (test_compute_with_comm.py:215-247)
         x, w = _mk(32, 64, 128, True, torch.float32, seed=5)
         got = hip_cls("MojoGemmAll2All")(w.to(DEV), None, True, scatter_dim=0, gather_dim=0)(x.to(DEV))
         torch.testing.assert_close(to_cpu(got), x @ w, atol=1e-4, rtol=1e-4)
     finally:
-        os.environ.pop("MOJO_HIP_COMM_CHUNKS", None)
         dist.destroy_process_group()

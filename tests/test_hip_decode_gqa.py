@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, to_cpu, torch_cls
+from hip_utils import (DEV, assert_close_tree, hip_cls, last_launch, run_hip_case, skip_unless_experiments_build, switch_env, to_cpu,
+                       torch_cls)
 
 pytestmark = pytest.mark.gpu
 ATOL = RTOL = 2e-2
@@ -137,16 +138,13 @@ def test_decode_length_above_the_hint_is_truncated_not_out_of_bounds():
     dev = [t.to(DEV) for t in (q, k, v, lens_t, table)]
     op = hip_cls("MojoPagedDecodeGQA")()
     ref = torch_cls("MojoPagedDecodeGQA")()
-    import os
+    forms = []
     for chunk_env in (None, "64"):
-        if chunk_env:
-            os.environ["MOJO_HIP_DECODE_CHUNK"] = chunk_env
-        try:
+        with switch_env(MOJO_HIP_DECODE_CHUNK=chunk_env):
             hint = 1024                                              # row 2 (3000 tokens) is above it
             out = op(*dev, max_total_seq_len=hint)
             torch.cuda.synchronize()
-        finally:
-            os.environ.pop("MOJO_HIP_DECODE_CHUNK", None)
+            forms.append(last_launch())
         assert torch.isfinite(out.float()).all()
         # rows inside the hint are untouched by the clamp
         want = ref(q, k, v, lens_t, table)
@@ -161,6 +159,7 @@ def test_decode_length_above_the_hint_is_truncated_not_out_of_bounds():
             if errs[cap] <= ATOL:
                 break
         assert min(errs.values()) <= ATOL, f"row above the hint matches no prefix: {min(errs.values())}"
+    assert "split+merge" not in forms[0] and "merge" in forms[1], forms          # both routes really ran
 
 
 def test_decode_hint_violation_raises_when_validation_is_on(monkeypatch):
@@ -234,14 +233,18 @@ def test_decode_paired_workgroups_on_ragged_batches(batch, layout, monkeypatch):
     ref = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)
     want = ref(q, k, v, lens_t, table)
     got = op(*dev, max_total_seq_len=700)
+    assert last_launch().startswith("decode_mfma:paired"), last_launch()
     assert_close_tree(to_cpu(got), want, ATOL, RTOL)
     assert torch.count_nonzero(got[3]) == 0
-    monkeypatch.setenv("MOJO_HIP_DECODE_PAIR", "0")
+    monkeypatch.setenv("MOJO_HIP_DECODE_PAIR", "0")                  # (the fixture makes the library re-read its switches)
     plain = op(*dev, max_total_seq_len=700)
+    assert last_launch().startswith("decode_mfma:fused"), last_launch()               # the OTHER form really ran
+    assert_close_tree(to_cpu(plain), want, ATOL, RTOL)
     torch.testing.assert_close(got.float(), plain.float(), atol=4e-3, rtol=4e-3)     # different chunk boundaries, same sums
     monkeypatch.delenv("MOJO_HIP_DECODE_PAIR")
     # launch-to-launch determinism
     assert torch.equal(op(*dev, max_total_seq_len=700), got)
+    assert last_launch().startswith("decode_mfma:paired"), last_launch()
 
 
 @pytest.mark.parametrize("layout", ["AABB", "ABAB"])
@@ -253,7 +256,10 @@ def test_decode_groups_of_eight_query_heads(batch, hq, hkv, d, lens, layout, hal
     blocks of four over a two-tile ring, query slices in LDS: K/V read once; the default) and the round-2 form that runs the
     4-head kernel on the two halves of every kv head (MOJO_HIP_DECODE_G8_HALVES=1, `hshift`).  Against the oracle in both
     head layouts, ragged lengths, the fused, paired and split + merge forms (short and long rows)."""
+    if halves == "1":
+        skip_unless_experiments_build()                              # (the halves form is compiled into experiments builds only)
     monkeypatch.setenv("MOJO_HIP_DECODE_G8_HALVES", halves)
+    monkeypatch.setenv("MOJO_HIP_DECODE_MFMA", "0")                  # both forms belong to the vector-unit kernel
     torch.manual_seed(hq + d)
     page = 16
     need = [(n + page - 1) // page for n in lens]
@@ -299,6 +305,7 @@ def test_decode_matrix_core_kernel(cfg, layout, monkeypatch):
     want = torch_cls("MojoPagedDecodeGQA")(is_causal=True, gqa_layout=layout)(q, k, v, lens_t, table)
     dev = [t.to(DEV) for t in (q, k, v, lens_t, table)]
     got = op(*dev)
+    assert last_launch().startswith("decode_mfma:"), last_launch()
     assert_close_tree(to_cpu(got), want, ATOL, RTOL)
     assert torch.equal(op(*dev), got)
     if (lens_t <= 0).any():
@@ -312,6 +319,8 @@ def test_decode_matrix_core_kernel(cfg, layout, monkeypatch):
     if hq // hkv in (1, 2, 4, 8):
         monkeypatch.setenv("MOJO_HIP_DECODE_MFMA", "0")
         plain = op(*dev)
+        assert last_launch().startswith("decode_valu:"), last_launch()                # the vector-unit kernel really ran
+        assert_close_tree(to_cpu(plain), want, ATOL, RTOL)
         torch.testing.assert_close(got.float(), plain.float(), atol=8e-3, rtol=8e-3)
 
 
@@ -332,3 +341,31 @@ def test_decode_matrix_core_kernel_holes_and_replay(monkeypatch):
     short = op(*dev, max_total_seq_len=128)
     want_short = ref(q, k, v, lens.clamp(max=128), table)
     assert_close_tree(to_cpu(short), want_short, ATOL, RTOL)
+
+
+@pytest.mark.parametrize("fuse", ["1", "0"], ids=["grouped", "no_fuse"])
+@pytest.mark.parametrize("cfg", [(8, 32, 8, 128, 8192), (8, 8, 1, 128, 8192), (3, 64, 8, 128, 5000)], ids=["8B_B8", "70B_tp8", "70B_B3"])
+def test_decode_small_grids_grouped_form_and_without_fusion(cfg, fuse, monkeypatch):
+    """Few (sequence, kv-head) rows, many chunks each: the GROUPED form (eight-wave workgroups merge eight chunks in LDS and
+    leave one partial; the merge kernel reads n_chunks / 8 partials per row).  ADVICE r4: with MOJO_HIP_DECODE_FUSE=0 the
+    launch fell through to one partial per chunk while the merge still divided the chunk count by eight — rows of 2..8
+    chunks were never written, longer rows merged an eighth of their partials.  Both settings against the oracle, ragged
+    lengths incl. rows of one chunk, of 2..8 chunks and of more; and the two forms agree."""
+    batch, hq, hkv, d, ctx = cfg
+    g = torch.Generator().manual_seed(ctx + batch)
+    lens = torch.randint(ctx // 2, ctx, (batch,), generator=g).tolist()
+    lens[0], lens[1] = 100, 700                                        # one chunk; a few chunks
+    lens[-1] = ctx
+    q, k, v, lens_t, table = make_decode_inputs(batch, hq, hkv, d, 0, 16, lens=lens, seed=7)
+    dev = [t.to(DEV) for t in (q, k, v, lens_t, table)]
+    op = hip_cls("MojoPagedDecodeGQA")()
+    want = torch_cls("MojoPagedDecodeGQA")()(q, k, v, lens_t, table)
+    monkeypatch.setenv("MOJO_HIP_DECODE_FUSE", fuse)
+    out = torch.full((batch, hq, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    got = op(*dev, max_total_seq_len=ctx)
+    form = last_launch()
+    assert form.startswith("decode_mfma:grouped+merge" if fuse == "1" else "decode_mfma:split+merge"), form
+    assert torch.isfinite(got.float()).all()
+    assert_close_tree(to_cpu(got), want, ATOL, RTOL)
+    assert torch.equal(op(*dev, max_total_seq_len=ctx), got)
+    del out

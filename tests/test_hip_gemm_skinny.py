@@ -3,7 +3,7 @@ K-major weights, optional row maps — reached through `mojo_hip_group_gemm_stri
 import pytest
 import torch
 
-from hip_utils import DEV, max_ulp_bf16ish, to_cpu
+from hip_utils import DEV, last_launch, max_ulp_bf16ish, to_cpu
 from mojo_opset_amd.backends.hip import lib as L
 from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
 
@@ -86,7 +86,7 @@ def test_ragged_decode_groups_integer_data_is_exact(dtype, counts, k, n):
 def test_dense_gemm_split_over_k_for_few_output_tiles_is_exact(m, k, n, bias, dtype, monkeypatch):
     """More than 128 rows but few 256x256 output tiles: K is cut into slices that go to fp32 slabs and a second launch sums
     them in slice order (gemm_api.hip, gemm_dense_splitk256).  Small-integer data makes every product and partial sum exact,
-    so the split, the unsplit (MOJO_HIP_GEMM_SPLITK256=1) and the fp32 reference must agree to the bit — ragged edges in M
+    so the split, the unsplit (MOJO_HIP_GEMM_SPLITK=1) and the fp32 reference must agree to the bit — ragged edges in M
     and N, bias added after the rounding."""
     import torch.nn.functional as F
     from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
@@ -99,11 +99,14 @@ def test_dense_gemm_split_over_k_for_few_output_tiles_is_exact(m, k, n, bias, dt
         want = (want.float() + b.float()).to(dtype)
     got = dense_gemm(x, w, b, False)
     assert torch.equal(got, want)
-    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK256", "1")
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
     assert torch.equal(dense_gemm(x, w, b, False), want)
-    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK256", "3")
+    unsplit = last_launch()
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "3")
     assert torch.equal(dense_gemm(x, w, b, False), want)
-    monkeypatch.delenv("MOJO_HIP_GEMM_SPLITK256")
+    if k >= 3 * 8 * 64:                                            # (a slice keeps at least 8 K-tiles: shorter K clamps the forced split)
+        assert ":splitk" in last_launch() and ":splitk" not in unsplit, (unsplit, last_launch())
+    monkeypatch.delenv("MOJO_HIP_GEMM_SPLITK")
     # random data: the split only reorders fp32 partial sums
     xr, wr = torch.randn(m, k, device=DEV, dtype=dtype), torch.randn(n, k, device=DEV, dtype=dtype)
     ref = F.linear(xr.float(), wr.float())
@@ -192,10 +195,13 @@ def test_gemm_swiglu_every_workgroup_size_gives_the_same_bits(monkeypatch):
     w = (torch.randn(2 * inter, k, device=DEV) * 0.1).to(torch.bfloat16)
     ref = _swiglu_chain(x, w)
     for nw in (4, 5, 6, 7, 8):
-        monkeypatch.setenv("MOJO_HIP_GEMM_GLU_WAVES", str(nw))
+        monkeypatch.setenv("MOJO_HIP_GEMM_WAVES", str(nw))
         assert torch.equal(dense_gemm_swiglu(x, w), ref), nw
-    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY_GLU", "0")
+        assert last_launch() == f"gemm_skinny:glu:waves{nw}", last_launch()
+    monkeypatch.delenv("MOJO_HIP_GEMM_WAVES")
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", str(31 & ~4))               # without the fused SwiGLU epilogue: GEMM, then the activation
     assert torch.equal(dense_gemm_swiglu(x, w), ref)
+    assert not last_launch().startswith("gemm_skinny:glu"), last_launch()
 
 
 def test_gemm_swiglu_integer_data_is_exact():

@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, hip_cls, run_hip_case, skip_unless_experiments_build, to_cpu, torch_cls
+from hip_utils import (DEV, hip_cls, last_launch, launches_of, run_hip_case, skip_unless_experiments_build, switch_env, to_cpu,
+                       torch_cls)
 
 pytestmark = pytest.mark.gpu
 # The reference's bound for these ops is atol = rtol = 1e-2, but it was never exercised against an accelerated
@@ -67,9 +68,9 @@ def exact_mla(q, ckv, kpe, table, w, sink, h, nope, rope, vd, r, kv_lens, q_off=
 def prefill_route(h, nope, rope, vd, tq, dtype=torch.bfloat16):
     """Which formulation HIPPagedPrefillMLA takes for these dimensions: "decompress" (the golden's own: un-page, one
     decompression GEMM, flash attention with D_qk = nope + rope) or "absorbed" (the decode kernel per query token)."""
-    import os
+    from mojo_opset_amd import switches
     from mojo_opset_amd.backends.hip import lib as L
-    if os.environ.get("MOJO_HIP_MLA_PREFILL", "decompress") == "absorbed" or tq < 16:
+    if switches.get("MOJO_HIP_MLA_PREFILL", "decompress") == "absorbed" or tq < 16:
         return "absorbed"
     return "decompress" if L.load().mojo_hip_mla_prefill_supported(nope, rope, vd, L.dtype_code(dtype)) else "absorbed"
 
@@ -187,12 +188,10 @@ def test_mla_prefill_reference_space(cfg, sink):
     got = op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV))
     check_mla(to_cpu(got), want, exact, prefill_route(h, nope, rope, vd, q.shape[0]))
     # the other formulation on the same inputs (the route small / unsupported shapes and over-budget batches take)
-    import os
-    os.environ["MOJO_HIP_MLA_PREFILL"] = "absorbed"
-    try:
+    with switch_env(MOJO_HIP_MLA_PREFILL="absorbed"):
         got_abs = op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV))
-    finally:
-        os.environ.pop("MOJO_HIP_MLA_PREFILL", None)
+        hist = launches_of(lambda: op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
+    assert "mla_prefill_attn" not in hist and ("mla512:" in hist or "mla_latent:" in hist), hist      # the absorbed kernels really ran
     check_mla(to_cpu(got_abs), want, exact, "absorbed")
 
 
@@ -275,6 +274,7 @@ def test_mla_decode_r512_kernels_agree(cfg, kernel, monkeypatch):
     op = build("MojoPagedDecodeMLA", h, nope, rope, vd, r, sink, w, sk, DEV)
     monkeypatch.setenv("MOJO_HIP_MLA_KERNEL", kernel)
     got = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV)))
+    assert f"mla512:{kernel}:" in launches_of(lambda: op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV)))
     again = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), lens_t.to(DEV), table.to(DEV)))
     assert torch.equal(got, again)                                   # no race between the staggered wave groups
     if b <= 5:
@@ -518,12 +518,9 @@ def test_mla_weight_repack_follows_the_parameter():
     op.load_state_dict({"kv_b_proj": w1.to(DEV)})
     assert torch.equal(op(*dev), want1)
     op.kv_b_proj.data.copy_(w2.to(DEV))                      # invisible to the version counter ...
-    os.environ["MOJO_HIP_VALIDATE"] = "1"
-    try:
+    with switch_env(MOJO_HIP_VALIDATE="1"):
         with pytest.raises(RuntimeError, match="refresh_weights"):
             op(*dev)
-    finally:
-        os.environ.pop("MOJO_HIP_VALIDATE", None)
     op.refresh_weights()                                     # ... until the caller says so
     assert torch.equal(op(*dev), want2)
 
@@ -556,24 +553,19 @@ def test_mla_prefill_decompressed_route(cfg, sink):
         assert torch.equal(got, got2)
     # the batch walked in slices of sequences (a byte budget for the decompressed image that only fits two of them), and
     # the same with the per-sequence bound passed by the caller instead of taken from the table width: same numbers
-    import os
     kv_cols_bytes = h * (nope + vd) * 2
-    os.environ["MOJO_HIP_MLA_PREFILL_BYTES"] = str(2 * table.shape[1] * page * kv_cols_bytes)
-    try:
+    with switch_env(MOJO_HIP_MLA_PREFILL_BYTES=2 * table.shape[1] * page * kv_cols_bytes):
         sliced = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
-    finally:
-        os.environ.pop("MOJO_HIP_MLA_PREFILL_BYTES", None)
     assert torch.equal(sliced, got)
     hinted = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV),
                        max_total_seq_len=max(kv_lens)))
     assert torch.equal(hinted, got)
     # dispatch slots per (sequence, head) padded to an odd count (engine rotation) or not: every block visited once either way
-    os.environ["MOJO_HIP_MLA_PREFILL_ODD_SLOTS"] = "0"
-    try:
-        even = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
-    finally:
-        os.environ.pop("MOJO_HIP_MLA_PREFILL_ODD_SLOTS", None)
-    assert torch.equal(even, got)
+    from mojo_opset_amd.backends.hip import lib as _L
+    if _L.built_with_experiments():                      # (the placement switch exists in experiments builds only)
+        with switch_env(MOJO_HIP_MLA_PREFILL_ODD_SLOTS="0"):
+            even = to_cpu(op(q.to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV), cu_total_seq_lens=cu(kv_lens).to(DEV)))
+        assert torch.equal(even, got)
     # padding rows behind the last sequence read as zeros (the golden's `torch.zeros` output, :393)
     pad = torch.randn(5, h, nope + rope, generator=g).to(torch.bfloat16)
     got3 = to_cpu(op(torch.cat([q, pad]).to(DEV), ckv.to(DEV), kpe.to(DEV), cu(q_lens).to(DEV), table.to(DEV),
@@ -582,7 +574,7 @@ def test_mla_prefill_decompressed_route(cfg, sink):
 
 
 def test_mla_prefill_head_group_pipeline_gives_the_same_bits(monkeypatch):
-    """MOJO_HIP_MLA_PREFILL_GROUPS: the decompression of head group g + 1 on a side stream beside the attention of group g
+    """`op.prefill_head_groups`: the decompression of head group g + 1 on a side stream beside the attention of group g
     (opt-in; `mojo_hip_mla_prefill_attn` takes a head range, the GEMM writes a column block of the image).  Per-head work is
     independent: every group count gives the bits of the single launch, also when the batch is walked in slices."""
     h, nope, rope, vd, r, page = 64, 128, 64, 128, 512, 16
@@ -596,7 +588,7 @@ def test_mla_prefill_head_group_pipeline_gives_the_same_bits(monkeypatch):
     kw = dict(cu_total_seq_lens=cu(kv_lens).to(DEV), max_total_seq_len=max(kv_lens))
     outs = {}
     for groups in ("1", "2", "4"):
-        monkeypatch.setenv("MOJO_HIP_MLA_PREFILL_GROUPS", groups)
+        op.prefill_head_groups = int(groups)
         outs[groups] = to_cpu(op(*args, **kw))
     assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["4"])
     monkeypatch.setenv("MOJO_HIP_MLA_PREFILL_BYTES", str(max(kv_lens) * h * (nope + vd) * 2))      # one sequence per slice

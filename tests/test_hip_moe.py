@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, hip_cls, run_hip_case, to_cpu, torch_cls
+from hip_utils import DEV, hip_cls, last_launch, run_hip_case, to_cpu, torch_cls
 from mojo_opset_amd.core import check_tol_diff
 
 pytestmark = pytest.mark.gpu
@@ -214,13 +214,14 @@ def test_experts_fused_swiglu_epilogue_is_bit_identical_to_the_two_kernel_path(e
     x = torch.randn(sum(counts), hidden, dtype=dtype, device=DEV)
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
     act = torch.empty(x.shape[0], inter, dtype=dtype, device=DEV)
-    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY_RAGGED", "0")       # (a decode-sized case would otherwise take the streaming form)
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", str(31 & ~2))     # (no ragged streaming form: a decode-sized case would otherwise take it)
     assert op._fused_up_swiglu(x, op.up_proj_weight.detach(), cnt, act, inter)
     fused = op(x, cnt)
     monkeypatch.setenv("MOJO_HIP_EXPERTS_FUSED", "0")
+    assert not op._fused_up_swiglu(x, op.up_proj_weight.detach(), cnt, act, inter)       # the switch is seen: the two-kernel path runs
     plain = op(x, cnt)
     assert torch.equal(fused, plain)
-    monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY_RAGGED")
+    monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY")
     monkeypatch.delenv("MOJO_HIP_EXPERTS_FUSED")
     assert torch.equal(op(x, cnt), fused)                        # whatever the library picks by itself: the same bits
 
@@ -247,10 +248,12 @@ def test_experts_streaming_form_for_ragged_decode_groups_is_bit_identical(expert
     x = torch.rand(sum(counts), hidden, dtype=dtype, device=DEV)          # (the data of the reference's own experts test)
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
     streamed = op(x, cnt)
-    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY_RAGGED", "0")
+    assert last_launch() == "gemm_skinny:ragged", last_launch()
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", str(31 & ~2))     # every decode-sized form but the ragged one
     tiled = op(x, cnt)
+    assert last_launch().startswith("gemm256:") or last_launch().startswith("gemm_generic"), last_launch()   # the OTHER kernel really ran
     assert torch.equal(streamed, tiled)
-    monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY_RAGGED")
+    monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY")
     op.forward_diff_with(ref, x, cnt, mixed_tol=True, ref_device="cpu")
 
 
@@ -311,16 +314,19 @@ def test_moe_layer_reference_space(experts, k, hidden, inter, tokens):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("k,hidden,tokens", [(2, 4096, 1000), (1, 512, 33), (8, 1024, 70), (3, 2048, 4096)])
 def test_gating_eight_expert_kernel_agrees_with_general_kernel(k, hidden, tokens, dtype, monkeypatch):
-    """E = 8 takes a dedicated streaming kernel (a lane owns hidden elements, not an expert); MOJO_HIP_GATING_E8=0 runs the
+    """E = 8 takes a dedicated streaming kernel (a lane owns hidden elements, not an expert); MOJO_HIP_GATING=1 runs the
     general one.  Identical expert choice (up to near-ties), gates to 1e-5, and the oracle agrees with both."""
     torch.manual_seed(5)
     op = hip_cls("MojoMoEGating")(hidden_size=hidden, num_experts=8, top_k=k).to(DEV)
     with torch.no_grad():
         op.gate_weight.normal_(std=0.05)
     x = torch.rand(tokens, hidden, dtype=dtype, device=DEV)
+    monkeypatch.setenv("MOJO_HIP_GATING", "2")                   # streaming kernels only (the E = 8 specialisation where it applies)
     idx_s, g_s = op(x)
-    monkeypatch.setenv("MOJO_HIP_GATING_E8", "0")
+    assert last_launch() == ("moe_gating:e8" if hidden % 512 == 0 and tokens >= 32 else "moe_gating:general"), last_launch()
+    monkeypatch.setenv("MOJO_HIP_GATING", "1")                   # (the fixture makes the library re-read its switches)
     idx_g, g_g = op(x)
+    assert last_launch() == "moe_gating:general", last_launch()  # the general kernel really ran
     same = idx_s == idx_g
     assert float(same.float().mean()) >= 0.999
     torch.testing.assert_close(g_s[same], g_g[same], atol=1e-5, rtol=1e-4)
@@ -328,9 +334,10 @@ def test_gating_eight_expert_kernel_agrees_with_general_kernel(k, hidden, tokens
     ref = torch_cls("MojoMoEGating")(hidden_size=hidden, num_experts=8, top_k=k)
     ref.load_state_dict({k_: v_.cpu() for k_, v_ in op.state_dict().items()})
     want_idx, want_g = ref(x.cpu())
-    ok = idx_s.cpu() == want_idx
-    assert float(ok.float().mean()) >= 0.999
-    torch.testing.assert_close(g_s.cpu()[ok], want_g[ok], atol=1e-5, rtol=1e-4)
+    for idx_d, g_d in ((idx_s, g_s), (idx_g, g_g)):              # the oracle against BOTH kernels
+        ok = idx_d.cpu() == want_idx
+        assert float(ok.float().mean()) >= 0.999
+        torch.testing.assert_close(g_d.cpu()[ok], want_g[ok], atol=1e-5, rtol=1e-4)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -342,10 +349,12 @@ def test_gating_mfma_route_agrees_with_vector_route(dtype, monkeypatch):
     with torch.no_grad():
         op.gate_weight.normal_(std=0.05)
     x = torch.rand(tokens, hidden, dtype=dtype, device=DEV)
-    monkeypatch.setenv("MOJO_HIP_GATING_MFMA", "1")
+    monkeypatch.setenv("MOJO_HIP_GATING", "4")
     idx_m, g_m = op(x)
-    monkeypatch.setenv("MOJO_HIP_GATING_MFMA", "0")
+    assert last_launch() == "moe_gating:mfma", last_launch()
+    monkeypatch.setenv("MOJO_HIP_GATING", "1")
     idx_v, g_v = op(x)
+    assert last_launch() == "moe_gating:general", last_launch()
     same = idx_m == idx_v
     assert float(same.float().mean()) >= 0.999
     torch.testing.assert_close(g_m[same], g_v[same], atol=1e-4, rtol=1e-3)
@@ -364,12 +373,13 @@ def test_gating_few_token_kernel_matches_the_oracle(tokens, experts, k, hidden, 
     op = hip_cls("MojoMoEGating")(hidden_size=hidden, num_experts=experts, top_k=k).to(DEV)
     op.load_state_dict(ref.state_dict())
     x = torch.rand(tokens, hidden).to(dtype)
-    monkeypatch.setenv("MOJO_HIP_GATING_SMALL", "1")
+    monkeypatch.setenv("MOJO_HIP_GATING", "3")
     idx_s, gate_s = to_cpu(op(x.to(DEV)))
+    assert last_launch() == "moe_gating:small", last_launch()
     idx_w, gate_w = ref(x)
-    monkeypatch.setenv("MOJO_HIP_GATING_SMALL", "0")
-    monkeypatch.setenv("MOJO_HIP_GATING_MFMA", "0")
+    monkeypatch.setenv("MOJO_HIP_GATING", "1")
     idx_g, gate_g = to_cpu(op(x.to(DEV)))
+    assert last_launch() == "moe_gating:general", last_launch()
     # selections can only differ where two probabilities are closer than fp32 summation-order noise
     for idx_o, gate_o in ((idx_w.to(torch.int32), gate_w), (idx_g, gate_g)):
         same = (idx_s == idx_o).all(-1)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, assert_close_tree, hip_cls, run_hip_case, skip_unless_experiments_build, to_cpu, torch_cls
+from hip_utils import DEV, assert_close_tree, hip_cls, last_launch, run_hip_case, skip_unless_experiments_build, to_cpu, torch_cls
 
 pytestmark = pytest.mark.gpu
 ATOL = RTOL = 2e-2
@@ -152,8 +152,10 @@ def test_prefill_fast_staging_is_bit_identical_to_general_staging(page, layout_n
     args = (q.to(DEV), k, v, cu_q.to(DEV), table.to(DEV))
     monkeypatch.setenv("MOJO_HIP_PREFILL_FAST_STAGE", "0")
     want = op(*args, cu_total_seq_lens=cu_kv.to(DEV))
+    assert ":general_stage:" in last_launch(), last_launch()
     monkeypatch.setenv("MOJO_HIP_PREFILL_FAST_STAGE", "1")
     got = op(*args, cu_total_seq_lens=cu_kv.to(DEV))
+    assert ":fast_stage:" in last_launch(), last_launch()             # two different staging paths really ran
     assert torch.equal(got, want)
 
 
@@ -164,6 +166,7 @@ def test_prefill_block_order_does_not_change_the_result(monkeypatch):
     q, k, v, cu_q, table, cu_kv, kv_lens = make_prefill_inputs(q_lens, cached, 8, 2, 128, 16, seed=11, pad_tokens=5)
     op = hip_cls("MojoPagedPrefillGQA")()
     args = [t.to(DEV) for t in (q, k, v, cu_q, table)]
+    skip_unless_experiments_build()                                    # (the placement switch exists in experiments builds only)
     monkeypatch.setenv("MOJO_HIP_PREFILL_SKEW", "0")
     plain = op(*args, cu_total_seq_lens=cu_kv.to(DEV), max_q_len=max(q_lens), max_total_seq_len=max(kv_lens))
     monkeypatch.setenv("MOJO_HIP_PREFILL_SKEW", "1")
@@ -202,11 +205,13 @@ def test_prefill_key_split(cfg, layout, monkeypatch):
         assert L.load().mojo_hip_paged_prefill_gqa_workspace_bytes(q.shape[0], len(q_lens), hq, hkv, d, page, table.shape[1],
                                                                    max(q_lens), max(kv_lens)) > 0, "the rule should split this launch"
     got = op(*dev, **dkw)
+    assert not last_launch().endswith(":ksplit1"), last_launch()           # the split form really ran
     assert_close_tree(to_cpu(got), want, ATOL, RTOL)
     assert torch.count_nonzero(got[sum(q_lens):]) == 0                     # padding rows
     assert torch.equal(op(*dev, **dkw), got)
     monkeypatch.setenv("MOJO_HIP_PREFILL_KSPLIT", "1")
     plain = op(*dev, **dkw)
+    assert last_launch().endswith(":ksplit1"), last_launch()               # ... and the unsplit one
     torch.testing.assert_close(got.float(), plain.float(), atol=8e-3, rtol=8e-3)
     # a hole in the block table: rows behind the first negative id read as zero K/V, in the split form too
     table2 = table.clone()

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import bit_equal, load_golden
-from hip_utils import DEV, hip_cls, run_hip_case, to_cpu, torch_cls
+from hip_utils import DEV, hip_cls, last_launch, run_hip_case, to_cpu, torch_cls
 from oracle import quant_gemm_formula
 
 pytestmark = pytest.mark.gpu
@@ -126,9 +126,14 @@ def test_quant_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(m, k, 
     op.weight_scale.copy_(torch.rand(n, device=DEV) * 0.02)
     s_in = torch.rand(m, device=DEV)
     staged = op(x, s_in)
-    monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")
+    assert last_launch().startswith("gemm256:staged"), last_launch()
+    monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")          # (the fixture makes the library re-read its switches)
     direct = op(x, s_in)
+    assert last_launch().startswith("gemm256:direct"), last_launch()         # the OTHER epilogue really ran
     assert torch.equal(staged, direct)
+    if quant_dtype == torch.int8:                                 # the direct-store epilogue on its own: the integer formula, exactly
+        exact = quant_gemm_formula(x.cpu(), op.weight.cpu().t(), s_in.cpu(), op.weight_scale.cpu(), odt)
+        torch.testing.assert_close(to_cpu(direct), exact, atol=0, rtol=0)
 
 
 # ---- BASELINE config 5 at full size (DeepSeek-V3 dense projections, M = 4096) -------------------------------------------
@@ -229,7 +234,7 @@ def test_quant_gemm_split_k_route_is_deterministic_and_exact(quant_dtype, monkey
     exact = quant_gemm_formula(x, w.t(), xs, ws.to(torch.bfloat16), torch.bfloat16)
     outs = {}
     for sk in ("1", "2", "8"):
-        monkeypatch.setenv("MOJO_HIP_QGEMM_SPLITK", sk)
+        monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", sk)
         a = op(x.to(DEV), xs.to(DEV))
         b = op(x.to(DEV), xs.to(DEV))
         assert torch.equal(a, b), f"split {sk}: not deterministic"
