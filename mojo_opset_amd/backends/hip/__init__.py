@@ -5,7 +5,7 @@ the registry ignores them; on a ROCm host they are the first-priority backend.
 """
 from .operators.attention import *  # noqa: F401,F403
 from .operators.streaming import *  # noqa: F401,F403
-from .operators.gemm import HIPGroupGemm, HIPQuantGemm  # noqa: F401
+from .operators.gemm import HIPGemm, HIPGroupGemm, HIPQuantGemm, HIPSwiGLUMLP  # noqa: F401
 from .operators.mla import HIPPagedDecodeMLA, HIPPagedPrefillMLA  # noqa: F401
 from .operators.compute_with_comm import (HIPAllGatherGemm, HIPGemmAll2All, HIPGemmAllReduce,  # noqa: F401
                                           HIPGemmReduceScatter)

@@ -1,7 +1,8 @@
 """HIP<Op> classes of the GEMM family."""
 import torch
 
-from ....core.operators.gemm import MojoGroupGemm, MojoQuantGemm
+from ....core.operators.gemm import MojoGemm, MojoGroupGemm, MojoQuantGemm
+from ....core.operators.mlp import MojoSwiGLUMLP
 from .. import lib as L
 
 _ROCM = ["rocm"]
@@ -126,6 +127,43 @@ def qkv_rope_store(x: torch.Tensor, weight_qkv: torch.Tensor, bias, cos: torch.T
         q_heads, kv_heads, d, x2.stride(0), w.stride(0), n_blocks, page, key_cache.stride(0), key_cache.stride(1),
         key_cache.stride(2), L.dtype_code(x.dtype), L.ptr(ws), ws.numel(), L.stream_of(x2)), "hip qkv_rope_store")
     return q_out
+
+
+class HIPGemm(MojoGemm):
+    """`MojoGemm` (core/operators/gemm.py:12-56) on `mojo_hip_gemm`: ``F.linear(input, weight, bias)``.  Decode-sized inputs take
+    the weight-stream kernels with split-K (csrc/gemm_skinny.hip), larger ones the 256 x 256 tile kernel; the product is rounded
+    to the storage type and the bias added after the rounding, as torch's 16-bit ``F.linear`` does on the CPU."""
+
+    supported_platforms_list = _ROCM
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        w = self.weight.detach()
+        b = None if self.bias is None else self.bias.detach()
+        return dense_gemm(input, w, b, False)
+
+
+class HIPSwiGLUMLP(MojoSwiGLUMLP):
+    """`MojoSwiGLUMLP` (core/operators/mlp.py:7-37): ``fc2(silu(a1) * a2)``, ``a1, a2 = fc1(x).chunk(2, -1)``.  16-bit inputs
+    run `mojo_hip_gemm_swiglu` (at <= 64 rows ONE launch whose epilogue applies SwiGLU to the accumulators — the
+    ``[M, 2 * hidden]`` product never exists; same rounding points as projection -> `MojoSwiGLU`) followed by `mojo_hip_gemm`;
+    fp32 inputs run the projection, `mojo_hip_swiglu_rows` on its two halves, and the second projection.  ``fc1.weight``
+    ``[2 * hidden, in]`` is used in place: its first ``hidden`` rows are the gate, the rest the up projection — the layout
+    the fused kernel wants, so `state_dict` keys and layouts stay the golden's."""
+
+    supported_platforms_list = _ROCM
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        w1, w2 = self.fc1.weight.detach(), self.fc2.weight.detach()
+        if x.dtype in (torch.bfloat16, torch.float16) and x.dtype == w1.dtype == w2.dtype:
+            return dense_gemm(dense_gemm_swiglu(x, w1), w2, None, False)
+        a = dense_gemm(x, w1, None, False)
+        hidden = w1.shape[0] // 2
+        a2d = a.reshape(-1, 2 * hidden)
+        act = torch.empty(a2d.shape[0], hidden, dtype=a.dtype, device=a.device)
+        L.check(L.load().mojo_hip_swiglu_rows(L.ptr(a2d), L.c_void_p(a2d.data_ptr() + hidden * a2d.element_size()), L.ptr(act),
+                                              a2d.shape[0], hidden, 2 * hidden, 2 * hidden, hidden, L.dtype_code(a.dtype), 0.0,
+                                              L.stream_of(a2d)), "HIPSwiGLUMLP swiglu")
+        return dense_gemm(act.reshape(*a.shape[:-1], hidden), w2, None, False)
 
 
 class HIPGroupGemm(MojoGroupGemm):

@@ -1,12 +1,56 @@
-"""API classes `MojoGroupGemm` / `MojoQuantGemm`.
+"""API classes `MojoGemm` / `MojoGroupGemm` / `MojoQuantGemm` (`MojoGemm` is the reference's hook for the
+decode-sized dense products).
 
-Follows `mojo_opset/core/operators/gemm.py` (:59-124, :127-231).
+Follows `mojo_opset/core/operators/gemm.py` (:12-56, :59-124, :127-231).
 """
-from typing import Union
+import math
+from typing import Optional, Union
 
 import torch
+import torch.nn as nn
 
 from ..operator import MojoOperator
+
+
+class MojoGemm(MojoOperator):
+    """forward(input [..., in_features]) -> [..., out_features] = ``F.linear(input, weight, bias)``.
+
+    Either ``(in_features, out_features, bias=True)`` — Parameters ``weight [out, in]`` and ``bias [out]`` created with the
+    tensor factory kwargs and initialised like ``nn.Linear`` — or ``weight=<2-D tensor>`` alone (wrapped as the Parameter,
+    no bias).  ValueErrors as the reference raises them (`gemm.py:22-34`)."""
+
+    def __init__(self, in_features: Optional[int] = None, out_features: Optional[int] = None, bias: bool = True,
+                 weight: Optional[torch.Tensor] = None, **kwargs):
+        super().__init__(**kwargs)
+        if weight is not None:
+            if in_features is not None or out_features is not None:
+                raise ValueError("Provide either weight or in_features/out_features, not both.")
+            if weight.dim() != 2:
+                raise ValueError(f"weight must be 2D, got shape {tuple(weight.shape)}.")
+            self.out_features, self.in_features = weight.shape
+            self.weight = nn.Parameter(weight)
+            self.register_parameter("bias", None)
+            return
+        if in_features is None or out_features is None:
+            raise ValueError("in_features and out_features are required when weight is not provided.")
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.empty((out_features, in_features), **self.tensor_factory_kwargs))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features, **self.tensor_factory_kwargs))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"
 
 
 class MojoGroupGemm(MojoOperator):

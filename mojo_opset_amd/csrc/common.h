@@ -204,6 +204,14 @@ template <> struct elt<f16_t> {
   static __device__ __forceinline__ f16_t from_f(float v) { return static_cast<f16_t>(v); }
 };
 
+// acc (+ bias) -> storage type.  The golden has BOTH forms (core/operators/compute_with_comm.py:12-24): `input @ weight + bias`
+// for [K,N] weights rounds the product and then the sum (two roundings), `F.linear(input, weight, bias)` for [N,K] weights adds
+// the bias to the fp32 accumulator and rounds once (torch's addmm; also `MojoGemm.forward`, core/operators/gemm.py:45-46).
+template <typename T>
+__device__ __forceinline__ T round_with_bias(float acc, T bias, bool fused) {
+  return fused ? elt<T>::from_f(acc + elt<T>::to_f(bias)) : elt<T>::from_f(elt<T>::to_f(elt<T>::from_f(acc)) + elt<T>::to_f(bias));
+}
+
 template <typename T, int N> struct vec_of { typedef T type __attribute__((ext_vector_type(N))); };
 template <typename T> struct vec_of<T, 1> { typedef T type; };
 

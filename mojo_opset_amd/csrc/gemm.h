@@ -13,7 +13,8 @@ struct GemmArgs {
   const void* A;
   const void* W;
   void* C;
-  const void* bias;          // optional [N], same dtype as C; added after rounding (golden: two ops)
+  const void* bias;          // optional [N], same dtype as C; added after rounding (golden: two ops) unless bias_fused
+  int bias_fused = 0;        // 1: bias joins the fp32 accumulator, ONE rounding (F.linear semantics: the [N,K] weight layout)
   int64_t lda, ldc, w_group, w_k, w_n;
   int K, N, G;
   const int32_t* row_start;  // [G+1]   (unused when uniform_rows > 0)

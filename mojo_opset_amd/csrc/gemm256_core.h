@@ -74,10 +74,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base
 // ---- epilogues ---------------------------------------------------------------------------------------
 // A lane owns row m = ... + (lane & 15) and the 4 consecutive columns n .. n+3 of each 16x16 tile.
 template <typename T>
-struct EpiloguePlain {       // C = round_T(acc) (+ bias, added after the rounding: the golden runs two ops)
+struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the golden's `x @ w + b`), or round_T(acc + bias) (its F.linear)
   static constexpr bool kRowStaged = sizeof(T) == 2;   // may go through the wave-private LDS transpose (see the kernel's epilogue)
   typedef T out_t;
-  T* C; int64_t ldc; const T* bias;
+  T* C; int64_t ldc; const T* bias; bool bias_fused = false;
   __host__ __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
   __device__ __forceinline__ typename vec_of<T, 4>::type to4(int, f32x4 acc) const {
     typename vec_of<T, 4>::type o;
@@ -94,7 +94,7 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias, added after the roundi
     if (bias) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (n + e < n_limit) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
+        if (n + e < n_limit) o[e] = round_with_bias<T>(acc[e], bias[n + e], bias_fused);
     }
     T* dst = C + static_cast<int64_t>(m) * ldc + n;
     if (n + 4 <= n_limit) {

@@ -152,6 +152,7 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
   MOJO_REQUIRE(workspace && workspace_bytes >= 16 && aligned_to(workspace, 4), MOJO_EWORKSPACE, "gemm: workspace too small");
   GemmArgs a;
   a.A = input; a.W = weight; a.C = out; a.bias = bias;
+  a.bias_fused = (bias && w_k_stride == 1) ? 1 : 0;                     // [N,K] weights = the golden's F.linear(input, weight, bias): one rounding
   a.lda = lda; a.ldc = ldc; a.w_group = 0; a.w_k = w_k_stride; a.w_n = w_n_stride;
   a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
   if (a_map) {
@@ -259,6 +260,7 @@ extern "C" int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* wei
     if (sk > 1 && ws2_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4) {
       GemmArgs a;
       a.A = input; a.W = weight; a.C = gemm_out; a.bias = bias;
+      a.bias_fused = bias ? 1 : 0;                                       // (w_k == 1 here: F.linear semantics, as mojo_hip_gemm)
       a.lda = lda; a.ldc = n; a.w_group = 0; a.w_k = 1; a.w_n = w_n_stride;
       a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
       a.row_start = nullptr; a.tile_start = nullptr;

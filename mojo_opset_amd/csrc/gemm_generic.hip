@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(GemmArgs a) {
         const int n = n0 + tx * 4 + j;
         if (n >= a.N) continue;
         T o = elt<T>::from_f(acc[i][j]);
-        if (bias) o = elt<T>::from_f(elt<T>::to_f(o) + elt<T>::to_f(bias[n]));
+        if (bias) o = round_with_bias<T>(acc[i][j], bias[n], a.bias_fused != 0);
         C[static_cast<int64_t>(map_row(m, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n] = o;
       }
     }

@@ -50,7 +50,7 @@ int launch_gemm_mfma256(const GemmArgs& a_in, int dtype, int64_t m_total, hipStr
     const long long w128 = MOJO_SWITCH("MOJO_HIP_GEMM_W128", 0);
     const char e[2] = {static_cast<char>('0' + (w128 >= 0 && w128 <= 9 ? w128 : 0)), 0};
     if (e[0] >= '1' && e[0] <= '5' && dtype == MOJO_BF16 && a.w_k == 1 && !a.glu && a.splitk == 1 && a.K % 32 == 0 && a.K >= 128) {
-      g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias)};
+      g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias), a.bias_fused != 0};
       if (e[0] == '2') return w128::gemm_w128_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, 1>(a, epi, m_total, s);   // 2-4: timing-only ablations
       if (e[0] == '3') return w128::gemm_w128_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, 2>(a, epi, m_total, s);
       if (e[0] == '4') return w128::gemm_w128_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, 3>(a, epi, m_total, s);
@@ -60,10 +60,10 @@ int launch_gemm_mfma256(const GemmArgs& a_in, int dtype, int64_t m_total, hipStr
   }
 #endif
   if (dtype == MOJO_BF16) {
-    g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias)};
+    g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias), a.bias_fused != 0};
     return g256::gemm256_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, kExperimentsBuild>(a, epi, m_total, s);
   }
-  g256::EpiloguePlain<f16_t> epi{static_cast<f16_t*>(a.C), a.ldc, static_cast<const f16_t*>(a.bias)};
+  g256::EpiloguePlain<f16_t> epi{static_cast<f16_t*>(a.C), a.ldc, static_cast<const f16_t*>(a.bias), a.bias_fused != 0};
   return g256::gemm256_launch<g256::PolF16, g256::EpiloguePlain<f16_t>, kExperimentsBuild>(a, epi, m_total, s);
 }
 

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(v[e]);
     if (bias) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
+      for (int e = 0; e < 4; ++e) o[e] = round_with_bias<T>(v[e], bias[n + e], a.bias_fused != 0);
     }
     *reinterpret_cast<V4*>(C + static_cast<int64_t>(RAGGED ? row_base + t : map_row(row_base + t, a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
   };
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_finalize_kernel(GemmArgs a, i
     for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(acc[e]);
     if (bias) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(bias[n + e]));
+      for (int e = 0; e < 4; ++e) o[e] = round_with_bias<T>(acc[e], bias[n + e], a.bias_fused != 0);
     }
     *reinterpret_cast<V4*>(C + static_cast<int64_t>(map_row(static_cast<int>(m), a.c_rc, a.c_ml, a.c_off, a.c_mul)) * a.ldc + n) = o;
   }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_resnorm_kernel(GemmArgs a, in
     if (bias) {
       const V b = load_vec<T, VEC>(bias + v * VEC);
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) x[j] = static_cast<T>(static_cast<float>(x[j]) + static_cast<float>(b[j]));
+      for (int j = 0; j < VEC; ++j) x[j] = round_with_bias<T>(j < 4 ? lo[j & 3] : hi[j & 3], b[j], a.bias_fused != 0);
     }
     if (gemm_out && live) store_vec<T, VEC>(gemm_out + row * dim + v * VEC, x);
     if (residual) {

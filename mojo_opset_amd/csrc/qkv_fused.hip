@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void qkv_rope_store_kernel(QkvFusedArgs a) {
       if (a.bias) {
         const V8 b1 = load_vec<T, 8>(static_cast<const T*>(a.bias) + col), b2 = load_vec<T, 8>(static_cast<const T*>(a.bias) + col + half);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          x1[j] = static_cast<T>(static_cast<float>(x1[j]) + static_cast<float>(b1[j]));
-          x2[j] = static_cast<T>(static_cast<float>(x2[j]) + static_cast<float>(b2[j]));
+        for (int j = 0; j < 8; ++j) {                      // F.linear semantics ([N,K] weights): bias joins the accumulator, one rounding
+          x1[j] = round_with_bias<T>(j < 4 ? s1l[j & 3] : s1h[j & 3], b1[j], true);
+          x2[j] = round_with_bias<T>(j < 4 ? s2l[j & 3] : s2h[j & 3], b2[j], true);
         }
       }
     } else {

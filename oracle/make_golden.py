@@ -343,6 +343,35 @@ def gen_group_gemm():
     return recs
 
 
+def gen_dense():
+    """`MojoGemm` (core/operators/gemm.py:12-56) and `MojoSwiGLUMLP` (core/operators/mlp.py:7-37): the reference's hooks for the
+    dense projections and the gated MLP of a decoder layer (decode-sized and prefill-sized rows, with / without bias, the
+    ``weight=`` constructor form, 3-D inputs)."""
+    recs = []
+    for ci, (m, k, n, dtype, bias) in enumerate([
+        ((33,), 256, 192, torch.bfloat16, True), ((5,), 384, 64, torch.float16, False), ((2, 17), 128, 96, torch.bfloat16, True),
+        ((300,), 256, 136, torch.float16, True), ((7,), 64, 40, torch.float32, True), ((64,), 512, 256, torch.bfloat16, False),
+    ]):
+        torch.manual_seed(2100 + ci)
+        x = torch.randn(*m, k).to(dtype)
+        state = {"weight": (torch.randn(n, k) * 0.1).to(dtype)}
+        if bias:
+            state["bias"] = torch.randn(n).to(dtype)
+        recs.append(run_case("MojoGemm", {"args": (k, n), "kwargs": {"bias": bias, "dtype": dtype}}, state, (x,), {}))
+    torch.manual_seed(2150)
+    w = (torch.randn(48, 128) * 0.1).to(torch.bfloat16)
+    recs.append(run_case("MojoGemm", {"kwargs": {"weight": w}}, {}, (torch.randn(9, 128).to(torch.bfloat16),), {}))
+    for ci, (m, inp, outp, hidden, dtype) in enumerate([
+        ((40,), 128, 64, 96, torch.bfloat16), ((3,), 128, 128, 192, torch.bfloat16), ((2, 9), 64, 32, 72, torch.float16),
+        ((130,), 96, 64, 128, torch.float16), ((6,), 32, 16, 24, torch.float32),
+    ]):
+        torch.manual_seed(2200 + ci)
+        x = torch.randn(*m, inp).to(dtype)
+        state = {"fc1.weight": (torch.randn(2 * hidden, inp) * 0.1).to(dtype), "fc2.weight": (torch.randn(outp, hidden) * 0.1).to(dtype)}
+        recs.append(run_case("MojoSwiGLUMLP", {"args": (inp, outp, hidden)}, state, (x,), {}, cast=dtype))
+    return recs
+
+
 def gen_moe():
     """Gating / dispatch / experts / combine on the reference's own small shapes (tests/accuracy/operators/test_moe.py)
     plus ragged and empty-bucket cases."""
@@ -624,7 +653,7 @@ def main():
     torch.set_num_threads(4)
     makers = {
         "paged_decode_gqa": gen_decode_gqa, "paged_prefill_gqa": gen_prefill_gqa, "paged_mla": gen_mla, "rmsnorm": gen_norm,
-        "swiglu": gen_swiglu, "rope": gen_rope, "group_gemm": gen_group_gemm, "quant_gemm": gen_quant_gemm, "moe": gen_moe,
+        "swiglu": gen_swiglu, "rope": gen_rope, "group_gemm": gen_group_gemm, "dense": gen_dense, "quant_gemm": gen_quant_gemm, "moe": gen_moe,
         "moe_layer": gen_moe_layer, "quantizers": gen_quantizers, "store_paged_mla": gen_store_mla,
         "compute_with_comm": gen_comm, "paged_cache": gen_paged_cache,
     }

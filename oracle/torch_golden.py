@@ -17,6 +17,7 @@ from mojo_opset_amd.core.operators import compute_with_comm as _cc
 from mojo_opset_amd.core.operators import gemm as _gemm_api
 from mojo_opset_amd.core.operators import kv_cache as _kv
 from mojo_opset_amd.core.operators import mla as _mla
+from mojo_opset_amd.core.operators import mlp as _mlp_api
 from mojo_opset_amd.core.operators import moe as _moe
 from mojo_opset_amd.core.operators import normalization as _norm
 from mojo_opset_amd.core.operators import position_embedding as _pe
@@ -27,7 +28,7 @@ _CPU = ["rocm", "cpu"]
 __all__ = [
     "TorchPagedDecodeGQA", "TorchPagedPrefillGQA", "TorchPagedDecodeMLA", "TorchPagedPrefillMLA",
     "TorchRMSNorm", "TorchRMSNormInplace", "TorchResidualAddRMSNorm", "TorchSwiGLU", "TorchRotaryEmbedding", "TorchApplyRoPE",
-    "TorchStorePagedKVCache", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
+    "TorchStorePagedKVCache", "TorchGemm", "TorchSwiGLUMLP", "TorchGroupGemm", "TorchQuantGemm", "TorchGemmAllReduce",
     "TorchAllGatherGemm", "TorchGemmAll2All", "TorchGemmReduceScatter",
     "TorchMoEGating", "TorchMoEDispatch", "TorchExperts", "TorchMoECombine", "TorchMoE", "TorchDynamicQuant",
     "TorchResidualAddRMSNormQuant", "TorchStorePagedMLAKVCache",
@@ -376,6 +377,27 @@ class TorchStorePagedKVCache(_kv.MojoStorePagedKVCache):
 # ----------------------------------------------------------------------------------------------
 # gemm
 # ----------------------------------------------------------------------------------------------
+class TorchGemm(_gemm_api.MojoGemm):
+    """`core/operators/gemm.py:45-46`: ``F.linear(input, weight, bias)``."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return F.linear(input, self.weight, self.bias)
+
+
+class TorchSwiGLUMLP(_mlp_api.MojoSwiGLUMLP):
+    """`core/operators/mlp.py:27-33`: ``fc2(silu(a1) * a2)``, ``a1, a2 = fc1(x).chunk(2, -1)`` — in a 16-bit dtype the
+    projection, the SiLU and the product are each rounded to the storage type."""
+
+    supported_platforms_list = _CPU
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        a = self.fc1(x)
+        a1, a2 = a.chunk(2, dim=-1)
+        return self.fc2(F.silu(a1) * a2)
+
+
 class TorchGroupGemm(_gemm_api.MojoGroupGemm):
     """`core/operators/gemm.py:69-117`."""
 

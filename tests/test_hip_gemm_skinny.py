@@ -55,10 +55,10 @@ def test_skinny_dense_gemm_matches_fp32_reference(m, k, n, bias):
     w = torch.randn(n, k, dtype=torch.bfloat16) * 0.05                                   # F.linear layout = [N, K]
     b = torch.randn(n, dtype=torch.bfloat16) if bias else None
     got = to_cpu(dense_gemm(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), False))
-    want = (x.float() @ w.float().t()).to(torch.bfloat16)
-    if bias:
-        want = (want.float() + b.float()).to(torch.bfloat16)
-    assert max_ulp_bf16ish(got, want, atol=2e-2) <= (2 if bias else 1)      # bias: two roundings, each may differ by one step
+    # [N, K] weights = the golden's F.linear(input, weight, bias): the bias joins the fp32 accumulator, ONE rounding
+    # (core/operators/compute_with_comm.py:12-24, gemm.py:45-46; torch's CPU addmm rounds once — round-5 probe)
+    want = torch.nn.functional.linear(x, w, b)
+    assert max_ulp_bf16ish(got, want, atol=2e-2) <= 1
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -87,16 +87,14 @@ def test_dense_gemm_split_over_k_for_few_output_tiles_is_exact(m, k, n, bias, dt
     """More than 128 rows but few 256x256 output tiles: K is cut into slices that go to fp32 slabs and a second launch sums
     them in slice order (gemm_api.hip, gemm_dense_splitk256).  Small-integer data makes every product and partial sum exact,
     so the split, the unsplit (MOJO_HIP_GEMM_SPLITK=1) and the fp32 reference must agree to the bit — ragged edges in M
-    and N, bias added after the rounding."""
+    and N, the bias joining the accumulator before the one rounding (F.linear semantics of the [N, K] layout)."""
     import torch.nn.functional as F
     from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
     torch.manual_seed(m + n)
     x = torch.randint(-4, 5, (m, k)).to(dtype).to(DEV)
     w = torch.randint(-4, 5, (n, k)).to(dtype).to(DEV)
     b = torch.randint(-8, 9, (n,)).to(dtype).to(DEV) if bias else None
-    want = F.linear(x.float(), w.float()).to(dtype)
-    if b is not None:
-        want = (want.float() + b.float()).to(dtype)
+    want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)     # F.linear: ONE rounding, bias included
     got = dense_gemm(x, w, b, False)
     assert torch.equal(got, want)
     monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
@@ -246,9 +244,7 @@ def test_gemm_residual_rmsnorm_fused_equals_the_separate_calls_and_the_oracle(dt
         assert summed is None
     assert torch.equal(normed, want_n)
     # the oracle's chain (fp32 product rounded once, then the golden norm)
-    a_ref = (x.float() @ w.float().t()).to(dtype)
-    if bias:
-        a_ref = (a_ref.float() + b.float()).to(dtype)
+    a_ref = torch.nn.functional.linear(x.float(), w.float(), b.float() if bias else None).to(dtype)
     if resid:
         ref = torch_cls("MojoResidualAddRMSNorm")(n, eps, "pre", dtype=dtype)
         ref.weight.data.copy_(nw)
@@ -301,9 +297,7 @@ def test_qkv_rope_store_fused_equals_the_separate_calls_and_the_oracle(dtype, b,
     assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
     assert not torch.equal(kc, dev(kc0))                      # (something was stored)
     # the oracle's chain
-    qkv_ref = (x.float() @ w.float().t()).to(dtype)
-    if bias:
-        qkv_ref = (qkv_ref.float() + bs.float()).to(dtype)
+    qkv_ref = torch.nn.functional.linear(x.float(), w.float(), bs.float() if bias else None).to(dtype)
     q_ref, k_ref = torch_cls("MojoApplyRoPE")()(qkv_ref[:, : hq * d].reshape(1, b, hq, d), qkv_ref[:, hq * d: (hq + hkv) * d].reshape(1, b, hkv, d),
                                                 cos, sin, head_first=False)
     torch.testing.assert_close(to_cpu(q_got).float(), q_ref.squeeze(0).float(), atol=3e-2, rtol=2e-2)

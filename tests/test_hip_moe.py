@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from hip_utils import DEV, hip_cls, last_launch, run_hip_case, to_cpu, torch_cls
+from hip_utils import DEV, hip_cls, last_launch, launches_of, run_hip_case, to_cpu, torch_cls
 from mojo_opset_amd.core import check_tol_diff
 
 pytestmark = pytest.mark.gpu
@@ -248,10 +248,12 @@ def test_experts_streaming_form_for_ragged_decode_groups_is_bit_identical(expert
     x = torch.rand(sum(counts), hidden, dtype=dtype, device=DEV)          # (the data of the reference's own experts test)
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
     streamed = op(x, cnt)
-    assert last_launch() == "gemm_skinny:ragged", last_launch()
+    hist = launches_of(lambda: op(x, cnt))
+    assert "gemm_skinny:ragged" in hist, hist                    # (a projection whose K is no multiple of 128 keeps the tile kernel)
     monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", str(31 & ~2))     # every decode-sized form but the ragged one
     tiled = op(x, cnt)
-    assert last_launch().startswith("gemm256:") or last_launch().startswith("gemm_generic"), last_launch()   # the OTHER kernel really ran
+    hist = launches_of(lambda: op(x, cnt))
+    assert "gemm_skinny:ragged" not in hist and ("gemm256:" in hist or "gemm_generic" in hist), hist   # the OTHER kernels really ran
     assert torch.equal(streamed, tiled)
     monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY")
     op.forward_diff_with(ref, x, cnt, mixed_tol=True, ref_device="cpu")
