@@ -56,14 +56,41 @@ def _report(rank, **kw):
         pass
 
 
-def _compare(rank, name, got, want, tol):
+def _ulp_at(mag, dtype):
+    mant = {torch.bfloat16: 7, torch.float16: 10}[dtype]
+    return torch.pow(2.0, torch.floor(torch.log2(mag.double().clamp_min(2.0 ** -14))) - mant)
+
+
+def _partials_magnitude(ws, m, k, n, dtype, rank=None):
+    """sum over ranks of |round(x_r @ w_r)| for the per-rank recipe of the reference's tests (seed 42 + r, x [m, k / ws], w
+    [k / ws, n]): the magnitude at which the ws storage-type partials of an element are added.  (rank: the reduce-scatter chunk.)"""
+    kl = k // ws
+    mag = None
+    for r in range(ws):
+        torch.manual_seed(42 + r)
+        x = torch.randn(m, kl, dtype=dtype).to(DEV)
+        w = torch.randn(kl, n, dtype=dtype).to(DEV)
+        y = (x.float() @ w.float()).to(dtype).float().abs()
+        mag = y if mag is None else mag + y
+    if rank is not None:
+        mag = mag.chunk(ws, dim=0)[rank]
+    return mag.cpu()
+
+
+def _compare(rank, name, got, want, tol, mag=None):
     """The reference's bound is atol = rtol = tol (5e-3 for 16-bit data, 1e-4 for fp32).  Both sides round every rank's
     product to the storage type and then add storage-type values, so they can differ only where the fp32 accumulation
     order of the two GEMMs flips the rounding of a PARTIAL: at most one unit in the last place of each rank's partial.  For
     bf16 one ulp is 0.39-0.78 % — above 5e-3 — and where the ranks' partials cancel, one ulp of a large partial exceeds
     5e-3 of the small sum in fp16 too (measured: 4e-5 of the elements at 4096^3).  The 16-bit bound is therefore stated as
     '>= 99.9 % of the elements inside the reference's bound (bf16: 99.5 %), none farther than one ulp per rank at the
-    largest output magnitude'; fp32 meets the reference's bound outright."""
+    largest output magnitude'; fp32 meets the reference's bound outright.  With MORE than two ranks the golden's own
+    result depends on the association the collective library happens to use for the ws storage-type partials (gloo's ring
+    here, RCCL's on a node; the direct exchange adds them in fp32 and rounds once): every one of the ws - 1 additions may
+    move an element by an ulp of a partial sum, so the share of elements inside 5e-3 falls (measured at four ranks: 95.5 %
+    of the reference's own bf16 reduce-scatter vectors, 79 % at 1024^3 bf16).  Where the caller supplies `mag` = sum_r |y_r|
+    (the magnitude the partials are added at), the bound is stated per element in those units: |got - want| <= ws ulps at
+    `mag` (ws - 1 additions + one for the GEMMs' own summation order), for EVERY element."""
     got, want = got.detach().cpu(), torch.as_tensor(want).detach().cpu()
     assert got.shape == want.shape and got.dtype == want.dtype, (name, got.shape, want.shape, got.dtype, want.dtype)
     diff = (got.double() - want.double()).abs()
@@ -79,7 +106,12 @@ def _compare(rank, name, got, want, tol):
         ws = dist.get_world_size()
         rec["max_ulp"] = _ulps(got, want)
         rec["bound_abs"] = 2 * ws * ulp_top
-        ok = frac >= (0.995 if got.dtype == torch.bfloat16 else 0.999) and rec["max_abs"] <= rec["bound_abs"]
+        if ws > 2 and mag is not None:
+            excess = diff - ws * _ulp_at(mag, got.dtype)
+            rec["max_excess_over_ws_ulps_at_partials"] = float(excess.max())
+            ok = float(excess.max()) <= 0 and rec["max_abs"] <= rec["bound_abs"]
+        else:
+            ok = frac >= (0.995 if got.dtype == torch.bfloat16 else 0.999) and rec["max_abs"] <= rec["bound_abs"]
     _report(rank, **rec)
     assert ok, rec
 
@@ -96,7 +128,12 @@ def check_vectors(rank, ws, group):
         op = hip_cls(case["op"])(w, None, True, process_group=group, **case["ctor_kwargs"])
         got = op(x)
         torch.cuda.synchronize()
-        _compare(rank, f"vector:{case['op']}:{case['name']}", got, want, 5e-3 if x.dtype != torch.float32 else 1e-4)
+        mag = None
+        if ws > 2 and x.dtype != torch.float32 and case["op"] in ("MojoGemmAllReduce", "MojoGemmReduceScatter"):
+            mag = torch.stack([(c["x"].float() @ c["w"].float()).to(x.dtype).float().abs() for c in case["ranks"]]).sum(0)
+            if case["op"] == "MojoGemmReduceScatter":
+                mag = mag.chunk(ws, dim=0)[rank]
+        _compare(rank, f"vector:{case['op']}:{case['name']}", got, want, 5e-3 if x.dtype != torch.float32 else 1e-4, mag=mag)
 
 
 _CACHE = {}
@@ -160,7 +197,8 @@ def check_reference_shapes(rank, ws, group):
                     side = "oracle"
                 got = hip_cls(name)(weight=w.to(DEV), bias=None, trans_weight=True, process_group=group, **kw)(x.to(DEV))
                 torch.cuda.synchronize()
-                _compare(rank, f"{side}:{name}:{tag}", got, want, 5e-3)
+                mag = _cached(("mag", name, tag), lambda: _partials_magnitude(ws, m, k, n, dtype, rank if name == "MojoGemmReduceScatter" else None)) if ws > 2 else None
+                _compare(rank, f"{side}:{name}:{tag}", got, want, 5e-3, mag=mag)
     # AllGatherGemm: :97-103, one seed for all ranks, [N, K] weights, bias in the fp16 cases
     for scale in _scales():
         for m0, k0, n0, dtype, use_bias in ((4096, 4096, 4096, torch.float16, True), (2048, 4096, 8192, torch.float16, True),
@@ -224,7 +262,8 @@ def check_fewer_rows_than_ranks(rank, ws, group):
                 torch.cuda.synchronize()
                 assert time.time() - t0 < 10, "an empty share stalled the exchange"
                 _compare(rank, f"fp32ref:MojoGemmAllReduce:tiny{'_direct' if direct == '1' else ''}:{m}x{k}x{n}:{str(dtype)[6:]}",
-                         got, want, 5e-3 if dtype != torch.float32 else 2e-4)
+                         got, want, 5e-3 if dtype != torch.float32 else 2e-4,
+                         mag=_partials_magnitude(ws, m, k, n, dtype) if ws > 2 and dtype != torch.float32 else None)
         if direct == "1":
             assert peer._CACHE, "MOJO_HIP_COMM_DIRECT=1 but no peer exchange was built"
             for ex in peer._CACHE.values():
@@ -256,7 +295,7 @@ def check_config4_shapes(rank, ws, group):
                     side = "oracle"
                 got = hip_cls("MojoGemmAllReduce")(weight=w.to(DEV), bias=None, trans_weight=True, process_group=group)(x.to(DEV))
                 torch.cuda.synchronize()
-                _compare(rank, f"{side}:MojoGemmAllReduce:{tag}", got, want, 5e-3)
+                _compare(rank, f"{side}:MojoGemmAllReduce:{tag}", got, want, 5e-3, mag=_partials_magnitude(ws, m, k, n, dtype) if ws > 2 else None)
                 del got, want
             for n_total in (10240, 57344):
                 m, k, n = m0 // scale, 8192 // scale, n_total // scale // ws
@@ -371,8 +410,15 @@ def check_auto_selection(rank, ws, group):
             assert torch.equal(auto, outs["1" if choice[0]["algorithm"] == "direct" else "0"]), f"{name}: the selected path's result differs"
             if ws == 2:
                 assert torch.equal(outs["0"], outs["1"]), f"{name}: pipeline and direct exchange disagree at two ranks"
-            else:                                   # different associations of ws storage-type partials: ulps apart, not more
-                assert _ulps(outs["1"].cpu(), outs["0"].cpu()) <= 2 * ws
+            else:                                   # different associations of ws storage-type partials: ulps of the partials apart, not more
+                mags = [None] * ws
+                y = (x.float() @ w.float()).to(x.dtype).float().abs().cpu()
+                dist.all_gather_object(mags, y, group=group)
+                mag = torch.stack(mags).sum(0)
+                if key == "gemm_reduce_scatter":
+                    mag = mag.chunk(ws, dim=0)[rank]
+                excess = (outs["1"].double().cpu() - outs["0"].double().cpu()).abs() - ws * _ulp_at(mag, x.dtype)
+                assert float(excess.max()) <= 0, f"{name}: direct and pipeline differ by more than ws ulps at the partials' magnitude"
             _report(rank, check=f"auto:{name}:M{m}")
         xs = x[: m // ws].contiguous()
         op = hip_cls("MojoAllGatherGemm")(weight=w, bias=None, trans_weight=True, gather_dim=0, process_group=group)
@@ -404,6 +450,10 @@ def check_captured_direct(rank, ws, group):
     from mojo_opset_amd.comm import peer
 
     _setenv(MOJO_HIP_COMM_DIRECT="1", MOJO_HIP_COMM_CHUNKS="2", MOJO_HIP_PEER_MIN_BYTES=str(1 << 20))
+    torch.cuda.synchronize()
+    dist.barrier(group=group)
+    peer.release_all()                                        # (an earlier mode's 64 MiB exchange would never have to grow)
+    dist.barrier(group=group)
     dtype = torch.bfloat16
     m, k, n = 64, 512, 1024                                   # decode-sized rows: the case graphs exist for
     torch.manual_seed(7 + rank)
