@@ -416,13 +416,17 @@ def main():
                 "frac": head["tflops"] / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": (lambda o: None if not isinstance(o, dict) else int(
                     o.get("read_bytes_beyond_L2 (FETCH_SIZE KiB x 1024 x 2)", 0) + o.get("write_bytes", 0)))(
-                    _profiled("r3_group_gemm_order.json", "orders_measured_0")),
-                "traffic_source": "profiled: profiles/r3_group_gemm_order.json orders_measured_0 (rocprofv3 --pmc FETCH_SIZE x2 + "
-                                  "WRITE_SIZE, separate passes)",
+                    _profiled("r5_group_gemm_counters.json", "orders_measured_0")),
+                "traffic_source": "profiled: profiles/r5_group_gemm_counters.json orders_measured_0 (round-5 binary; rocprofv3 --pmc "
+                                  "FETCH_SIZE x2 + WRITE_SIZE, separate passes: scripts/profile_r5_gemm.sh)",
                 "algorithmic_bytes_per_launch": 2 * (16384 * 4096 + 8 * 4096 * 28672 + 16384 * 28672),
                 "flops_per_launch": 2.0 * 16384 * 4096 * 28672, "device_us_per_launch": head["us"],
-                "sustained_clock_mhz": (_profiled("r3_group_gemm_order.json", "orders_measured_0") or {}).get("sustained_clock_mhz"),
-                "mfma_busy_frac_profiled": (_profiled("r3_group_gemm_order.json", "orders_measured_0") or {}).get("mfma_busy_frac"),
+                "sustained_clock_mhz": (_profiled("r5_group_gemm_counters.json", "orders_measured_0") or {}).get("sustained_clock_mhz"),
+                "mfma_busy_frac_profiled": (_profiled("r5_group_gemm_counters.json", "orders_measured_0") or {}).get("mfma_busy_frac"),
+                "calibration_this_run": gg.get("mixtral_up_16384x4096x28672_G8_KN_calibration"),
+                "bare_mfma_loop_tflops_profiled": "profiles/r5_mfma_shape_power_probe.txt: a loop of NOTHING but 16x16x32 bf16 MFMAs on random "
+                                                  "register operands holds 2 060 TFLOP/s (0.82 of nominal) on this chip, 1 820 with its fragments "
+                                                  "re-read from LDS (0.73); the 32x32x16 form 1 830 / 1 630",
                 "workload": "MojoGroupGemm bf16, Mixtral up-projection: 16384 rows over 8 experts (balanced), K=4096, N=28672, "
                             "weights [G,K,N], random data (BASELINE configs[2])",
                 "kernel": "mojo::g256::gemm256_kernel<bf16>"}
@@ -468,6 +472,9 @@ def main():
     rec = _case("MojoQuantGemm", "fp8_e4m3_4096x7168x36864_NK")
     if rec:
         tr, src = _traffic("quant_gemm_fp8_4096x7168x36864")
+        q5 = _profiled("r5_quant_gemm_counters.json", "fp8")
+        if isinstance(q5, dict) and q5.get("hbm_bytes_per_launch"):
+            tr, src = int(q5["hbm_bytes_per_launch"]), "profiled: profiles/r5_quant_gemm_counters.json fp8 (round-5 binary; scripts/profile_r5_gemm.sh)"
         line["roofline_quant_gemm"] = {
             "bound": "mfma", "achieved": rec["tflops"], "peak": 5000.0, "unit": "TFLOP/s", "frac": rec["tflops"] / 5000.0,
             "traffic": tr, "traffic_source": src, "algorithmic_bytes_per_launch": 4096 * 7168 + 7168 * 36864 + 4096 * 36864 * 2,
@@ -475,13 +482,24 @@ def main():
             "us_min": rec.get("us_min"), "us_max": rec.get("us_max"),
             "workload": "MojoQuantGemm fp8 e4m3 (v_mfma_f32_16x16x128_f8f6f4), DeepSeek-V3 shape M=4096, K=7168, N=36864, weight [N,K] "
                         "(BASELINE configs[4]; fp8 parity is unpinned: the reference implements int8 only)",
-            "kernel": "mojo::g256::gemm256_kernel<PolF8, EpilogueDequant>"}
+            "kernel": "mojo::g256::gemm256_kernel<PolF8, EpilogueDequant>",
+            "sustained_clock_mhz": (q5 or {}).get("sustained_clock_mhz") if isinstance(q5, dict) else None,
+            "mfma_busy_frac_profiled": (q5 or {}).get("mfma_busy_frac") if isinstance(q5, dict) else None,
+            "lds_active_frac_of_cu_cycles_profiled": (q5 or {}).get("lds_active_frac_of_cu_cycles") if isinstance(q5, dict) else None,
+            "zero_operand_tflops_profiled": ((q5 or {}).get("wall_same_process") or {}).get("zeros_tflops", {}).get("median") if isinstance(q5, dict) else None}
     if isinstance(line.get("roofline_group_gemm"), dict):
         gg = line["roofline_group_gemm"]
         clk = gg.get("sustained_clock_mhz")
         gg.update({"target": 0.80, "ceiling_at_sustained_clock": None if not clk else clk / 2400.0,
                    "note": "target 0.80 of the nominal 2.5 PF is formally missed: at the clock the chip holds under this load "
                            "a 100 % busy matrix pipe would deliver `ceiling_at_sustained_clock` of the nominal peak"})
+    try:
+        from mojo_opset_amd import switches
+        line["switches_set"] = {k: v for k, v in switches.in_effect().items() if v is not None}     # which build / route produced the numbers
+        from mojo_opset_amd.backends.hip import lib as _lib
+        line["library"] = _lib.load().mojo_hip_version().decode()
+    except Exception as e:
+        line["switches_set"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not ns.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
         if not ns.no_extras:

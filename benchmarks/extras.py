@@ -159,6 +159,23 @@ def bench_group_gemm(device):
             continue
         out[name] = group_gemm_case(device, m, k, n, g, trans, split)
         torch.cuda.empty_cache()
+    # Calibration points for the headline shape ON THIS BOX, in this run (the "at the vendor library / clock-
+    # limited" claim belongs on a driver-run record): the same instruction stream on ZERO operands (least switching power: the
+    # clock the chip would hold if the data cost nothing) and hipBLASLt through torch.matmul, one product per expert.
+    if _want("mixtral_up_16384x4096x28672_G8_KN_calibration"):
+        try:
+            cal = {}
+            cal["zero_operand_tflops"] = group_gemm_case(device, 16384, 4096, 28672, 8, False, data="zeros")["tflops"]
+            torch.cuda.empty_cache()
+            cal["hipblaslt_same_box_tflops"] = group_gemm_case(device, 16384, 4096, 28672, 8, False, data="torch")["tflops"]
+            torch.cuda.empty_cache()
+            cal["hipblaslt_same_box_tflops_NK"] = group_gemm_case(device, 16384, 4096, 28672, 8, True, data="torch")["tflops"]
+            cal["note"] = ("zero operands: this kernel, same launch, all-zero data; hipBLASLt: torch.matmul per expert on random data — "
+                           "calibration, not product paths")
+            out["mixtral_up_16384x4096x28672_G8_KN_calibration"] = cal
+        except Exception as e:
+            out["mixtral_up_16384x4096x28672_G8_KN_calibration"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     return out
 
 
@@ -808,6 +825,70 @@ def bench_dense_decode(device):
     return out
 
 
+def _host_cost(fn, device_s, calls=1000, batch=200):
+    """Host-side cost of an eager call: `eager_host_us` = time the Python shim + ctypes call + HIP launch take to ENQUEUE one
+    call (batches of `batch` calls timed on the host clock with a sync BETWEEN batches, so the launch queue never fills and
+    the device never throttles the host), `eager_wall_us` = wall per call of the same loop including the device work,
+    `device_us` = the graph-replay figure.  An op whose `eager_host_us` exceeds its `device_us` needs graph capture to reach
+    its device number."""
+    import time
+
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    host, wall, done = 0.0, 0.0, 0
+    while done < calls:
+        t0 = time.perf_counter()
+        for _ in range(batch):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        host += t1 - t0
+        wall += t2 - t0
+        done += batch
+    return {"eager_host_us": host / done * 1e6, "eager_wall_us": wall / done * 1e6, "device_us": device_s * 1e6,
+            "needs_graph_capture": host / done > device_s, "calls": done}
+
+
+def bench_host_overhead(device):
+    """what the drop-in costs on the HOST.  The shims are Python + ctypes; for the operators of a decode step
+    (Llama-3-8B, B 64, ctx 4096) the enqueue cost per eager call next to the device time under graph replay."""
+    hq, hkv, d, page, bsz, ctx, hidden, inter = 32, 8, 128, 16, 64, 4096, 4096, 14336
+    dt = torch.bfloat16
+    k_cache, v_cache, table = _paged(device, [ctx + page] * bsz, hkv, d, page)
+    x = torch.randn(bsz, hidden, device=device, dtype=dt)
+    resid = torch.randn(bsz, hidden, device=device, dtype=dt)
+    cos, sin = torch.randn(bsz, d, device=device), torch.randn(bsz, d, device=device)
+    ctx_t = torch.full((bsz,), ctx, dtype=torch.int32, device=device)
+    total_t = ctx_t + 1
+    q = torch.randn(bsz, hq, d, device=device, dtype=dt)
+    k = torch.randn(bsz, hkv, d, device=device, dtype=dt)
+    v = torch.randn(bsz, hkv, d, device=device, dtype=dt)
+    gate, up = torch.randn(bsz, inter, device=device, dtype=dt), torch.randn(bsz, inter, device=device, dtype=dt)
+    norm = hip("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=device)
+    rope, store, attn, act = hip("MojoApplyRoPE")(), hip("MojoStorePagedKVCache")(), hip("MojoPagedDecodeGQA")(is_causal=True, gqa_layout="AABB"), hip("MojoSwiGLU")()
+    gemm = hip("MojoGemm")(weight=torch.randn(hidden, hq * d, device=device, dtype=dt) * 0.02)
+    mlp = hip("MojoSwiGLUMLP")(hidden, hidden, inter).to(dt).to(device)
+    o = torch.randn(bsz, hq * d, device=device, dtype=dt)
+    ops = {
+        "MojoResidualAddRMSNorm_64x4096": lambda: norm(x, resid),
+        "MojoApplyRoPE_64x(32+8)x128": lambda: rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False),
+        "MojoStorePagedKVCache_decode_64": lambda: store(k, v, k_cache, v_cache, table, None, ctx_t),
+        "MojoPagedDecodeGQA_B64_ctx4096": lambda: attn(q, k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1),
+        "MojoSwiGLU_64x14336": lambda: act(gate, up),
+        "MojoGemm_64x4096x4096": lambda: gemm(o),
+        "MojoSwiGLUMLP_64x4096x14336": lambda: mlp(x),
+    }
+    out = {}
+    for name, fn in ops.items():
+        if not _want(name):
+            continue
+        dev_s = _time_graph(fn, reps=4 if "Decode" in name or "MLP" in name else 20)
+        out[name] = _host_cost(fn, dev_s)
+    return out
+
+
 def run_extras(device, world, rank=0):
     out = {}
     for name, fn in (("MojoPagedDecodeGQA_bf16_other_contexts", bench_decode_variants),
@@ -815,7 +896,8 @@ def run_extras(device, world, rank=0):
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
                      ("MojoPagedPrefillMLA_bf16", bench_mla_prefill),
                      ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),
-                     ("dense_gemm_decode_bf16", bench_dense_decode), ("decode_layer_bf16", bench_decode_layer)):
+                     ("dense_gemm_decode_bf16", bench_dense_decode), ("decode_layer_bf16", bench_decode_layer),
+                     ("host_overhead_decode_step", bench_host_overhead)):
         try:
             out[name] = fn(device)
         except Exception as e:  # one failing extra must not hide the others
