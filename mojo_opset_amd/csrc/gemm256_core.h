@@ -796,7 +796,16 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
     // 1001-1008, reference case 1050-1068 -> 1070-1094, K = 512 (MLA decompression) 741-755 -> 748-804: inside the run-to-run
     // spread except at short K.  The hardware's own workgroup hand-over already hides most of what the loop was meant to
     // hide, and hipcc builds the loop body with 19-20 SGPR spills; results are identical (all GEMM tests pass with it on).
-    const bool off = MOJO_SWITCH("MOJO_HIP_GEMM_PERSIST", 0) != 1;
+    // ROUND 5: ON for short-K one-group products (at most 16 K-tiles: the MLA decompression GEMM, K = 512 / 1024), where a
+    // tile spends a third of its time outside the K loop.  Measured on the final binary (scripts/probes/gemm_shortk_bound.py,
+    // profiles/r5_gemm_shortk_bound.txt; bf16 [N,K], one group): 2048 x 512 x 32768 80.9 -> 73.9 us (849 -> 930 TF), 10240 x 512 x 32768
+    // 388.2 (with the start stagger; 411.4 without) -> 371.7 us, 2048 x 1024 x 32768 121.3 -> 114.6 us; K = 4096 373.1 -> 369.3 us
+    // (inside the spread: left on the classic launch).  The same probe bounds what ANY scheme that hides the epilogue can
+    // reach: with the C stores removed (timing only) the three short-K products take 58.1 / 261.5 / 103.1 us.
+    bool off = !(a.G == 1 && a.K / (KT_BYTES / P::EB) <= 16);
+#ifdef MOJO_HIP_BUILD_EXPERIMENTS
+    if (const long long force = MOJO_SWITCH("MOJO_HIP_GEMM_PERSIST", -1); force >= 0) off = force != 1;
+#endif
     const int cus = device_cu_count();
     if (!off && a.stage_rows && !a.glu && a.splitk == 1 && !epi.has_bias() && !a.ablate && blocks >= 2 * cus) {
       constexpr int LDS_P = LDS_BYTES + PERSIST_STAGE_BYTES;

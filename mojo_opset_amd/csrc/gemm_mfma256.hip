@@ -61,10 +61,10 @@ int launch_gemm_mfma256(const GemmArgs& a_in, int dtype, int64_t m_total, hipStr
 #endif
   if (dtype == MOJO_BF16) {
     g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias), a.bias_fused != 0};
-    return g256::gemm256_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, kExperimentsBuild>(a, epi, m_total, s);
+    return g256::gemm256_launch<g256::PolBF16, g256::EpiloguePlain<bf16_t>, true>(a, epi, m_total, s);
   }
   g256::EpiloguePlain<f16_t> epi{static_cast<f16_t*>(a.C), a.ldc, static_cast<const f16_t*>(a.bias), a.bias_fused != 0};
-  return g256::gemm256_launch<g256::PolF16, g256::EpiloguePlain<f16_t>, kExperimentsBuild>(a, epi, m_total, s);
+  return g256::gemm256_launch<g256::PolF16, g256::EpiloguePlain<f16_t>, true>(a, epi, m_total, s);
 }
 
 // 16-bit operands, fp32 output (optionally accumulated onto C): used by the MoE router for its hi/lo split product
