@@ -23,10 +23,13 @@ from ..backends.hip import lib as L
 
 _LOCK = threading.RLock()
 _CACHE: Dict[Tuple[object, int], "PeerExchange"] = {}
-# Captured twins that a graph may hold (they were handed out under capture) and whose eager exchange has since been
-# replaced by a larger one: kept alive — and checked — until release_all().  A captured launch has the twin's raw peer
-# pointers baked in; freeing it would make the next replay read and write freed or re-mapped IPC memory on every rank.
-_RETIRED_TWINS: List["PeerExchange"] = []
+# Exchanges that were replaced by a larger one: kept mapped — and checked — until release_all(), never freed in between.
+# Two reasons, both found the hard way: (1) a captured launch has its twin's raw peer pointers baked in — freeing
+# the twin would make the next replay read and write freed or re-mapped IPC memory on every rank; (2) a buffer freed and
+# re-allocated at the SAME virtual address exports the same IPC handle bytes, and a peer's `hipIpcOpenMemHandle` of that
+# handle then showed the OLD memory (caught by `_verify_mapping` in the 4-rank test of round 5: "opened mappings do not
+# show the peers' memory").  Capacity at least doubles on every rebuild, so the retired buffers add up to less than the live one.
+_RETIRED: List["PeerExchange"] = []
 
 
 class _DeviceBytes:
@@ -197,10 +200,7 @@ class PeerExchange:
 
     def close(self) -> None:
         if self.twin is not None:
-            if self.twin.handed_out_under_capture:
-                _RETIRED_TWINS.append(self.twin)            # a graph may replay over it: keep it mapped (see _RETIRED_TWINS)
-            else:
-                self.twin.close()
+            self.twin.close()
             self.twin = None
         lib = L.load()
         for p in self._opened:
@@ -221,11 +221,11 @@ def captured_ready(group, need_bytes: int) -> bool:
 
 def check_all(group=None, clear: bool = True) -> None:
     """Raise if any exchange of ``group`` (every group when None) recorded a timed-out wait: the eager exchanges, their
-    captured twins and the retired twins old graphs may still replay over.  Call it after a graph replay (or any step) whose
+    captured twins and the retired exchanges old graphs may still replay over.  Call it after a graph replay (or any step) whose
     outputs matter: a timed-out wait poisons its outputs with NaN and makes every later wait of that exchange give up at
     once, so one unnoticed timeout would otherwise turn every later replay into silent NaN.  Synchronises."""
     with _LOCK:
-        exs = [ex for ex in list(_CACHE.values()) + list(_RETIRED_TWINS) if group is None or ex.group is group]
+        exs = [ex for ex in list(_CACHE.values()) + list(_RETIRED) if group is None or ex.group is group]
     first = None
     for ex in exs:
         try:
@@ -254,11 +254,13 @@ def get_exchange(group, need_bytes: int) -> PeerExchange:
         if capturing:
             raise NotImplementedError("direct peer exchange under graph capture: no captured buffer of this size yet — run the "
                                       "operator once eagerly at this size (or larger) before capturing")
+        largest = 0
         for (k, cap) in [kc for kc in _CACHE if kc[0] == key]:
             torch.cuda.synchronize()
-            dist.barrier(group=group)           # nobody may still be reading the buffer that is about to go away
-            _CACHE.pop((k, cap)).close()
-        cap = max(int(need_bytes), switches.get_int("MOJO_HIP_PEER_MIN_BYTES", 64 << 20))
+            dist.barrier(group=group)           # (every rank retires the same exchanges in the same order)
+            _RETIRED.append(_CACHE.pop((k, cap)))   # retired, NOT freed: see _RETIRED
+            largest = max(largest, cap)
+        cap = max(int(need_bytes), switches.get_int("MOJO_HIP_PEER_MIN_BYTES", 64 << 20), 2 * largest)
         ex = PeerExchange(group, cap)
         ex.twin = PeerExchange(group, cap, captured=True)           # the graph-capturable twin, built while building is allowed
         _CACHE[(key, ex.capacity)] = ex
@@ -266,16 +268,12 @@ def get_exchange(group, need_bytes: int) -> PeerExchange:
 
 
 def release_all() -> None:
-    """Free every exchange, INCLUDING twins that captured graphs may hold: destroy those graphs first."""
+    """Free every exchange, INCLUDING retired ones and twins that captured graphs may hold: destroy those graphs first."""
     with _LOCK:
-        for ex in _CACHE.values():
-            if ex.twin is not None:
-                ex.twin.handed_out_under_capture = False
+        for ex in list(_CACHE.values()) + list(_RETIRED):
             ex.close()
         _CACHE.clear()
-        for tw in _RETIRED_TWINS:
-            tw.close()
-        _RETIRED_TWINS.clear()
+        _RETIRED.clear()
 
 
 # ---------------------------------------------------------------------------------------------------------------

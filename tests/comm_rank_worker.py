@@ -504,7 +504,8 @@ def check_captured_direct(rank, ws, group):
     yb = big(xb)
     torch.cuda.synchronize()
     assert torch.isfinite(yb.float()).all()
-    assert len(peer._RETIRED_TWINS) == 1 and peer._RETIRED_TWINS[0].handed_out_under_capture, "the captured twin must be retired, not freed"
+    assert len(peer._RETIRED) == 1 and peer._RETIRED[0].twin is not None and peer._RETIRED[0].twin.handed_out_under_capture, \
+        "the exchange the graph was captured over must be retired, not freed"
     for i in range(6, 9):
         load(i)
         graph.replay()

@@ -5,8 +5,10 @@ the `Mojo*` operator API.
 
 Bounds: the reference's own test of `MojoGemm` (tests/accuracy/operators/test_gemm.py:34-54) uses `forward_diff_with(...,
 mixed_tol=True)` (atol 2^-6 below 1, rtol 2^-6 above) and `assert_close` defaults on (1024, 4096, 4096) fp16 / bf16 with and
-without bias; `MojoSwiGLUMLP` has no accuracy test in the reference — it is held to one unit in the last place of the oracle
-here (every rounding point of the golden's chain is reproduced), and to the separate-operator chain bit for bit.
+without bias; `MojoSwiGLUMLP` has no accuracy test in the reference — it is held here to the reference's GEMM-family bound
+against the oracle plus a mean error below 1 % of the mean magnitude (every rounding point of the golden's chain is
+reproduced), to two units in the last place on the reference-captured vectors, and to the separate-operator chain bit for bit
+wherever both sum K in the same order.
 """
 import pytest
 import torch

@@ -61,7 +61,12 @@ class VirtualRanks:
         return self.alias[r][off: off + nb].view(dtype).view(rows, n)
 
     def begin(self):
-        """(epoch argument, byte offset of the call's data half) — as PeerExchange.begin_call on every rank."""
+        """(epoch argument, byte offset of the call's data half) — as PeerExchange.begin_call on every rank.  The ranks'
+        streams first wait for the caller's stream: the operands and the NaN-filled outputs were produced there (torch's
+        side streams are non-blocking: nothing orders them behind the default stream by itself)."""
+        here = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(here)
         if self.captured:
             for r in range(self.ws):
                 L.check(self.lib.mojo_hip_peer_begin(self.data, self.flags, self.ws, r, self.sp(r)), "begin")
@@ -101,8 +106,8 @@ def all_reduce(v, parts, n_chunks):
     m, n = parts[0].shape
     dtype, es = parts[0].dtype, parts[0].element_size()
     code = L.dtype_code(dtype)
-    epoch, base = v.begin()
     outs = [torch.full((m, n), float("nan"), dtype=dtype, device=DEV) for _ in range(ws)]
+    epoch, base = v.begin()                                    # (behind everything the caller's stream produced: operands and outputs)
     for c, (lo, hi) in enumerate(_chunks(m, n_chunks)):
         rows, off = hi - lo, base + lo * n * es
         for r in range(ws):                                    # "GEMM" into the peer buffer, then signal — every rank first
@@ -128,8 +133,8 @@ def reduce_scatter(v, parts, n_chunks):
     ml = m // ws
     dtype, es = parts[0].dtype, parts[0].element_size()
     code = L.dtype_code(dtype)
-    epoch, base = v.begin()
     outs = [torch.full((ml, n), float("nan"), dtype=dtype, device=DEV) for _ in range(ws)]
+    epoch, base = v.begin()                                    # (behind everything the caller's stream produced: operands and outputs)
     for c, (lo, hi) in enumerate(_chunks(ml, n_chunks)):
         rc, off = hi - lo, base + ws * lo * n * es
         for r in range(ws):
@@ -149,8 +154,8 @@ def all_gather(v, shards):
     ws = v.ws
     ml, k = shards[0].shape
     dtype, es = shards[0].dtype, shards[0].element_size()
-    epoch, base = v.begin()
     outs = [torch.full((ws * ml, k), float("nan"), dtype=dtype, device=DEV) for _ in range(ws)]
+    epoch, base = v.begin()                                    # (behind everything the caller's stream produced: operands and outputs)
     for r in range(ws):
         with torch.cuda.stream(v.streams[r]):
             v.view(r, base, ml, k, dtype).copy_(shards[r])
@@ -206,12 +211,13 @@ def test_a_missing_peer_times_out_and_poisons_only_the_waiters():
     v = VirtualRanks(ws, 1 << 20)
     try:
         v.lib.mojo_hip_peer_set_timeout_ms(300)
-        epoch, base = v.begin()
         es, code = 2, L.dtype_code(torch.bfloat16)
         outs = [torch.zeros(m, n, dtype=torch.bfloat16, device=DEV) for _ in range(ws)]
+        pats = [_pattern(r, m, n, torch.bfloat16) for r in range(ws)]
+        epoch, base = v.begin()
         for r in range(ws - 1):                                  # rank 7 stays silent
             with torch.cuda.stream(v.streams[r]):
-                v.view(r, base, m, n, torch.bfloat16).copy_(_pattern(r, m, n, torch.bfloat16))
+                v.view(r, base, m, n, torch.bfloat16).copy_(pats[r])
             L.check(v.lib.mojo_hip_peer_signal(v.data, v.flags, ws, r, 0, 0, epoch, v.sp(r)), "signal")
         for r in range(ws - 1):
             r0, r1 = m * r // ws, m * (r + 1) // ws
