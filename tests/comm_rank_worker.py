@@ -450,10 +450,6 @@ def check_captured_direct(rank, ws, group):
     from mojo_opset_amd.comm import peer
 
     _setenv(MOJO_HIP_COMM_DIRECT="1", MOJO_HIP_COMM_CHUNKS="2", MOJO_HIP_PEER_MIN_BYTES=str(1 << 20))
-    torch.cuda.synchronize()
-    dist.barrier(group=group)
-    peer.release_all()                                        # (an earlier mode's 64 MiB exchange would never have to grow)
-    dist.barrier(group=group)
     dtype = torch.bfloat16
     m, k, n = 64, 512, 1024                                   # decode-sized rows: the case graphs exist for
     torch.manual_seed(7 + rank)
@@ -499,13 +495,19 @@ def check_captured_direct(rank, ws, group):
     peer.check_all(group)                                     # eager exchanges AND their captured twins
     # a later eager call with a larger payload rebuilds the exchange.  The twin the graph was captured over must
     # stay mapped (the graph holds its raw peer pointers): it is retired, not freed, and the graph keeps replaying correctly.
+    # (nothing is freed to get there — an uncached buffer freed and re-allocated at the same address showed its OLD contents to
+    # peers on this platform: the payload is simply made larger than whatever exchange an earlier mode left behind)
+    cap_now = max(ex.capacity for ex in peer._CACHE.values())
+    retired_before = len(peer._RETIRED)
     big = hip_cls("MojoGemmAllReduce")(weight=(torch.randn(k, 4096) * 0.05).to(dtype).to(DEV), bias=None, trans_weight=True, process_group=group)
-    xb = torch.randn(2048, k).to(dtype).to(DEV)               # 16 MiB payload > the 1 MiB the first exchange was built with
+    xb = torch.randn(cap_now // (4096 * 2) + 256, k).to(dtype).to(DEV)          # payload just above the current capacity
     yb = big(xb)
     torch.cuda.synchronize()
     assert torch.isfinite(yb.float()).all()
-    assert len(peer._RETIRED) == 1 and peer._RETIRED[0].twin is not None and peer._RETIRED[0].twin.handed_out_under_capture, \
+    assert len(peer._RETIRED) == retired_before + 1 and peer._RETIRED[-1].twin is not None and peer._RETIRED[-1].twin.handed_out_under_capture, \
         "the exchange the graph was captured over must be retired, not freed"
+    assert max(ex.capacity for ex in peer._CACHE.values()) >= 2 * cap_now, "capacity at least doubles on a rebuild"
+    del yb, xb, big
     for i in range(6, 9):
         load(i)
         graph.replay()

@@ -23,26 +23,42 @@ from mojo_opset_amd.comm.peer import _DeviceBytes, _ptr_array
 pytestmark = pytest.mark.gpu
 
 
+_POOL = {}                      # bytes -> the 8 buffers of this process, allocated ONCE and never freed (see VirtualRanks)
+
+
 class VirtualRanks:
-    """`ws` symmetric peer buffers of ONE process + the per-call bookkeeping of `PeerExchange` (epoch, parity halves)."""
+    """`ws` symmetric peer buffers of ONE process + the per-call bookkeeping of `PeerExchange` (epoch, parity halves).
+
+    The buffers come from a per-process pool that is never freed: on this platform an uncached allocation that is freed and
+    re-allocated at the same virtual address can show its OLD contents to some compute units (this test failed intermittently
+    — stale operands, never a timeout — while it allocated and freed eight buffers per case, and never on plain `hipMalloc`
+    memory, which the runtime pools; a bare write-then-read probe on one uncached buffer, scripts/probes/uc_visibility_probe.hip,
+    is clean).  The product follows the same rule: `comm/peer.py` retires an exchange it outgrows instead of freeing it."""
 
     def __init__(self, ws, capacity, captured=False):
         self.lib = L.load()
         self.ws, self.cap, self.captured = ws, capacity, captured
         self.halves = 1 if captured else 2
         ctrl = int(self.lib.mojo_hip_peer_ctrl_bytes())
-        total = self.halves * capacity + 4096 + ctrl
-        self.bufs = []
-        for _ in range(ws):
-            p = ctypes.c_void_p()
-            rc = self.lib.mojo_hip_peer_alloc(ctypes.byref(p), total, 1)
-            if rc != 0:
-                L.check(self.lib.mojo_hip_peer_alloc(ctypes.byref(p), total, 0), "peer_alloc")
-            self.bufs.append(p)
+        total = 2 * capacity + 4096 + ctrl                      # (sized for two halves; the captured layout uses the front part)
+        if total not in _POOL:
+            bufs = []
+            for _ in range(int(self.lib.mojo_hip_peer_max_ranks()) // 2):      # 8 of the 16 ranks the kernels support
+                p = ctypes.c_void_p()
+                rc = self.lib.mojo_hip_peer_alloc(ctypes.byref(p), total, 1)
+                if rc != 0:
+                    L.check(self.lib.mojo_hip_peer_alloc(ctypes.byref(p), total, 0), "peer_alloc")
+                bufs.append(p)
+            _POOL[total] = bufs
+        self.bufs = _POOL[total][:ws]
+        whole = [torch.as_tensor(_DeviceBytes(b.value, total), device=torch.device(DEV, 0)) for b in self.bufs]
+        for w in whole:
+            w.zero_()                                           # data, flags, epoch word, counters, error word: a fresh exchange
+        torch.cuda.synchronize()
         self.flag_off = self.halves * capacity + 4096
         self.data = _ptr_array([b.value for b in self.bufs])
         self.flags = _ptr_array([b.value + self.flag_off for b in self.bufs])
-        self.alias = [torch.as_tensor(_DeviceBytes(b.value, self.halves * capacity), device=torch.device(DEV, 0)) for b in self.bufs]
+        self.alias = [w[: self.halves * capacity] for w in whole]
         self.streams = [torch.cuda.Stream() for _ in range(ws)]
         self.epoch = 0
         self.old_timeout = self.lib.mojo_hip_peer_set_timeout_ms(3000)
@@ -50,8 +66,6 @@ class VirtualRanks:
     def close(self):
         torch.cuda.synchronize()
         self.lib.mojo_hip_peer_set_timeout_ms(self.old_timeout)
-        for b in self.bufs:
-            self.lib.mojo_hip_peer_free(b)
 
     def sp(self, r):
         return ctypes.c_void_p(self.streams[r].cuda_stream)
