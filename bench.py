@@ -441,10 +441,10 @@ def main():
         return rec if isinstance(rec, dict) and "us" in rec else None
 
     def _traffic(tag):
-        t = (_profiled("r4_traffic.json", tag) or _profiled("r3_traffic.json", tag))
+        t = (_profiled("r5_traffic.json", tag) or _profiled("r4_traffic.json", tag) or _profiled("r3_traffic.json", tag))
         if not isinstance(t, dict):
             return None, None
-        return t.get("hbm_bytes_per_op"), f"profiled: profiles/r4_traffic.json (r3_traffic.json when absent):{tag} ({t.get('collected', '')}; kernels: {', '.join(t.get('kernels', []))})"
+        return t.get("hbm_bytes_per_op"), f"profiled: profiles/r5_traffic.json (r4 / r3 file when absent):{tag} ({t.get('collected', '')}; kernels: {', '.join(t.get('kernels', []))})"
 
     rec = _case("MojoPagedDecodeMLA_bf16", "B64_H128_ctx4096_page16")
     if rec:
