@@ -770,6 +770,30 @@ def bench_decode_layer(device):
         return _GEMM_NORM(m, w_dn, None, r2, norm1.weight, 1e-5)
 
     t_fused = _time_graph(layer_fused, reps=4, replays=5)
+
+    # The same layer written ONLY against the reference's operator API (round 5): `MojoGemm` for the projections and
+    # `MojoSwiGLUMLP` for the gated MLP — what a model file of the reference gets with MOJO_BACKEND=hip and no code change.  The
+    # MLP's gate|up projection + SwiGLU is one launch (mojo_hip_gemm_swiglu) behind that class; the other fusions need the chain
+    # helpers above.
+    g_qkv, g_o = hip("MojoGemm")(weight=w_qkv), hip("MojoGemm")(weight=w_o)
+    mlp = hip("MojoSwiGLUMLP")(hidden, hidden, inter).to(dt).to(device)
+    with torch.no_grad():
+        mlp.fc1.weight.copy_(w_gu)
+        mlp.fc2.weight.copy_(w_dn)
+
+    def layer_api():
+        h, r1 = norm1(x, resid)
+        qkv = g_qkv(h)
+        q = qkv[:, : hq * d].reshape(bsz, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].reshape(bsz, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].reshape(bsz, hkv, d).contiguous()
+        q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
+        store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, None, ctx_t)
+        o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, total_t, table, max_total_seq_len=ctx + 1)
+        h2, r2 = norm2(g_o(o.reshape(bsz, hq * d)), r1)
+        return mlp(h2), r2
+
+    t_api = _time_graph(layer_api, reps=4, replays=5)
     # the same operators one at a time (each under graph replay on its own): their sum against the whole layer shows what
     # chaining costs (cold weights: each GEMM's 0.1 - 0.2 GB of weights is evicted from the 256 MB MALL by the next one)
     h, r1 = norm1(x, resid)
@@ -807,7 +831,11 @@ def bench_decode_layer(device):
     res.update({"weights_MB": weights / 1e6, "kv_MB": kv / 1e6, "tokens_per_s_one_layer": bsz / t,
                 "per_op_us": {n: v * 1e6 for n, v in parts.items()}, "sum_of_ops_us": sum(parts.values()) * 1e6,
                 "note": "graph replay; bytes = the layer's weights + the K/V the attention reads (activations are noise at B = 64)"})
-    return {"llama3_8b_layer_B64_ctx4096": res, "llama3_8b_layer_B64_ctx4096_fused": fused}
+    api = _hbm(t_api, weights + kv)
+    api.update({"tokens_per_s_one_layer": bsz / t_api,
+                "note": "graph replay; the layer written only against the reference's operator API: MojoResidualAddRMSNorm, MojoGemm (QKV, o), "
+                        "MojoApplyRoPE, MojoStorePagedKVCache, MojoPagedDecodeGQA, MojoSwiGLUMLP (gate|up + SwiGLU in one launch, then down)"})
+    return {"llama3_8b_layer_B64_ctx4096": res, "llama3_8b_layer_B64_ctx4096_fused": fused, "llama3_8b_layer_B64_ctx4096_mojo_api": api}
 
 
 def bench_dense_decode(device):
