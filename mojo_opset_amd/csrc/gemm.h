@@ -117,6 +117,11 @@ int launch_gemm_skinny_ragged(const GemmArgs& a, int dtype, int64_t m_total, hip
 int launch_gemm_mfma256_f32out(const GemmArgs& a, int dtype, int accumulate, int64_t m_total, hipStream_t s);
 bool gemm_mfma256_ok(const GemmArgs& a, int dtype);
 
+// 128 x 128 tiles for one dense 16-bit product with [N,K] weights that under-fills the 256 x 256 kernel (gemm_tile128.hip)
+bool gemm_tile128_ok(const GemmArgs& a, int dtype);
+bool gemm_tile128_use(const GemmArgs& a, int dtype, int64_t m_total, bool model_prefers);   // MOJO_HIP_GEMM_TILE128: 1 / 0 override the model
+int launch_gemm_tile128(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
+
 // generic path (any dtype in {f32,f16,bf16}, any K/N, any strides)
 int launch_gemm_generic(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
 

@@ -109,7 +109,8 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
 // same 68 us (K = 4096) from 129 to 2048 rows, 2-4 x the vendor library's time.  K is cut so that ~256 workgroups run; the
 // slices go to fp32 slabs and launch_gemm_splitk_finalize sums them in slice order (deterministic).
 // MOJO_HIP_GEMM_SPLITK=<n> forces the split (1 = off).
-static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n) {
+static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelled_us = nullptr) {
+  if (modelled_us) *modelled_us = static_cast<double>(ceil_div(ceil_div(m, 256) * ceil_div(n, 256), 256)) * (k / 64) * 1.06;
   if (m <= 128 || n % 4 != 0 || k % 64 != 0) return 1;
   const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), nkt = k / 64;
   if (int64_t sk = MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0); sk > 0) {
@@ -129,7 +130,22 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n) {
     const double c = cost(sk);
     if (c < best_cost * 0.999) { best = sk; best_cost = c; }
   }
+  if (modelled_us) *modelled_us = cost(best);
   return static_cast<int>(best);
+}
+
+// 128 x 128 tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  Modelled times from measurements on this chip
+// (profiles/r5_gemm_tile128_ab.txt, 80 shapes): a 128 x 128 tile's K-tile takes 0.33 us on an otherwise idle chip and 0.45 us with
+// every CU busy (clock, L2), one workgroup per CU up to 256 tiles; two per CU up to 512 tiles, 0.70-0.90 us per K-tile of the
+// pair; ~5 us of launch, prologue and epilogue.  The 256 kernel's model runs ~15 % under its measured times on split launches,
+// hence the factor.  On the measured grid the rule is within 0.2 % (geometric mean) of always picking the faster form.
+static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n) {
+  const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 64;
+  if (tiles > 512) return false;
+  const double t128 = 5.0 + nkt * (tiles <= 256 ? 0.33 + 0.12 * tiles / 256.0 : 0.70 + 0.20 * (tiles - 256) / 256.0);
+  double t256 = 0;
+  (void)gemm_dense_splitk256(m, k, n, &t256);
+  return t128 < 1.15 * t256;
 }
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
@@ -174,6 +190,8 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
       if (!gemm_skinny_ok(a, dtype)) { a.splitk = 1; a.slab = nullptr; }
     }
   }
+  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && gemm_tile128_use(a, dtype, m, gemm_dense_prefers_tile128(m, k, n)))
+    return launch_gemm_tile128(a, dtype, m, s);
   if (a.splitk == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && !gemm_skinny_ok(a, dtype) && gemm_mfma256_ok(a, dtype)) {
     const int sk = gemm_dense_splitk256(m, k, n);       // few output tiles: cut K, sum the slices in a second launch
     if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {
