@@ -134,15 +134,18 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
   return static_cast<int>(best);
 }
 
-// 128 x 128 tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  Modelled times from measurements on this chip
-// (profiles/r5_gemm_tile128_ab.txt, 80 shapes): a 128 x 128 tile's K-tile takes 0.33 us on an otherwise idle chip and 0.45 us with
-// every CU busy (clock, L2), one workgroup per CU up to 256 tiles; two per CU up to 512 tiles, 0.70-0.90 us per K-tile of the
-// pair; ~5 us of launch, prologue and epilogue.  The 256 kernel's model runs ~15 % under its measured times on split launches,
-// hence the factor.  On the measured grid the rule is within 0.2 % (geometric mean) of always picking the faster form.
+// 128-row tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  Modelled times from measurements on this chip
+// (profiles/r5_gemm_tile128_ab.txt, 80 shapes): up to 256 tiles of 128 x 128, one workgroup per CU, a K-tile takes 0.33 us on an
+// otherwise idle chip and 0.45 us with every CU busy (clock, L2), plus ~5 us of launch, prologue and epilogue; beyond, up to
+// 256 tiles of 128 x 256 (eight waves), 0.34 us + 0.47 us x the share of busy CUs, plus ~6 us.  The 256 kernel's model runs
+// ~15 % under its measured times on split launches, hence the factor.  On the measured grid the rule is within 0.3 %
+// (geometric mean) of always picking the faster form, and 13.5 % ahead of the 256 kernel alone.
 static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n) {
-  const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 64;
-  if (tiles > 512) return false;
-  const double t128 = 5.0 + nkt * (tiles <= 256 ? 0.33 + 0.12 * tiles / 256.0 : 0.70 + 0.20 * (tiles - 256) / 256.0);
+  const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 64;
+  double t128;
+  if (narrow <= 256) t128 = 5.0 + nkt * (0.33 + 0.12 * narrow / 256.0);
+  else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + 0.47 * wide / 256.0);
+  else return false;
   double t256 = 0;
   (void)gemm_dense_splitk256(m, k, n, &t256);
   return t128 < 1.15 * t256;

@@ -18,7 +18,7 @@
 
 int main(int argc, char** argv) {
   const int K = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 4096;
-  const int ms[] = {128, 256, 512, 1024, 2048};
+  const int ms[] = {128, 256, 512, 1024, 2048, 4096};
   for (int m : ms) {
     std::vector<uint16_t> ha(static_cast<size_t>(m) * K), hw(static_cast<size_t>(N) * K);
     unsigned s = 12345u;
@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
       best = ms_ < best ? ms_ : best; sum += ms_;
     }
     const double us = best * 1e3 / iters;
-    printf("ablate %d piece %d sched %d K %d N %d M %5d tiles %4d : %7.1f us  (%.3f us per K-tile, %6.0f TFLOP/s)\n", T128_ABLATE, T128_PIECE, T128_SCHED, K, N, m,
+    printf("shape %s ablate %d piece %d sched %d K %d N %d M %5d tiles %4d : %7.1f us  (%.3f us per K-tile, %6.0f TFLOP/s)\n", getenv("MOJO_HIP_GEMM_TILE128") ? getenv("MOJO_HIP_GEMM_TILE128") : "auto", T128_ABLATE, T128_PIECE, T128_SCHED, K, N, m,
            ((m + 127) / 128) * ((N + 127) / 128), us, us / (K / 64), 2.0 * m * K * N / us / 1e6);
     hipFree(A); hipFree(W); hipFree(C);
   }

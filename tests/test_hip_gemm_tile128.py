@@ -24,37 +24,39 @@ pytestmark = pytest.mark.gpu
     (129, 64, 128, False),          # one K-tile, one row past a tile
     (256, 192, 384, True),          # odd K-tile count
     (300, 1024, 520, True),         # ragged in M and N (N % 128 = 8)
-    (1000, 4096, 4096, False),      # 8 x 32 tiles = one per CU: the four-stage ring
+    (1000, 4096, 4096, False),      # 8 x 32 tiles = one per CU
     (1024, 8192, 1024, True),       # 64 tiles
-    (2048, 512, 4100, False),       # 16 x 33 tiles > CUs: two workgroups per CU, two-stage ring; N % 128 = 4
+    (2048, 512, 4100, False),       # 16 x 33 tiles of 128 x 128 > CUs: 128 x 256 tiles, eight waves, three-stage ring; N % 256 = 4
     (513, 320, 260, True),
 ])
-def test_tile128_integer_data_is_exact(dtype, m, k, n, bias):
+@pytest.mark.parametrize("shape", ["1", "128", "256"])
+def test_tile128_integer_data_is_exact(dtype, m, k, n, bias, shape):
     torch.manual_seed(m + n)
     x = torch.randint(-4, 5, (m, k)).to(dtype).to(DEV)
     w = torch.randint(-4, 5, (n, k)).to(dtype).to(DEV)
     b = torch.randint(-8, 9, (n,)).to(dtype).to(DEV) if bias else None
     want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)      # ONE rounding, bias included
-    with switch_env(MOJO_HIP_GEMM_TILE128="1"):
+    with switch_env(MOJO_HIP_GEMM_TILE128=shape):                   # 1: the launcher's own choice of shape; 128 / 256: forced
         got = dense_gemm(x, w, b, False)
         form = last_launch()
-    assert form.startswith("gemm128:"), form
-    assert form.endswith("ring2" if ((m + 127) // 128) * ((n + 127) // 128) > 256 else "ring4"), form
+    wide = shape == "256" or (shape == "1" and ((m + 127) // 128) * ((n + 127) // 128) > 256)
+    assert form == ("gemm128:128x256" if wide else "gemm128:128x128"), form
     assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,k,n,bias", [(1024, 4096, 4096, True), (384, 2048, 6144, False), (1500, 1024, 1000, True), (2048, 256, 8192, False)])
-def test_tile128_gives_the_bits_of_the_unsplit_256_tile_kernel(dtype, m, k, n, bias):
+@pytest.mark.parametrize("shape", ["128", "256"])
+def test_tile128_gives_the_bits_of_the_unsplit_256_tile_kernel(dtype, m, k, n, bias, shape):
     """Random data, both forms forced and asserted: same products, same fp32 order, same rounding -> the same bits; and both
     within one unit in the last place of the fp32 reference."""
     torch.manual_seed(k + n)
     x = torch.randn(m, k, dtype=dtype, device=DEV)
     w = (torch.randn(n, k, device=DEV) * 0.05).to(dtype)
     b = torch.randn(n, device=DEV).to(dtype) if bias else None
-    with switch_env(MOJO_HIP_GEMM_TILE128="1"):
+    with switch_env(MOJO_HIP_GEMM_TILE128=shape):
         small = dense_gemm(x, w, b, False)
-        assert last_launch().startswith("gemm128:"), last_launch()
+        assert last_launch() == "gemm128:128x" + shape, last_launch()
         again = dense_gemm(x, w, b, False)
     with switch_env(MOJO_HIP_GEMM_TILE128="0", MOJO_HIP_GEMM_SPLITK="1"):
         large = dense_gemm(x, w, b, False)
@@ -66,15 +68,17 @@ def test_tile128_gives_the_bits_of_the_unsplit_256_tile_kernel(dtype, m, k, n, b
 
 
 def test_tile128_default_choice_and_switch():
-    """Default: taken where the 256 x 256 tiles number at most three quarters of the CUs and there are more than 128 rows;
-    not for a launch that fills the chip, not for `[K, N]` weights, not below 129 rows; MOJO_HIP_GEMM_TILE128=0 turns it off."""
+    """Default: taken where the time model of gemm_api.hip prefers it (more than 128 rows, at most 512 tiles of 128 x 128, and a
+    modelled time below the 256 x 256 kernel's best split); not for a launch that fills the chip with 256 x 256 tiles, not for
+    `[K, N]` weights, not below 129 rows; MOJO_HIP_GEMM_TILE128=0 turns it off."""
     def form(m, k, n, trans=False):
         x = torch.randn(m, k, dtype=torch.bfloat16, device=DEV)
         w = torch.randn((k, n) if trans else (n, k), dtype=torch.bfloat16, device=DEV)
         dense_gemm(x, w, None, trans)
         return last_launch()
-    assert form(1024, 4096, 4096).startswith("gemm128:")
-    assert form(512, 1024, 8192).startswith("gemm128:")
+    assert form(1024, 4096, 4096) == "gemm128:128x128"
+    assert form(512, 1024, 8192) == "gemm128:128x128"
+    assert form(2048, 4096, 4096) == "gemm128:128x256"                # 512 tiles of 128 x 128 -> 256 of 128 x 256
     assert form(8192, 1024, 8192).startswith("gemm256:")              # 1024 tiles of 256 x 256
     assert form(1024, 4096, 4096, trans=True).startswith("gemm256:")
     assert form(128, 4096, 4096).startswith("gemm_skinny")
@@ -82,7 +86,8 @@ def test_tile128_default_choice_and_switch():
         assert form(1024, 4096, 4096).startswith("gemm256:")
 
 
-def test_tile128_row_maps_and_strided_operands():
+@pytest.mark.parametrize("shape", ["128", "256"])
+def test_tile128_row_maps_and_strided_operands(shape):
     """The chunked GEMM + collective pipelines' view: logical row m reads A row (m / rc) * ml + off + m % rc and writes the C
     row of its own map; A and C with row strides wider than K and N."""
     torch.manual_seed(5)
@@ -93,9 +98,9 @@ def test_tile128_row_maps_and_strided_operands():
     out_full = torch.zeros(blocks * 3 * rc, n + 8, dtype=dtype, device=DEV)
     a_map, c_map = (rc, 2 * rc, rc), (rc, 3 * rc, 2 * rc)            # second sub-chunk of 2 -> third sub-chunk of 3
     eng = HipGemmEngine()
-    with switch_env(MOJO_HIP_GEMM_TILE128="1"):
+    with switch_env(MOJO_HIP_GEMM_TILE128=shape):
         eng(a_full[:, :k], w, None, False, out=out_full[:, :n], rows=blocks * rc, a_map=a_map, c_map=c_map)
-        assert last_launch().startswith("gemm128:"), last_launch()
+        assert last_launch() == "gemm128:128x" + shape, last_launch()
     a_rows = torch.cat([a_full[b * 2 * rc + rc: b * 2 * rc + 2 * rc, :k] for b in range(blocks)])
     want = F.linear(a_rows.float(), w.float()).to(dtype)
     got = torch.cat([out_full[b * 3 * rc + 2 * rc: b * 3 * rc + 3 * rc, :n] for b in range(blocks)])
