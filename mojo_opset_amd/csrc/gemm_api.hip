@@ -135,20 +135,21 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
 }
 
 // 128-row tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  Modelled times from measurements on this chip
-// (profiles/r5_gemm_tile128_ab.txt, 80 shapes): up to 256 tiles of 128 x 128, one workgroup per CU, a K-tile takes 0.33 us on an
-// otherwise idle chip and 0.45 us with every CU busy (clock, L2), plus ~5 us of launch, prologue and epilogue; beyond, up to
-// 256 tiles of 128 x 256 (eight waves), 0.34 us + 0.47 us x the share of busy CUs, plus ~6 us.  The 256 kernel's model runs
-// ~15 % under its measured times on split launches, hence the factor.  On the measured grid the rule is within 0.3 %
-// (geometric mean) of always picking the faster form, and 13.5 % ahead of the 256 kernel alone.
-static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n) {
+// (profiles/r5_gemm_tile128_ab.txt, r5_gemm_tile128_ab_kn.txt: 80 shapes per weight layout): up to 256 tiles of 128 x 128, one
+// workgroup per CU, a K-tile takes 0.30 us on an otherwise idle chip and 0.425 us with every CU busy (clock, L2), plus ~5 us of
+// launch, prologue and epilogue; beyond, up to 256 tiles of 128 x 256 (eight waves), 0.34 us + 0.47 us x the share of busy
+// CUs, plus ~6 us; [K,N] weights (transposed fragment reads) 0.05 / 0.04 us more.  The 256 kernel's model runs ~15-20 % under its
+// measured times on split launches, hence the factor.  On the measured grids the rule is within 0.2 % (geometric mean) of always
+// picking the faster form, and 15 % ([N,K]) / 12.5 % ([K,N]) ahead of the 256 kernel alone.
+static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n, bool w_nmajor) {
   const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 64;
   double t128;
-  if (narrow <= 256) t128 = 5.0 + nkt * (0.33 + 0.12 * narrow / 256.0);
-  else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + 0.47 * wide / 256.0);
+  if (narrow <= 256) t128 = 5.0 + nkt * (0.30 + (w_nmajor ? 0.05 : 0.0) + 0.125 * narrow / 256.0);
+  else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + (w_nmajor ? 0.04 : 0.0) + 0.47 * wide / 256.0);
   else return false;
   double t256 = 0;
   (void)gemm_dense_splitk256(m, k, n, &t256);
-  return t128 < 1.15 * t256;
+  return t128 < 1.2 * t256;
 }
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
@@ -193,7 +194,7 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
       if (!gemm_skinny_ok(a, dtype)) { a.splitk = 1; a.slab = nullptr; }
     }
   }
-  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && gemm_tile128_use(a, dtype, m, gemm_dense_prefers_tile128(m, k, n)))
+  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && gemm_tile128_use(a, dtype, m, gemm_dense_prefers_tile128(m, k, n, w_n_stride == 1)))
     return launch_gemm_tile128(a, dtype, m, s);
   if (a.splitk == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && !gemm_skinny_ok(a, dtype) && gemm_mfma256_ok(a, dtype)) {
     const int sk = gemm_dense_splitk256(m, k, n);       // few output tiles: cut K, sum the slices in a second launch

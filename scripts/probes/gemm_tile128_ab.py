@@ -11,21 +11,26 @@ shapes = ((4096, 4096), (4096, 6144), (4096, 28672), (14336, 4096), (3584, 8192)
 ms = (192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096)
 
 
+TRANS = len(sys.argv) > 1 and sys.argv[1] == "KN"          # [K, N] weights (`x @ w`) instead of F.linear's [N, K]
+
+
 def leg(x, w, value):
     os.environ["MOJO_HIP_GEMM_TILE128"] = value
     switches.reload()
-    t = _time(lambda: dense_gemm(x, w, None, False), 20, 5, repeats=3)
+    t = _time(lambda: dense_gemm(x, w, None, TRANS), 20, 5, repeats=3)
     return t, L.last_launch()
 
 
 for k, n in shapes:
     w = torch.randn(n, k, device=dev, dtype=torch.bfloat16) * 0.02
+    if TRANS:
+        w = w.t().contiguous()
     row = {}
     for m in ms:
         x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
         t256, f256 = leg(x, w, "0")
         t128, f128 = leg(x, w, "1")
-        t_lib = _time(lambda: torch.nn.functional.linear(x, w), 20, 5, repeats=3)
+        t_lib = _time((lambda: x @ w) if TRANS else (lambda: torch.nn.functional.linear(x, w)), 20, 5, repeats=3)
         tf = lambda t: round(2.0 * m * k * n / t / 1e12)
         row[m] = {"t256_us": round(t256 * 1e6, 1), "t128_us": round(t128 * 1e6, 1), "hipblaslt_us": round(t_lib * 1e6, 1),
                   "tf256": tf(t256), "tf128": tf(t128), "tf_lib": tf(t_lib), "f256": f256, "f128": f128,

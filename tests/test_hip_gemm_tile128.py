@@ -1,7 +1,7 @@
-"""GPU parity of the 128 x 128-tile dense GEMM (`csrc/gemm_tile128.hip`): the form `mojo_hip_gemm` / `mojo_hip_gemm_rowmap`
-take for one 16-bit product with `[N, K]` weights (the golden's `F.linear(input, weight, bias)`, core/operators/gemm.py:45-46
-and compute_with_comm.py:12-24) whose 256 x 256 tiles would leave most of the chip idle — a prefill chunk of a few hundred to
-two thousand rows.
+"""GPU parity of the 128-row-tile dense GEMM (`csrc/gemm_tile128.hip`): the form `mojo_hip_gemm` / `mojo_hip_gemm_rowmap`
+take for one 16-bit product — `[N, K]` weights (the golden's `F.linear(input, weight, bias)`, core/operators/gemm.py:45-46) or
+`[K, N]` weights (`input @ weight (+ bias)`, compute_with_comm.py:12-24 with trans_weight) — whose 256 x 256 tiles would leave
+most of the chip idle: a prefill chunk of a few hundred to two thousand rows.
 
 Exactness: small-integer data makes every product and partial sum exact in fp32, so the result must equal the fp32 reference
 to the bit whatever the tile shape; on random data the 128-tile form and the unsplit 256-tile form add the same products in
@@ -30,64 +30,82 @@ pytestmark = pytest.mark.gpu
     (513, 320, 260, True),
 ])
 @pytest.mark.parametrize("shape", ["1", "128", "256"])
-def test_tile128_integer_data_is_exact(dtype, m, k, n, bias, shape):
+@pytest.mark.parametrize("layout", ["NK", "KN"])
+def test_tile128_integer_data_is_exact(dtype, m, k, n, bias, shape, layout):
     torch.manual_seed(m + n)
+    if layout == "KN":
+        n = (n + 7) // 8 * 8                                        # [K, N] rows are read in 16-byte pieces
     x = torch.randint(-4, 5, (m, k)).to(dtype).to(DEV)
     w = torch.randint(-4, 5, (n, k)).to(dtype).to(DEV)
     b = torch.randint(-8, 9, (n,)).to(dtype).to(DEV) if bias else None
-    want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)      # ONE rounding, bias included
+    if layout == "NK":
+        want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)  # F.linear: ONE rounding, bias included
+    else:
+        w = w.t().contiguous()                                      # [K, N]: `x @ w` is rounded, then `+ b` is (two operators)
+        want = (x.float() @ w.float()).to(dtype)
+        want = want if b is None else (want.float() + b.float()).to(dtype)
     with switch_env(MOJO_HIP_GEMM_TILE128=shape):                   # 1: the launcher's own choice of shape; 128 / 256: forced
-        got = dense_gemm(x, w, b, False)
+        got = dense_gemm(x, w, b, layout == "KN")
         form = last_launch()
     wide = shape == "256" or (shape == "1" and ((m + 127) // 128) * ((n + 127) // 128) > 256)
-    assert form == ("gemm128:128x256" if wide else "gemm128:128x128"), form
+    assert form == ("gemm128:128x256:" if wide else "gemm128:128x128:") + layout, form
     assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,k,n,bias", [(1024, 4096, 4096, True), (384, 2048, 6144, False), (1500, 1024, 1000, True), (2048, 256, 8192, False)])
 @pytest.mark.parametrize("shape", ["128", "256"])
-def test_tile128_gives_the_bits_of_the_unsplit_256_tile_kernel(dtype, m, k, n, bias, shape):
+@pytest.mark.parametrize("layout", ["NK", "KN"])
+def test_tile128_gives_the_bits_of_the_unsplit_256_tile_kernel(dtype, m, k, n, bias, shape, layout):
     """Random data, both forms forced and asserted: same products, same fp32 order, same rounding -> the same bits; and both
     within one unit in the last place of the fp32 reference."""
     torch.manual_seed(k + n)
     x = torch.randn(m, k, dtype=dtype, device=DEV)
     w = (torch.randn(n, k, device=DEV) * 0.05).to(dtype)
     b = torch.randn(n, device=DEV).to(dtype) if bias else None
+    trans = layout == "KN"
+    if trans:
+        w = w.t().contiguous()
     with switch_env(MOJO_HIP_GEMM_TILE128=shape):
-        small = dense_gemm(x, w, b, False)
-        assert last_launch() == "gemm128:128x" + shape, last_launch()
-        again = dense_gemm(x, w, b, False)
+        small = dense_gemm(x, w, b, trans)
+        assert last_launch() == f"gemm128:128x{shape}:{layout}", last_launch()
+        again = dense_gemm(x, w, b, trans)
     with switch_env(MOJO_HIP_GEMM_TILE128="0", MOJO_HIP_GEMM_SPLITK="1"):
-        large = dense_gemm(x, w, b, False)
+        large = dense_gemm(x, w, b, trans)
         assert last_launch().startswith("gemm256:") and ":splitk" not in last_launch(), last_launch()
     assert torch.equal(small, again)
     assert torch.equal(small, large)
-    want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)
-    assert max_ulp_bf16ish(to_cpu(small), to_cpu(want), atol=2e-2) <= 1
+    if trans:
+        want = (x.float() @ w.float()).to(dtype)
+        want = want if b is None else (want.float() + b.float()).to(dtype)
+    else:
+        want = F.linear(x.float(), w.float(), b if b is None else b.float()).to(dtype)
+    # (x @ w + b: a last-place difference of the rounded product can land on a smaller binade after the bias is added)
+    assert max_ulp_bf16ish(to_cpu(small), to_cpu(want), atol=2e-2) <= (2 if trans and bias else 1)
 
 
 def test_tile128_default_choice_and_switch():
     """Default: taken where the time model of gemm_api.hip prefers it (more than 128 rows, at most 512 tiles of 128 x 128, and a
     modelled time below the 256 x 256 kernel's best split); not for a launch that fills the chip with 256 x 256 tiles, not for
-    `[K, N]` weights, not below 129 rows; MOJO_HIP_GEMM_TILE128=0 turns it off."""
+    not below 129 rows; MOJO_HIP_GEMM_TILE128=0 turns it off."""
     def form(m, k, n, trans=False):
         x = torch.randn(m, k, dtype=torch.bfloat16, device=DEV)
         w = torch.randn((k, n) if trans else (n, k), dtype=torch.bfloat16, device=DEV)
         dense_gemm(x, w, None, trans)
         return last_launch()
-    assert form(1024, 4096, 4096) == "gemm128:128x128"
-    assert form(512, 1024, 8192) == "gemm128:128x128"
-    assert form(2048, 4096, 4096) == "gemm128:128x256"                # 512 tiles of 128 x 128 -> 256 of 128 x 256
+    assert form(1024, 4096, 4096) == "gemm128:128x128:NK"
+    assert form(512, 1024, 8192) == "gemm128:128x128:NK"
+    assert form(2048, 4096, 4096) == "gemm128:128x256:NK"             # 512 tiles of 128 x 128 -> 256 of 128 x 256
     assert form(8192, 1024, 8192).startswith("gemm256:")              # 1024 tiles of 256 x 256
-    assert form(1024, 4096, 4096, trans=True).startswith("gemm256:")
+    assert form(1024, 4096, 4096, trans=True) == "gemm128:128x128:KN"
     assert form(128, 4096, 4096).startswith("gemm_skinny")
     with switch_env(MOJO_HIP_GEMM_TILE128="0"):
         assert form(1024, 4096, 4096).startswith("gemm256:")
 
 
 @pytest.mark.parametrize("shape", ["128", "256"])
-def test_tile128_row_maps_and_strided_operands(shape):
+@pytest.mark.parametrize("layout", ["NK", "KN"])
+def test_tile128_row_maps_and_strided_operands(shape, layout):
     """The chunked GEMM + collective pipelines' view: logical row m reads A row (m / rc) * ml + off + m % rc and writes the C
     row of its own map; A and C with row strides wider than K and N."""
     torch.manual_seed(5)
@@ -98,9 +116,10 @@ def test_tile128_row_maps_and_strided_operands(shape):
     out_full = torch.zeros(blocks * 3 * rc, n + 8, dtype=dtype, device=DEV)
     a_map, c_map = (rc, 2 * rc, rc), (rc, 3 * rc, 2 * rc)            # second sub-chunk of 2 -> third sub-chunk of 3
     eng = HipGemmEngine()
+    wk = w.t().contiguous() if layout == "KN" else w
     with switch_env(MOJO_HIP_GEMM_TILE128=shape):
-        eng(a_full[:, :k], w, None, False, out=out_full[:, :n], rows=blocks * rc, a_map=a_map, c_map=c_map)
-        assert last_launch() == "gemm128:128x" + shape, last_launch()
+        eng(a_full[:, :k], wk, None, layout == "KN", out=out_full[:, :n], rows=blocks * rc, a_map=a_map, c_map=c_map)
+        assert last_launch() == f"gemm128:128x{shape}:{layout}", last_launch()
     a_rows = torch.cat([a_full[b * 2 * rc + rc: b * 2 * rc + 2 * rc, :k] for b in range(blocks)])
     want = F.linear(a_rows.float(), w.float()).to(dtype)
     got = torch.cat([out_full[b * 3 * rc + 2 * rc: b * 3 * rc + 3 * rc, :n] for b in range(blocks)])
