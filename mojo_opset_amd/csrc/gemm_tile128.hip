@@ -6,7 +6,7 @@
 // of the GEMM + collective pipelines.  There a product has fewer 256 x 256 tiles than the chip has CUs, and gemm256_core.h either
 // runs on part of the chip or cuts K into slices whose fp32 slabs cost more than the matrix work (M 1024 x 4096 x 4096: 4 slices,
 // 27 of 48 us are slab traffic).  hipBLASLt switches to 128-row macro tiles for these shapes and was 15-35 % faster
-// (profiles/r5_gemm_mid_m.txt).  This kernel is that tile shape (measured against both: profiles/r5_gemm_tile128_ab.txt,
+// (profiles/r5_gemm_mid_m_before.txt).  This kernel is that tile shape (measured against both: profiles/r5_gemm_tile128_ab.txt,
 // r5_gemm_tile128_ab_kn.txt — M 1024 x 4096 x 4096 [N,K]: 47.7 -> 32.2 us, hipBLASLt 36.3):
 //
 //   * 128 x 128 output tile, K-tiles of 128 bytes, FOUR waves (2 x 2), each 64 x 64 of C on v_mfma_f32_16x16x32 (64 accumulator
