@@ -86,6 +86,10 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the
     return o;
   }
   __device__ __forceinline__ void row_begin(int) {}
+  // gemm_tile128_core.h: what the epilogue needs from memory, requested BEFORE the K loop (nothing here)
+  struct Pre {};
+  __device__ __forceinline__ void preload(Pre&, int, int, int, int) const {}
+  __device__ __forceinline__ void store_pre(const Pre&, int, int, int m, int n, int n_limit, f32x4 acc) const { store(m, n, n_limit, acc); }
   __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
     typedef typename vec_of<T, 4>::type V4;
     V4 o;
@@ -127,6 +131,7 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
   typedef TO out_t;
   TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;
   float rs;
+  bool vec4 = false;         // store(): four outputs in one store where they fit (the caller vouches for ldc % 4 == 0 and an aligned C)
   __host__ __device__ __forceinline__ bool has_bias() const { return false; }
   __device__ __forceinline__ typename vec_of<TO, 4>::type to4(int n, ACC acc) const {   // full tiles only: n + 4 <= N
     typename vec_of<TO, 4>::type o;
@@ -139,8 +144,39 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
     return o;
   }
   __device__ __forceinline__ void row_begin(int m) { rs = row_scale[m]; }
+  // gemm_tile128_core.h: a lane's four row scales and sixteen column scales (a 64 x 64 wave tile: rows m_first + 16 i, columns
+  // n_first + 16 j + e), requested BEFORE the K loop — fetched in the epilogue they cost two dependent memory latencies
+  // (~6 us of a 20 us launch at K 4096)
+  struct Pre { float rs[4]; float cs[4][4]; };
+  __device__ __forceinline__ void preload(Pre& p, int m_first, int m_limit, int n_first, int n_limit) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p.rs[i] = row_scale[min(m_first + i * 16, m_limit - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p.cs[j][e] = static_cast<float>(col_scale[min(n_first + j * 16 + e, n_limit - 1)]);
+  }
+  __device__ __forceinline__ void store_pre(const Pre& p, int i, int j, int m, int n, int n_limit, ACC acc) const {
+    TO* dst = C + static_cast<int64_t>(m) * ldc + n;
+    typename vec_of<TO, 4>::type o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), p.rs[i]), p.cs[j][e]);
+      asm volatile("" : "+v"(v));                          // see store(): the fp32 product is a value of its own
+      o[e] = elt<TO>::from_f(v);
+    }
+    if (vec4 && n + 4 <= n_limit) {
+      *reinterpret_cast<typename vec_of<TO, 4>::type*>(dst) = o;
+    } else {
+      for (int e = 0; e < 4 && n + e < n_limit; ++e) dst[e] = o[e];
+    }
+  }
   __device__ __forceinline__ void store(int m, int n, int n_limit, ACC acc) const {
     TO* dst = C + static_cast<int64_t>(m) * ldc + n;
+    if (vec4 && n + 4 <= n_limit) {
+      *reinterpret_cast<typename vec_of<TO, 4>::type*>(dst) = to4(n, acc);
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e < n_limit) {

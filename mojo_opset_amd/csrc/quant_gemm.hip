@@ -11,6 +11,7 @@
 #include <type_traits>
 
 #include "gemm256_core.h"
+#include "gemm_tile128_core.h"
 #ifdef MOJO_HIP_BUILD_EXPERIMENTS        // in-launch split-K combine, measured slower (DESIGN Appendix A #9): opt-in build only
 #include "experiments/splitk_combine.h"
 #endif
@@ -490,6 +491,29 @@ static int quant_splitk(int64_t m, int k, int n) {
   return sk < 1 ? 1 : static_cast<int>(sk);
 }
 
+// 128-row tiles (gemm_tile128_core.h) for a mid-size M with [N,K] weights: the launches the 256 x 256 kernel can only fill by
+// cutting K into fp32 / int32 slabs.  Same time model as the 16-bit products (gemm_api.hip, gemm_dense_prefers_tile128): a
+// K-tile is 128 bytes of K in both, and the 128-row tile is bound by its fill, not by the (twice as fast) 8-bit MFMAs; the
+// 256 x 256 kernel's dequantising epilogue adds ~10 us (its scales are fetched after the K loop; here they are requested before
+// it).  Measured, both kernels forced in one process, 80 shapes per dtype (profiles/r5_quant_tile128_ab.txt): M 1024 x 4096 x 4096
+// int8 39 -> 19 us, M 512 x 2048 x 7168 48 -> 12 us; over the grid the rule is 63 % faster (geometric mean) than the 256 x 256
+// kernel alone and within 0.7 % of always picking the faster form.
+static bool quant_tile128_ok(int64_t m, const GemmArgs& a, int out_elt_bytes) {
+  return m > 128 && a.w_k == 1 && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.w_n % 16 == 0 && a.ldc % 4 == 0 &&
+         aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 4 * out_elt_bytes);
+}
+static bool quant_prefers_tile128(int64_t m, int k, int n) {
+  const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 128;
+  double t128;
+  if (narrow <= 256) t128 = 5.0 + nkt * (0.30 + 0.125 * narrow / 256.0);
+  else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + 0.47 * wide / 256.0);
+  else return false;
+  const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), sk = quant_splitk(m, k, n);
+  const double t256 = static_cast<double>(ceil_div(tiles * sk, 256)) * (static_cast<double>(nkt) / sk) * 1.06 + 10.0 +
+                      (sk > 1 ? 2.0 * sk * m * n * 4.0 / 5e6 + 4.0 : 0.0);
+  return t128 < 1.2 * t256;
+}
+
 template <typename TO>
 static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, int quant_dtype, void* slab_ws,
                      hipStream_t s) {
@@ -498,6 +522,17 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
     return fp8 ? launch_quant_gemv<TO, true>(a, rs, cs, m, s) : launch_quant_gemv<TO, false>(a, rs, cs, m, s);
   if (quant_skinny_ok(m, a) && (gemm_skinny_mask() & SKINNY_UNIFORM))
     return fp8 ? launch_quant_skinny<TO, true>(a, rs, cs, m, slab_ws, s) : launch_quant_skinny<TO, false>(a, rs, cs, m, slab_ws, s);
+  if (quant_tile128_ok(m, a, sizeof(TO))) {
+    const int f = g128::forced_choice();
+    if (f < 0 ? quant_prefers_tile128(m, a.K, a.N) : f == 1) {
+      if (fp8) {
+        g256::EpilogueDequant<TO, f32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f, true};
+        return g128::launch<g256::PolF8>(a, epi, m, s);
+      }
+      g256::EpilogueDequant<TO, i32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f, true};
+      return g128::launch<g256::PolI8>(a, epi, m, s);
+    }
+  }
   if (g256::gemm256_layout_ok(a, 1)) {
     const int sk = quant_splitk(m, a.K, a.N);
     if (sk > 1) {

@@ -128,6 +128,7 @@ def test_quant_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(m, k, 
     # (few output tiles would otherwise take the split-K route, whose slabs go through a finalize kernel — NOT this epilogue:
     # round 4's version of this test compared that route with itself)
     monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")             # (and not the 128-row-tile kernel, which has its own epilogue)
     staged = op(x, s_in)
     assert last_launch().startswith("gemm256:staged"), last_launch()
     monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")          # (the fixture makes the library re-read its switches)
@@ -248,3 +249,50 @@ def test_quant_gemm_split_k_route_is_deterministic_and_exact(quant_dtype, monkey
             torch.testing.assert_close(outs[sk].float(), exact.float(), atol=2e-2 * k ** 0.5, rtol=2 ** -7)
     if quant_dtype == torch.int8:
         assert torch.equal(outs["1"], outs["2"]) and torch.equal(outs["1"], outs["8"])
+
+
+@pytest.mark.parametrize("quant_dtype", [torch.int8, torch.float8_e4m3fn])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("m,k,n", [(129, 128, 128), (300, 384, 520), (1024, 7168, 1536), (513, 1024, 4104), (2048, 512, 2304)])
+@pytest.mark.parametrize("shape", ["128", "256"])
+def test_quant_gemm_tile128_equals_the_256_tile_kernel_and_the_integer_formula(m, k, n, odt, quant_dtype, shape, monkeypatch):
+    """Mid-size M with `[N,K]` weights (`trans_weight=True`): the 128-row-tile kernel (csrc/gemm_tile128_core.h; both tile
+    widths forced in turn) against the unsplit 256 x 256 kernel — int32 accumulation is exact, and the fp8 products are summed by
+    the same instruction in the same order, so the outputs must be the same bits; int8 also equals the integer formula exactly.
+    Ragged M and N, one and odd K-tile counts."""
+    torch.manual_seed(m + n)
+    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=odt, trans_weight=True, quant_dtype=quant_dtype, weight_dtype=quant_dtype, device=DEV)
+    if quant_dtype == torch.int8:
+        op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=DEV))
+        x = torch.randint(-127, 128, (m, k), dtype=torch.int8, device=DEV)
+    else:
+        op.weight.copy_(torch.randn(n, k, device=DEV).to(quant_dtype))
+        x = torch.randn(m, k, device=DEV).to(quant_dtype)
+    op.weight_scale.copy_(torch.rand(n, device=DEV) * 0.02)
+    s_in = torch.rand(m, device=DEV)
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", shape)
+    small = op(x, s_in)
+    assert last_launch() == f"gemm128:128x{shape}:NK", last_launch()
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
+    large = op(x, s_in)
+    assert last_launch().startswith("gemm256:") and ":splitk" not in last_launch(), last_launch()
+    assert torch.equal(small, large)
+    if quant_dtype == torch.int8:
+        exact = quant_gemm_formula(x.cpu(), op.weight.cpu().t(), s_in.cpu(), op.weight_scale.cpu(), odt)
+        torch.testing.assert_close(to_cpu(small), exact, atol=0, rtol=0)
+
+
+def test_quant_gemm_tile128_default_choice():
+    """Taken by default where the time model prefers it (few 256 x 256 tiles, `[N,K]` weights, more than 128 rows); `[K,N]`
+    weights and chip-filling launches stay on the 256 x 256 kernel."""
+    def form(m, k, n, trans):
+        op = hip_cls("MojoQuantGemm")(k, n, output_dtype=torch.bfloat16, trans_weight=trans, device=DEV)
+        op.weight.copy_(torch.randint(-127, 128, (n, k) if trans else (k, n), dtype=torch.int8, device=DEV))
+        op.weight_scale.fill_(0.01)
+        op(torch.randint(-127, 128, (m, k), dtype=torch.int8, device=DEV), torch.rand(m, device=DEV))
+        return last_launch()
+    assert form(1024, 4096, 4096, True) == "gemm128:128x128:NK"
+    assert form(2048, 4096, 4096, True) == "gemm128:128x256:NK"
+    assert form(1024, 4096, 4096, False).startswith("gemm256:")
+    assert form(8192, 1024, 8192, True).startswith("gemm256:")
