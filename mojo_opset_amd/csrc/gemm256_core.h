@@ -76,6 +76,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base
 template <typename T>
 struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the golden's `x @ w + b`), or round_T(acc + bias) (its F.linear)
   static constexpr bool kRowStaged = sizeof(T) == 2;   // may go through the wave-private LDS transpose (see the kernel's epilogue)
+  static constexpr bool kLdsScales = false;
   typedef T out_t;
   T* C; int64_t ldc; const T* bias; bool bias_fused = false;
   __host__ __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
@@ -111,6 +112,7 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the
 
 struct EpilogueF32 {         // C (fp32) = acc, or C += acc: two-pass products (x @ w_hi, then + x @ w_lo) of the MoE router
   static constexpr bool kRowStaged = false;
+  static constexpr bool kLdsScales = false;
   float* C; int64_t ldc; int accumulate;
   __device__ __forceinline__ void row_begin(int) {}
   __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
@@ -128,6 +130,11 @@ struct EpilogueF32 {         // C (fp32) = acc, or C += acc: two-pass products (
 template <typename TO, typename ACC>
 struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_scale[n] )   (golden: gemm.py:213-223)
   static constexpr bool kRowStaged = sizeof(TO) == 2;
+  // 256 x 256 kernel, row-staged epilogue: every thread fetches ONE of the tile's 256 row / 256 column scales before the K loop
+  // and parks it in 2 KiB of LDS behind the tile buffers when the loop is over; the epilogue reads its scales from there.  Fetched
+  // inside the epilogue they were an exposed memory latency per tile: 3.4 % of the M 4096 x 7168 x 36864 product, 9 % at K 4096
+  // (scripts/probes/quant_headline_scales.py: the same kernel with constants in place of the fetches).
+  static constexpr bool kLdsScales = sizeof(TO) == 2;
   typedef TO out_t;
   TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;
   float rs;
@@ -137,13 +144,35 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
     typename vec_of<TO, 4>::type o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+#ifdef QG_NO_SCALE_LOADS                                  // timing only (scripts/probes/quant_headline_scales.py): what the scale fetches cost
+      float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), rs), 0.5f);
+#else
       float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), rs), static_cast<float>(col_scale[n + e]));
+#endif
       asm volatile("" : "+v"(v));                          // see store(): the fp32 product is a value of its own
       o[e] = elt<TO>::from_f(v);
     }
     return o;
   }
+#ifdef QG_NO_SCALE_LOADS
+  __device__ __forceinline__ void row_begin(int m) { rs = 0.25f + m * 1e-6f; }
+#else
   __device__ __forceinline__ void row_begin(int m) { rs = row_scale[m]; }
+#endif
+  // thread t of the 512: t < 256 the scale of row m0 + t, else of column n0 + t - 256 (clamped to valid entries)
+  __device__ __forceinline__ float scale_for_thread(int t, int m0, int m_limit, int n0, int n_limit) const {
+    return t < 256 ? row_scale[min(m0 + t, m_limit - 1)] : static_cast<float>(col_scale[min(n0 + t - 256, n_limit - 1)]);
+  }
+  __device__ __forceinline__ typename vec_of<TO, 4>::type to4_scaled(ACC acc, float row, f32x4 col) const {
+    typename vec_of<TO, 4>::type o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), row), col[e]);
+      asm volatile("" : "+v"(v));                          // see store(): the fp32 product is a value of its own
+      o[e] = elt<TO>::from_f(v);
+    }
+    return o;
+  }
   // gemm_tile128_core.h: a lane's four row scales and sixteen column scales (a 64 x 64 wave tile: rows m_first + 16 i, columns
   // n_first + 16 j + e), requested BEFORE the K loop — fetched in the epilogue they cost two dependent memory latencies
   // (~6 us of a 20 us launch at K 4096)
@@ -343,6 +372,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     for (int h = 0; h < 2; ++h) srcW[h] += static_cast<int64_t>(kt0) * w_step;
   };
   locate(bid);
+  float pre_scale = 0.f;                            // (EpilogueDequant: see kLdsScales)
+  if constexpr (Epi::kLdsScales && !PERSIST) {
+    if (a.stage_rows) pre_scale = epi.scale_for_thread(threadIdx.x, m0, m_end, n0, a.N);
+  }
 
   // stage half-tile `which` (0:A0 1:A1 2:W0 3:W1) of K-tile kt (relative to this slice) into buffer buf
   auto stage = [&](int which, int kt, int buf) {
@@ -725,20 +758,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     // stride 128 B, 8-byte slot s of row r at s ^ (((r >> 1) & 3) << 2) (2-way = minimal conflicts for the writes,
     // 16-byte pairs stay together for the reads).
     if (a.stage_rows && n0 + BN <= a.N && !epi.has_bias()) {
+      typedef __attribute__((address_space(3))) float lds_float;
+      lds_float* scales = reinterpret_cast<lds_float*>(smem + LDS_BYTES);     // [256 row scales | 256 column scales], kLdsScales only
+      if constexpr (Epi::kLdsScales && !PERSIST) scales[threadIdx.x] = pre_scale;
       __builtin_amdgcn_s_barrier();                        // every wave is done with the tile buffers (and its DMA has landed)
       lds_char* reg = smem + wave * 16384;
       typedef typename Epi::out_t OT;
       typedef typename vec_of<OT, 4>::type V4;
       typedef typename vec_of<OT, 8>::type V8;
       const int l15 = lane & 15, g4 = lane >> 4;
+      f32x4 col_scale_v[4];                               // (read once: behind the staging stores below the compiler would re-read them per row tile)
+      if constexpr (Epi::kLdsScales && !PERSIST) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          col_scale_v[nt] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(scales + 256 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4);
+      }
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const int row = (mt >> 2) * 64 + (mt & 3) * 16 + l15;
         const int sw = ((row >> 1) & 3) << 2;
-        epi.row_begin(min(m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15, m_end - 1));   // rows past the group: staged, never stored
+        float row_scale_v = 0.f;
+        if constexpr (Epi::kLdsScales && !PERSIST) row_scale_v = scales[(mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15];
+        else epi.row_begin(min(m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15, m_end - 1));   // rows past the group: staged, never stored
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const V4 o = epi.to4(n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4, acc[mt][nt]);
+          V4 o;
+          if constexpr (Epi::kLdsScales && !PERSIST)
+            o = epi.to4_scaled(acc[mt][nt], row_scale_v, col_scale_v[nt]);
+          else
+            o = epi.to4(n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4, acc[mt][nt]);
           const int slot = ((nt >> 1) * 8 + (nt & 1) * 4 + g4) ^ sw;
           *reinterpret_cast<__attribute__((address_space(3))) V4*>(reg + row * 128 + slot * 8) = o;
         }
@@ -861,16 +909,17 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
       return MOJO_OK;
     }
   }
+  constexpr int LDS_K = LDS_BYTES + (Epi::kLdsScales ? 2048 : 0);      // + the epilogue's scales
   if (a.w_n == 1) {
     auto* fn = gemm256_kernel<P, true, Epi>;
     static std::atomic<uint64_t> attr_set{0};
-    if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
+    if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_K);
+    hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_K, s, a, epi);
   } else {
     auto* fn = gemm256_kernel<P, false, Epi>;
     static std::atomic<uint64_t> attr_set{0};
-    if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_BYTES, s, a, epi);
+    if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_K);
+    hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_K, s, a, epi);
   }
   MOJO_CHECK_LAUNCH("gemm256");
   note_launch("gemm256:%s:%s%s%s", a.stage_rows ? "staged" : "direct", a.w_n == 1 ? "KN" : "NK", a.splitk > 1 ? ":splitk" : "",
