@@ -922,8 +922,8 @@ inline int gemm256_launch(const GemmArgs& a_in, const Epi& epi, int64_t m_total,
     hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(blocks)), dim3(512), LDS_K, s, a, epi);
   }
   MOJO_CHECK_LAUNCH("gemm256");
-  note_launch("gemm256:%s:%s%s%s", a.stage_rows ? "staged" : "direct", a.w_n == 1 ? "KN" : "NK", a.splitk > 1 ? ":splitk" : "",
-              a.stagger_ticks ? ":stagger" : "");
+  note_launch("gemm256:%s:%s%s%s%s", a.stage_rows ? "staged" : "direct", a.w_n == 1 ? "KN" : "NK", a.splitk > 1 ? ":splitk" : "",
+              a.stagger_ticks ? ":stagger" : "", a.glu ? ":glu" : "");
   return MOJO_OK;
 }
 

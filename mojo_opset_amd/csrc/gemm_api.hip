@@ -243,6 +243,13 @@ extern "C" int mojo_hip_gemm_swiglu(const void* input, const void* weight, void*
   a.uniform_rows = static_cast<int>(m);
   a.glu = 1;
   if (gemm_skinny_glu_ok(a, dtype)) return launch_gemm_skinny_glu(a, dtype, s);
+  // Prefill-sized rows: the 256 x 256 kernel's fused-SwiGLU tiles (an output tile pairs 128 gate columns with their 128 up
+  // columns: MojoExperts' epilogue, here with one group) where they fill the chip — the [M, 2 I] product (117 MB written and
+  // read back at M 2048, I 14336) never exists.  Below ~3/4 of a round of tiles the unfused route is faster: its product runs
+  // on the 128-row tiles of gemm_tile128.hip.  MOJO_HIP_GEMM_SKINNY without bit 4 (SKINNY_GLU) turns every fused form off.
+  if ((gemm_skinny_mask() & SKINNY_GLU) && m > 128 && gemm_mfma256_glu_ok(a, dtype) &&
+      ceil_div(m, 256) * (inter / 128) >= 192 && lda % 8 == 0 && ldc % 8 == 0)
+    return launch_gemm_mfma256(a, dtype, m, s);
   // any other shape: the product into the workspace, then the activation over its two halves (same bits: the fused
   // epilogue rounds where these two launches round)
   MOJO_REQUIRE(workspace && workspace_bytes >= mojo_hip_gemm_swiglu_workspace_bytes(m, k, inter) && aligned_to(workspace, 16),

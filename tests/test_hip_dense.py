@@ -133,3 +133,33 @@ def test_swiglu_mlp_fp32_and_graph_capture():
         torch.cuda.synchronize()
         assert torch.equal(out, op16(xs))
     assert last_launch()
+
+
+@pytest.mark.parametrize("m,inp,hidden", [(512, 1024, 14336), (2048, 4096, 14336), (300, 512, 24576)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_swiglu_prefill_rows_take_the_fused_tiles_and_give_the_unfused_bits(m, inp, hidden, dtype):
+    """More than 128 rows and enough fused tiles to fill the chip: `mojo_hip_gemm_swiglu` runs the 256 x 256 kernel's
+    fused-SwiGLU epilogue with one group (`gemm256:...:glu`; the [M, 2 hidden] product never exists).  A/B against the unfused
+    route (MOJO_HIP_GEMM_SKINNY without bit 4: the product, then `mojo_hip_swiglu_rows`), both forms asserted: the fused
+    epilogue rounds where the two launches round, so the outputs are the same bits; and both match the oracle's MLP front half."""
+    from hip_utils import switch_env
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_swiglu
+    torch.manual_seed(m + hidden)
+    x = torch.randn(m, inp, device=DEV).to(dtype)
+    w = (torch.randn(2 * hidden, inp, device=DEV) * 0.03).to(dtype)
+    hist = launches_of(lambda: dense_gemm_swiglu(x, w))
+    fused = dense_gemm_swiglu(x, w)
+    assert ":glu" in hist and "gemm256:" in hist, hist
+    with switch_env(MOJO_HIP_GEMM_SKINNY="27"):
+        hist2 = launches_of(lambda: dense_gemm_swiglu(x, w))
+        unfused = dense_gemm_swiglu(x, w)
+    assert ":glu" not in hist2, hist2
+    assert torch.equal(fused, unfused)
+    a = torch.nn.functional.linear(x.float(), w.float()).to(dtype).float()           # the golden's rounding points
+    want = (torch.nn.functional.silu(a[:, :hidden]).to(dtype).float() * a[:, hidden:]).to(dtype)
+    # (three rounded stages: where the rounded gate or up value flips its last place — a different fp32 summation order is
+    # enough — silu(gate) * up moves by up to two of the factors' last places: 2^-7 each; over 29 M outputs a handful sit at 2 %.
+    # Twice the reference's GEMM-family tolerance per element, and a mean error below 1 % of the mean magnitude)
+    err = (fused.float() - want.float()).abs()
+    assert bool((err <= 2.0 ** -5 * want.float().abs() + 2.0 ** -5).all())
+    assert float(err.mean()) <= 0.01 * float(want.float().abs().mean())
