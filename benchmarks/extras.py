@@ -838,6 +838,128 @@ def bench_decode_layer(device):
     return {"llama3_8b_layer_B64_ctx4096": res, "llama3_8b_layer_B64_ctx4096_fused": fused, "llama3_8b_layer_B64_ctx4096_mojo_api": api}
 
 
+def bench_dense_mid_m(device):
+    """Dense products at mid-size M (a prefill chunk of 256-2048 tokens; config 4 at M 1024): this backend's `mojo_hip_gemm`
+    (kernel form recorded: the 128-row tiles of round 5, or the 256 x 256 kernel) next to hipBLASLt on the same box in the same
+    run (`F.linear` / `x @ w`), and MojoQuantGemm ([N,K] weights) at the same sizes.  Device times under graph replay."""
+    from mojo_opset_amd.backends.hip import lib as _L
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+    out = {}
+    dt = torch.bfloat16
+    for m, k, n in ((512, 4096, 4096), (1024, 4096, 4096), (2048, 4096, 4096), (1024, 4096, 6144), (512, 3584, 8192), (1024, 14336, 4096)):
+        x = torch.randn(m, k, device=device, dtype=dt)
+        for layout in ("NK", "KN"):
+            if not _want(f"dense_{m}x{k}x{n}_{layout}"):
+                continue
+            w = torch.randn(n, k, device=device, dtype=dt) * 0.02
+            w = w if layout == "NK" else w.t().contiguous()
+            trans = layout == "KN"
+            t = _time_graph(lambda: dense_gemm(x, w, None, trans), reps=10)
+            form = _L.last_launch()
+            t_lib = _time_graph((lambda: x @ w) if trans else (lambda: torch.nn.functional.linear(x, w)), reps=10)
+            rec = _mfma(t, 2.0 * m * k * n)
+            rec.update({"kernel_form": form, "hipblaslt_same_box_us": t_lib * 1e6, "time_vs_hipblaslt": t / t_lib})
+            out[f"dense_{m}x{k}x{n}_{layout}"] = rec
+    for qd, tag in ((torch.int8, "int8"), (torch.float8_e4m3fn, "fp8_e4m3")):
+        for m, k, n in ((512, 4096, 4096), (1024, 4096, 4096), (1024, 7168, 4096), (2048, 7168, 1536)):
+            if not _want(f"quant_{tag}_{m}x{k}x{n}_NK"):
+                continue
+            op = hip("MojoQuantGemm")(k, n, output_dtype=dt, trans_weight=True, quant_dtype=qd, weight_dtype=qd, device=device)
+            if qd == torch.int8:
+                op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=device))
+                xq = torch.randint(-127, 128, (m, k), dtype=torch.int8, device=device)
+            else:
+                op.weight.copy_(torch.randn(n, k, device=device).to(qd))
+                xq = torch.randn(m, k, device=device).to(qd)
+            op.weight_scale.fill_(0.01)
+            sc = torch.rand(m, device=device)
+            t = _time_graph(lambda: op(xq, sc), reps=10)
+            rec = _mfma(t, 2.0 * m * k * n, peak=2 * MFMA_BF16_PEAK_TFLOPS)
+            rec["kernel_form"] = _L.last_launch()
+            out[f"quant_{tag}_{m}x{k}x{n}_NK"] = rec
+            del op
+    return out
+
+
+def bench_prefill_layer(device):
+    """One whole Llama-3-8B decoder layer at PREFILL, written only against the reference's operator API (what a model file gets
+    with MOJO_BACKEND=hip): MojoResidualAddRMSNorm -> MojoGemm (QKV) -> MojoApplyRoPE -> MojoStorePagedKVCache ->
+    MojoPagedPrefillGQA -> MojoGemm (o) -> MojoResidualAddRMSNorm -> MojoSwiGLUMLP.  Two batches: 4 x 2048 new tokens (the
+    projections are chip-filling 256 x 256-tile GEMMs, gate|up with the fused SwiGLU epilogue) and a CHUNK of 1024 tokens behind
+    4096 cached ones (mid-size M: the 128-row-tile kernel of round 5).  One captured graph each; MFMA fraction of the whole layer
+    against the dense bf16 peak."""
+    hq, hkv, d, page, hidden, inter = 32, 8, 128, 16, 4096, 14336
+    dt = torch.bfloat16
+    w_qkv = torch.randn((hq + 2 * hkv) * d, hidden, device=device, dtype=dt) * 0.02
+    w_o = torch.randn(hidden, hq * d, device=device, dtype=dt) * 0.02
+    norm1 = hip("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=device)
+    norm2 = hip("MojoResidualAddRMSNorm")(hidden, 1e-5, "pre", dtype=dt, device=device)
+    rope, store, attn = hip("MojoApplyRoPE")(), hip("MojoStorePagedKVCache")(), hip("MojoPagedPrefillGQA")()
+    g_qkv, g_o = hip("MojoGemm")(weight=w_qkv), hip("MojoGemm")(weight=w_o)
+    mlp = hip("MojoSwiGLUMLP")(hidden, hidden, inter).to(dt).to(device)
+    with torch.no_grad():
+        mlp.fc1.weight.normal_(std=0.02)
+        mlp.fc2.weight.normal_(std=0.02)
+    out = {}
+    for name, (q_lens, cached) in {"llama3_8b_prefill_layer_4x2048": ([2048] * 4, [0] * 4),
+                                   "llama3_8b_prefill_layer_chunk1024_cached4096": ([1024], [4096])}.items():
+        if not _want(name):
+            continue
+        tokens = sum(q_lens)
+        kv = [a + b for a, b in zip(q_lens, cached)]
+        k_cache, v_cache, table = _paged(device, kv, hkv, d, page)
+        cu = lambda l: torch.tensor([0] + list(torch.tensor(l).cumsum(0).tolist()), dtype=torch.int32, device=device)  # noqa: E731
+        cu_q, cu_kv = cu(q_lens), cu(kv)
+        ctx_t = torch.tensor(cached, dtype=torch.int32, device=device)
+        x = torch.randn(tokens, hidden, device=device, dtype=dt)
+        resid = torch.randn(tokens, hidden, device=device, dtype=dt)
+        cos, sin = torch.randn(tokens, d, device=device), torch.randn(tokens, d, device=device)
+
+        def layer():
+            h, r1 = norm1(x, resid)
+            qkv = g_qkv(h)
+            q = qkv[:, : hq * d].reshape(tokens, hq, d)
+            k = qkv[:, hq * d: (hq + hkv) * d].reshape(tokens, hkv, d)
+            v = qkv[:, (hq + hkv) * d:].reshape(tokens, hkv, d).contiguous()
+            q_r, k_r = rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False)
+            store(k_r.squeeze(0).contiguous(), v, k_cache, v_cache, table, cu_q, ctx_t)
+            o = attn(q_r.squeeze(0).contiguous(), k_cache, v_cache, cu_q, table, cu_total_seq_lens=cu_kv, max_q_len=max(q_lens),
+                     max_total_seq_len=max(kv))
+            h2, r2 = norm2(g_o(o.reshape(tokens, hq * d)), r1)
+            return mlp(h2), r2
+
+        from mojo_opset_amd.backends.hip import lib as _L
+        _L.launch_history(clear=True)
+        layer()
+        forms = _L.launch_history()
+        t = _time_graph(layer, reps=2, replays=5)
+        h, r1 = norm1(x, resid)
+        qkv = g_qkv(h)
+        q = qkv[:, : hq * d].reshape(tokens, hq, d).contiguous()
+        k = qkv[:, hq * d: (hq + hkv) * d].reshape(tokens, hkv, d).contiguous()
+        v = qkv[:, (hq + hkv) * d:].reshape(tokens, hkv, d).contiguous()
+        o = attn(q, k_cache, v_cache, cu_q, table, cu_total_seq_lens=cu_kv, max_q_len=max(q_lens), max_total_seq_len=max(kv)).reshape(tokens, hq * d)
+        parts = {
+            "norm_x2": 2 * _time_graph(lambda: norm1(x, resid), reps=4),
+            "qkv_gemm": _time_graph(lambda: g_qkv(h), reps=4),
+            "rope": _time_graph(lambda: rope(q.unsqueeze(0), k.unsqueeze(0), cos, sin, head_first=False), reps=4),
+            "kv_store": _time_graph(lambda: store(k, v, k_cache, v_cache, table, cu_q, ctx_t), reps=4),
+            "attention": _time_graph(lambda: attn(q, k_cache, v_cache, cu_q, table, cu_total_seq_lens=cu_kv, max_q_len=max(q_lens), max_total_seq_len=max(kv)), reps=2),
+            "o_gemm": _time_graph(lambda: g_o(o), reps=4),
+            "swiglu_mlp": _time_graph(lambda: mlp(h), reps=2),
+        }
+        gemm_flops = 2.0 * tokens * hidden * ((hq + 2 * hkv) * d + hq * d + 3 * inter)
+        attn_flops = sum(4.0 * hq * d * (a * b - a * a / 2.0) for a, b in zip(q_lens, kv))
+        rec = _mfma(t, gemm_flops + attn_flops)
+        rec.update({"tokens": tokens, "tokens_per_s_one_layer": tokens / t, "gemm_tflop": gemm_flops / 1e12, "attention_tflop": attn_flops / 1e12,
+                    "per_op_us": {n: v_ * 1e6 for n, v_ in parts.items()}, "sum_of_ops_us": sum(parts.values()) * 1e6,
+                    "kernel_forms": forms,
+                    "note": "graph replay; the layer written only against the reference's operator API (MojoGemm, MojoSwiGLUMLP, ...)"})
+        out[name] = rec
+        del k_cache, v_cache
+    return out
+
+
 def bench_dense_decode(device):
     """Decode-sized dense bf16 GEMMs with K-major ([N,K], `F.linear`) weights — the GEMM half of the GEMM+collective ops at
     decode batch sizes; timed under HIP-graph replay (the Python shim's launch overhead would hide the kernel)."""
@@ -924,7 +1046,8 @@ def run_extras(device, world, rank=0):
                      ("MojoPagedPrefillGQA_bf16", bench_prefill), ("MojoPagedDecodeMLA_bf16", bench_mla_decode),
                      ("MojoPagedPrefillMLA_bf16", bench_mla_prefill),
                      ("streaming_ops", bench_streaming), ("MoE_bf16", bench_moe),
-                     ("dense_gemm_decode_bf16", bench_dense_decode), ("decode_layer_bf16", bench_decode_layer),
+                     ("dense_gemm_decode_bf16", bench_dense_decode), ("dense_gemm_mid_m", bench_dense_mid_m),
+                     ("decode_layer_bf16", bench_decode_layer), ("prefill_layer_bf16", bench_prefill_layer),
                      ("host_overhead_decode_step", bench_host_overhead)):
         try:
             out[name] = fn(device)
