@@ -42,7 +42,7 @@
 #ifndef T128_TR_BUILTIN        // 1 = the [K,N] transposed reads through the builtin: hipcc then waits vmcnt(0) in front of each (measurement)
 #define T128_TR_BUILTIN 0
 #endif
-#ifndef T128_ABLATE            // scripts/probes/tile128_anatomy.hip compiles this file with 2 / 3 / 4 (timing only, wrong results)
+#ifndef T128_ABLATE            // scripts/probes/tile128_anatomy.hip compiles this file with 1 (no C stores) / 2 / 3 / 4 (timing only, wrong results)
 #define T128_ABLATE 0
 #endif
 
@@ -337,6 +337,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
     for (int j = 0; j < WN; ++j) {
       const int n = n0 + wn * (WN * 16) + j * 16 + (lane >> 4) * 4;
       if (n >= a.N) continue;
+      if constexpr (T128_ABLATE == 1) {              // timing only: keep the accumulators alive, store (almost) nothing
+        if (__builtin_bit_cast(int, acc[i][j][0]) != 0x7fc12345) continue;
+      }
       epi.store_pre(pre, i, j, mc, n, a.N, acc[i][j]);
     }
   }

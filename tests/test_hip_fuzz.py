@@ -133,11 +133,46 @@ def test_fuzz_group_gemm_exact(seed):
     assert torch.equal(to_cpu(got).float()[: sum(counts)], want.to(dtype).float())
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_dense_gemm_exact(seed):
+    """`mojo_hip_gemm` above 128 rows — the 128-row tiles (both tile widths forced or the launcher's / the time model's own
+    choice), the 256 x 256 kernel with and without its K split: small-integer operands, ragged M and N, K-tile counts from one
+    up, both weight layouts and 16-bit types, bias with the golden's rounding (`F.linear`: one rounding; `x @ w + b`: two)."""
+    import torch.nn.functional as F
+    from hip_utils import last_launch, switch_env
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+    rnd = random.Random(4500 + seed + OFFSET)
+    m = rnd.choice([129, 130, 255, 256, 257, 300, 511, 640, 1000, 1024, 1100, 2047, 2500])
+    k = 64 * rnd.choice([1, 2, 3, 4, 5, 8, 9, 16, 31, 64])
+    n = 8 * rnd.choice([1, 2, 15, 16, 17, 32, 33, 64, 100, 128, 130, 512, 515])
+    trans = rnd.random() < 0.5
+    dtype = rnd.choice([torch.bfloat16, torch.float16])
+    force = rnd.choice([None, None, "1", "128", "256", "0"])
+    g = torch.Generator().manual_seed(seed + OFFSET)
+    x = torch.randint(-3, 4, (m, k), generator=g).to(dtype).to(DEV)
+    w = torch.randint(-3, 4, (n, k), generator=g).to(dtype).to(DEV)
+    b = torch.randint(-8, 9, (n,), generator=g).to(dtype).to(DEV) if rnd.random() < 0.5 else None
+    if trans:
+        w = w.t().contiguous()
+        want = (x.float() @ w.float()).to(dtype)
+        want = want if b is None else (want.float() + b.float()).to(dtype)
+    else:
+        want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)
+    with switch_env(MOJO_HIP_GEMM_TILE128=force):
+        got = dense_gemm(x, w, b, trans)
+        form = last_launch()
+    assert torch.equal(got, want), (form, m, k, n, trans, force)
+    if force in ("1", "128", "256"):
+        assert form.startswith("gemm128:"), form
+    if force == "0":
+        assert not form.startswith("gemm128:"), form
+
+
 @pytest.mark.parametrize("seed", range(20))
 def test_fuzz_quant_gemm_int8_exact(seed):
     from test_hip_quant_gemm import _quantize, quant_gemm_formula
     rnd = random.Random(5000 + seed + OFFSET)
-    m = rnd.choice([1, 2, 4, 5, 16, 31, 32, 33, 64, 100, 128, 129, 300, 513])
+    m = rnd.choice([1, 2, 4, 5, 16, 31, 32, 33, 64, 100, 128, 129, 300, 513, 700, 1500, 2100])     # (above 128 rows with [N,K] weights: the 128-row tiles too)
     k = rnd.choice([48, 64, 128, 256, 272, 512, 1024, 1536, 4096])
     n = rnd.choice([3, 10, 64, 128, 192, 256, 1000, 4096])
     trans = rnd.random() < 0.5
