@@ -87,10 +87,28 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the
     return o;
   }
   __device__ __forceinline__ void row_begin(int) {}
-  // gemm_tile128_core.h: what the epilogue needs from memory, requested BEFORE the K loop (nothing here)
-  struct Pre {};
-  __device__ __forceinline__ void preload(Pre&, int, int, int, int) const {}
-  __device__ __forceinline__ void store_pre(const Pre&, int, int, int m, int n, int n_limit, f32x4 acc) const { store(m, n, n_limit, acc); }
+  // gemm_tile128_core.h: what the epilogue needs from memory, requested BEFORE the K loop: a lane's sixteen bias values (a
+  // 64 x 64 wave tile: columns n_first + 16 j + e) — fetched in the epilogue they are an exposed memory latency per launch
+  struct Pre { T b[4][4]; };
+  __device__ __forceinline__ void preload(Pre& p, int, int, int n_first, int n_limit) const {
+    if (!bias) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p.b[j][e] = bias[min(n_first + j * 16 + e, n_limit - 1)];
+  }
+  __device__ __forceinline__ void store_pre(const Pre& p, int, int j, int m, int n, int n_limit, f32x4 acc) const {
+    typedef typename vec_of<T, 4>::type V4;
+    V4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = bias ? round_with_bias<T>(acc[e], p.b[j][e], bias_fused) : static_cast<T>(acc[e]);
+    T* dst = C + static_cast<int64_t>(m) * ldc + n;
+    if (n + 4 <= n_limit) {
+      *reinterpret_cast<V4*>(dst) = o;
+    } else {
+      for (int e = 0; e < 4 && n + e < n_limit; ++e) dst[e] = o[e];
+    }
+  }
   __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
     typedef typename vec_of<T, 4>::type V4;
     V4 o;
