@@ -76,7 +76,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, lds_char* dst_wave_base
 template <typename T>
 struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the golden's `x @ w + b`), or round_T(acc + bias) (its F.linear)
   static constexpr bool kRowStaged = sizeof(T) == 2;   // may go through the wave-private LDS transpose (see the kernel's epilogue)
-  static constexpr bool kLdsScales = false;
+  // 256 x 256 kernel, row-staged epilogue WITH a bias: every thread of the second half of the workgroup fetches one of the tile's
+  // 256 bias values before the K loop and parks it in LDS (EpilogueDequant's mechanism, below).  Until round 5 a bias sent the
+  // tile through the direct 8-byte stores with the bias fetched in the epilogue: + 18-25 % on a prefill-sized projection with a
+  // bias (8192 x 4096 x 6144: 281 -> 332 us), + 59 % at K 1024.
+  static constexpr bool kLdsScales = sizeof(T) == 2;
+  __host__ __device__ __forceinline__ bool lds_values() const { return bias != nullptr; }   // (no bias: the epilogue as before)
+  __device__ __forceinline__ float scale_for_thread(int t, int, int, int n0, int n_limit) const {
+    return (bias && t >= 256) ? static_cast<float>(bias[min(n0 + t - 256, n_limit - 1)]) : 0.f;
+  }
+  __device__ __forceinline__ typename vec_of<T, 4>::type to4_scaled(f32x4 acc, float, f32x4 col) const {
+    typename vec_of<T, 4>::type o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = round_with_bias<T>(acc[e], static_cast<T>(col[e]), bias_fused);   // (a 16-bit value through fp32: exact)
+    return o;
+  }
   typedef T out_t;
   T* C; int64_t ldc; const T* bias; bool bias_fused = false;
   __host__ __device__ __forceinline__ bool has_bias() const { return bias != nullptr; }
@@ -131,6 +145,7 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the
 struct EpilogueF32 {         // C (fp32) = acc, or C += acc: two-pass products (x @ w_hi, then + x @ w_lo) of the MoE router
   static constexpr bool kRowStaged = false;
   static constexpr bool kLdsScales = false;
+  __host__ __device__ __forceinline__ bool lds_values() const { return false; }
   float* C; int64_t ldc; int accumulate;
   __device__ __forceinline__ void row_begin(int) {}
   __device__ __forceinline__ void store(int m, int n, int n_limit, f32x4 acc) const {
@@ -153,6 +168,7 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
   // inside the epilogue they were an exposed memory latency per tile: 3.4 % of the M 4096 x 7168 x 36864 product, 9 % at K 4096
   // (scripts/probes/quant_headline_scales.py: the same kernel with constants in place of the fetches).
   static constexpr bool kLdsScales = sizeof(TO) == 2;
+  __host__ __device__ __forceinline__ bool lds_values() const { return true; }
   typedef TO out_t;
   TO* C; int64_t ldc; const float* row_scale; const bf16_t* col_scale;
   float rs;
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   locate(bid);
   float pre_scale = 0.f;                            // (EpilogueDequant: see kLdsScales)
   if constexpr (Epi::kLdsScales && !PERSIST) {
-    if (a.stage_rows) pre_scale = epi.scale_for_thread(threadIdx.x, m0, m_end, n0, a.N);
+    if (a.stage_rows && epi.lds_values()) pre_scale = epi.scale_for_thread(threadIdx.x, m0, m_end, n0, a.N);
   }
 
   // stage half-tile `which` (0:A0 1:A1 2:W0 3:W1) of K-tile kt (relative to this slice) into buffer buf
@@ -775,10 +791,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     // are free behind the barrier) and stores 64-byte row pieces, 16 bytes per lane: 16 instructions.  LDS image: row
     // stride 128 B, 8-byte slot s of row r at s ^ (((r >> 1) & 3) << 2) (2-way = minimal conflicts for the writes,
     // 16-byte pairs stay together for the reads).
-    if (a.stage_rows && n0 + BN <= a.N && !epi.has_bias()) {
+    bool lds_vals = false;                                 // the epilogue's per-row / per-column values come from LDS (uniform)
+    if constexpr (Epi::kLdsScales && !PERSIST) lds_vals = epi.lds_values();
+    if (a.stage_rows && n0 + BN <= a.N && (!epi.has_bias() || lds_vals)) {
       typedef __attribute__((address_space(3))) float lds_float;
-      lds_float* scales = reinterpret_cast<lds_float*>(smem + LDS_BYTES);     // [256 row scales | 256 column scales], kLdsScales only
-      if constexpr (Epi::kLdsScales && !PERSIST) scales[threadIdx.x] = pre_scale;
+      lds_float* scales = reinterpret_cast<lds_float*>(smem + LDS_BYTES);     // [256 row values | 256 column values], kLdsScales only
+      if constexpr (Epi::kLdsScales && !PERSIST) {
+        if (lds_vals) scales[threadIdx.x] = pre_scale;
+      }
       __builtin_amdgcn_s_barrier();                        // every wave is done with the tile buffers (and its DMA has landed)
       lds_char* reg = smem + wave * 16384;
       typedef typename Epi::out_t OT;
@@ -787,24 +807,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
       const int l15 = lane & 15, g4 = lane >> 4;
       f32x4 col_scale_v[4];                               // (read once: behind the staging stores below the compiler would re-read them per row tile)
       if constexpr (Epi::kLdsScales && !PERSIST) {
+        if (lds_vals) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          col_scale_v[nt] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(scales + 256 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4);
+          for (int nt = 0; nt < 4; ++nt)
+            col_scale_v[nt] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(scales + 256 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4);
+        }
       }
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) {
         const int row = (mt >> 2) * 64 + (mt & 3) * 16 + l15;
         const int sw = ((row >> 1) & 3) << 2;
         float row_scale_v = 0.f;
-        if constexpr (Epi::kLdsScales && !PERSIST) row_scale_v = scales[(mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15];
-        else epi.row_begin(min(m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15, m_end - 1));   // rows past the group: staged, never stored
+        if constexpr (Epi::kLdsScales && !PERSIST) {
+          if (lds_vals) row_scale_v = scales[(mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15];
+        }
+        if (!lds_vals) epi.row_begin(min(m0 + (mt >> 2) * 128 + wm * 64 + (mt & 3) * 16 + l15, m_end - 1));   // rows past the group: staged, never stored
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           V4 o;
-          if constexpr (Epi::kLdsScales && !PERSIST)
-            o = epi.to4_scaled(acc[mt][nt], row_scale_v, col_scale_v[nt]);
-          else
-            o = epi.to4(n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4, acc[mt][nt]);
+          bool done = false;
+          if constexpr (Epi::kLdsScales && !PERSIST) {
+            if (lds_vals) { o = epi.to4_scaled(acc[mt][nt], row_scale_v, col_scale_v[nt]); done = true; }
+          }
+          if (!done) o = epi.to4(n0 + (nt >> 1) * 128 + wn * 32 + (nt & 1) * 16 + g4 * 4, acc[mt][nt]);
           const int slot = ((nt >> 1) * 8 + (nt & 1) * 4 + g4) ^ sw;
           *reinterpret_cast<__attribute__((address_space(3))) V4*>(reg + row * 128 + slot * 8) = o;
         }

@@ -163,3 +163,39 @@ def test_gemm_swiglu_prefill_rows_take_the_fused_tiles_and_give_the_unfused_bits
     err = (fused.float() - want.float()).abs()
     assert bool((err <= 2.0 ** -5 * want.float().abs() + 2.0 ** -5).all())
     assert float(err.mean()) <= 0.01 * float(want.float().abs().mean())
+
+
+@pytest.mark.parametrize("layout", ["NK", "KN"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n", [(2048, 512, 2048), (4096, 1024, 1536), (1000, 256, 4096)])
+def test_gemm_with_bias_leaves_through_the_row_staged_epilogue_with_the_direct_stores_bits(m, k, n, dtype, layout):
+    """Chip-filling products WITH a bias on the 256 x 256 kernel: the row-staged epilogue now takes the bias from LDS (fetched
+    before the K loop) instead of sending the tile through the direct 8-byte stores.  A/B against MOJO_HIP_GEMM_STAGE_ROWS=0
+    (direct stores, bias fetched in the epilogue), both forms asserted: the same bits; small-integer data: equal to the golden's
+    rounding exactly (`F.linear`: one rounding; `x @ w + b`: two)."""
+    from hip_utils import switch_env
+    from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
+    torch.manual_seed(m + n)
+    trans = layout == "KN"
+    x = torch.randint(-4, 5, (m, k)).to(dtype).to(DEV)
+    w = torch.randint(-4, 5, (n, k)).to(dtype).to(DEV)
+    b = torch.randint(-8, 9, (n,)).to(dtype).to(DEV)
+    if trans:
+        w = w.t().contiguous()
+        want = ((x.float() @ w.float()).to(dtype).float() + b.float()).to(dtype)
+    else:
+        want = torch.nn.functional.linear(x.float(), w.float(), b.float()).to(dtype)
+    with switch_env(MOJO_HIP_GEMM_TILE128="0"):
+        staged = dense_gemm(x, w, b, trans)
+        assert last_launch().startswith("gemm256:staged"), last_launch()
+        with switch_env(MOJO_HIP_GEMM_STAGE_ROWS="0"):
+            direct = dense_gemm(x, w, b, trans)
+            assert last_launch().startswith("gemm256:direct"), last_launch()
+        xr = torch.randn(m, k, device=DEV).to(dtype)
+        br = torch.randn(n, device=DEV).to(dtype)
+        wr = (torch.randn(k, n, device=DEV) * 0.05).to(dtype) if trans else (torch.randn(n, k, device=DEV) * 0.05).to(dtype)
+        staged_r = dense_gemm(xr, wr, br, trans)
+        with switch_env(MOJO_HIP_GEMM_STAGE_ROWS="0"):
+            direct_r = dense_gemm(xr, wr, br, trans)
+    assert torch.equal(staged, want) and torch.equal(direct, want)
+    assert torch.equal(staged_r, direct_r)
