@@ -67,7 +67,6 @@ constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 1
 // SIMD: a 64 x 128 wave tile would need the accumulators in AGPRs, and hipcc then shuttles fragments through them); S = ring stages
 template <typename P, typename Epi, int NWN, int S, bool W_NMAJOR /* true: W is [K,N] (n contiguous); false: [N,K] */>
 __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi epi) {
-  static_assert(P::EB == 2 || !W_NMAJOR, "[K,N] weights: 16-bit elements only");
   typedef typename P::acc_t acc_t;
   constexpr int EB = P::EB;
   constexpr int BK = KT_BYTES / EB;
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   // columns (l % 2) * 8 .. + 8.  u = 0, 1 enumerates this wave's (half-tile, k-block) pairs.
   constexpr int NW = 2 * NWN, NH = BN / 128, KBW = 8 / NW;       // waves, half-tiles, k-blocks per wave and half-tile
   static_assert(NH * KBW == 2, "two (half-tile, k-block) pairs per wave");
-  if constexpr (W_NMAJOR) {
+  if constexpr (W_NMAJOR && EB == 2) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int hh = NH == 2 ? u : 0, kb = NH == 2 ? wave : wave * 2 + u;
@@ -151,7 +150,21 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
       w2_off[u] = (n_b - n_a) * 2;
     }
   }
-  const int64_t w_step = W_NMAJOR ? static_cast<int64_t>(BK) * a.w_k * 2 : KT_BYTES;
+  // 1-byte [K,N] weights: gemm256_core.h's image of a 128 k x 128 n half-tile — [k / 8][n / 16][8 k][16 n], 128-byte blocks, block
+  // (kb, nb) in slot nb ^ (kb / 2 % 2) of its k-block — read back by ds_read_b64_tr_b8.  16 k-blocks per half-tile; a wave
+  // fills four (half-tile, k-block) pairs u = 0 .. 3 with one request each (8 k-rows x 128 columns): lane l -> row l % 8,
+  // slot l / 8.
+  if constexpr (W_NMAJOR && EB == 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int hh = NH == 2 ? (u >> 1) : 0, kb = NH == 2 ? wave * 2 + (u & 1) : wave * 4 + u;
+      const int nb = (lane >> 3) ^ ((kb >> 1) & 1);
+      int n = n0 + hh * 128 + nb * 16;
+      if (n > a.N - 16) n = a.N - 16;                              // partial n-tile: stay inside the row (those columns are never stored)
+      srcW[u] = static_cast<const char*>(a.W) + static_cast<int64_t>(kb * 8 + (lane & 7)) * a.w_k + n;
+    }
+  }
+  const int64_t w_step = W_NMAJOR ? static_cast<int64_t>(BK) * a.w_k * EB : KT_BYTES;
   auto stage_piece = [&](int kt, int slot, int p) {  // LDS-DMA request p of the wave's PIECES for K-tile kt (p is a constant after unrolling)
     lds_char* dst = smem + slot * STAGE_BYTES;
     if (p < 2 * AB) {
@@ -159,10 +172,14 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
     } else if constexpr (!W_NMAJOR) {
       const int h = p - 2 * AB;
       glds16(srcW[h] + static_cast<int64_t>(kt) * KT_BYTES, dst + TILE_A_BYTES + (WB * wave) * 2048 + h * 1024);
-    } else {
+    } else if constexpr (EB == 2) {
       const int u = (p - 2 * AB) >> 1, second = (p - 2 * AB) & 1;
       const int hh = NH == 2 ? u : 0, kb = NH == 2 ? wave : wave * 2 + u;
       glds16(srcW[u] + kt * w_step + (second ? w2_off[u] : 0), dst + TILE_A_BYTES + hh * 16384 + kb * 2048 + second * 1024);
+    } else {
+      const int u = p - 2 * AB;
+      const int hh = NH == 2 ? (u >> 1) : 0, kb = NH == 2 ? wave * 2 + (u & 1) : wave * 4 + u;
+      glds16(srcW[u] + kt * w_step, dst + TILE_A_BYTES + hh * 16384 + kb * 1024);
     }
   };
   auto stage = [&](int kt, int slot) {               // all PIECES of a stage (prologue)
@@ -194,16 +211,25 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   struct WBuf { frag32 f[WN]; i32x2 r[16]; };        // [N,K]: f;  [K,N]: r[j * 4 + ks * 2 + (k rows 0-3 | 4-7)]
   const unsigned smem_u32 = static_cast<unsigned>(reinterpret_cast<size_t>(smem));
   unsigned tr_lane[2];
-  {
+  if constexpr (EB == 2) {
     const int grp = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
     const unsigned base = TILE_A_BYTES + (wn >> 1) * 16384 + ((wn & 1) * 4) * 256 + grp * 2048 + pp * 8;
     tr_lane[0] = base + (qq + ((grp & 1) ? 4 : 0)) * 32;          // k rows 0-3 of the block
     tr_lane[1] = base + (qq + ((grp & 1) ? 0 : 4)) * 32;          // k rows 4-7
+  } else {   // 1-byte: block (kb, nb) at kb * 1024 + (nb ^ (kb / 2 % 2)) * 128, kb = ks * 8 + 2 * (lane / 16) + half; lane 2q + p -> row q, cols 8p
+    const int grp = lane >> 4, qq = (lane & 15) >> 1, pp = lane & 1;
+    const unsigned base = TILE_A_BYTES + (wn >> 1) * 16384 + ((wn & 1) * 4) * 128 + grp * 2048 + qq * 16 + pp * 8;
+    tr_lane[0] = base + ((0 ^ (grp & 1)) * 128);                  // column tiles 0 and 2 (+ 256)
+    tr_lane[1] = base + ((1 ^ (grp & 1)) * 128);                  // column tiles 1 and 3 (+ 256)
   }
 #define T128_TR4(R, A0, A1, O0, O1)                                                                                   \
   asm volatile("ds_read_b64_tr_b16 %0, %4 offset:" #O0 "\n\tds_read_b64_tr_b16 %1, %5 offset:" #O0                     \
                "\n\tds_read_b64_tr_b16 %2, %4 offset:" #O1 "\n\tds_read_b64_tr_b16 %3, %5 offset:" #O1                 \
                : "=&v"((R)[0]), "=&v"((R)[1]), "=&v"((R)[2]), "=&v"((R)[3]) : "v"(A0), "v"(A1) : "memory")
+#define T128_TR4B(R, A, O0, O1, O2, O3)                                                                               \
+  asm volatile("ds_read_b64_tr_b8 %0, %4 offset:" #O0 "\n\tds_read_b64_tr_b8 %1, %4 offset:" #O1                       \
+               "\n\tds_read_b64_tr_b8 %2, %4 offset:" #O2 "\n\tds_read_b64_tr_b8 %3, %4 offset:" #O3                   \
+               : "=&v"((R)[0]), "=&v"((R)[1]), "=&v"((R)[2]), "=&v"((R)[3]) : "v"(A) : "memory")
   auto issue_w_tr = [&](WBuf& b, int slot, int j) {  // 16 columns of [K,N] weights: four transposed reads (j is a constant after unrolling)
 #if T128_TR_BUILTIN
     typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -215,13 +241,21 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
 #else
     const unsigned a0 = smem_u32 + slot * STAGE_BYTES + tr_lane[0], a1 = smem_u32 + slot * STAGE_BYTES + tr_lane[1];
     i32x2* r = b.r + j * 4;
-    if (j == 0) T128_TR4(r, a0, a1, 0, 8192);
-    else if (j == 1) T128_TR4(r, a0, a1, 256, 8448);
-    else if (j == 2) T128_TR4(r, a0, a1, 512, 8704);
-    else T128_TR4(r, a0, a1, 768, 8960);
+    if constexpr (EB == 2) {
+      if (j == 0) T128_TR4(r, a0, a1, 0, 8192);
+      else if (j == 1) T128_TR4(r, a0, a1, 256, 8448);
+      else if (j == 2) T128_TR4(r, a0, a1, 512, 8704);
+      else T128_TR4(r, a0, a1, 768, 8960);
+    } else {                                         // r[j * 4 + ks * 2 + (k-block 2 grp | 2 grp + 1)]
+      if (j == 0) T128_TR4B(r, a0, 0, 1024, 8192, 9216);
+      else if (j == 1) T128_TR4B(r, a1, 0, 1024, 8192, 9216);
+      else if (j == 2) T128_TR4B(r, a0, 256, 1280, 8448, 9472);
+      else T128_TR4B(r, a1, 256, 1280, 8448, 9472);
+    }
 #endif
   };
 #undef T128_TR4
+#undef T128_TR4B
   auto retire_w_tr = [&](WBuf& b) {                  // behind an lgkmcnt(0): the registers are defined from here on
 #if !T128_TR_BUILTIN
     asm volatile("" : "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]), "+v"(b.r[4]), "+v"(b.r[5]), "+v"(b.r[6]), "+v"(b.r[7]));
@@ -350,8 +384,11 @@ inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipS
   constexpr int BN = NWN * 64, LDS = S * (TILE_A_BYTES + BN * KT_BYTES);
   const int64_t tiles = ceil_div(m_total, BM) * ceil_div(a.N, BN);
   MOJO_REQUIRE(tiles < (1LL << 31), MOJO_EUNSUPPORTED, "gemm(128-row tiles): grid too large");
-  if constexpr (P::EB == 2) {
-    if (a.w_n == 1) {                                 // [K,N] (16-bit elements only)
+  // [K,N] weights: 16-bit and int8.  (fp8: its MFMA is inline asm with the accumulator tied in place, the kernel then sits at
+  // 256 registers with spills, and hipcc splits the live ranges of the transposed reads' destinations — copies them while
+  // the reads are in flight: scripts/check_async_lds_reads.py flags 30 such moves.  Not instantiated; the 256 x 256 kernel runs it.)
+  if constexpr (P::EB == 2 || P::KS == 2) {
+    if (a.w_n == 1) {                                 // [K,N]
       auto* fn = gemm128_kernel<P, Epi, NWN, S, true>;
       static std::atomic<uint64_t> attr_set{0};
       if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

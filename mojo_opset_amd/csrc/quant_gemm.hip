@@ -498,15 +498,19 @@ static int quant_splitk(int64_t m, int k, int n) {
 // it).  Measured, both kernels forced in one process, 80 shapes per dtype (profiles/r5_quant_tile128_ab.txt): M 1024 x 4096 x 4096
 // int8 39 -> 19 us, M 512 x 2048 x 7168 48 -> 12 us; over the grid the rule is 63 % faster (geometric mean) than the 256 x 256
 // kernel alone and within 0.7 % of always picking the faster form.
-static bool quant_tile128_ok(int64_t m, const GemmArgs& a, int out_elt_bytes) {
-  return m > 128 && a.w_k == 1 && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.w_n % 16 == 0 && a.ldc % 4 == 0 &&
+static bool quant_tile128_ok(int64_t m, const GemmArgs& a, int out_elt_bytes, bool fp8) {
+  const bool layout = (a.w_k == 1 && a.w_n % 16 == 0) ||                                      // [N,K] (trans_weight)
+                      (!fp8 && a.w_n == 1 && a.w_k % 16 == 0 && a.N % 16 == 0 && a.N >= 16);    // [K,N], int8: transposed byte reads
+  return m > 128 && layout && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldc % 4 == 0 &&
          aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 4 * out_elt_bytes);
 }
-static bool quant_prefers_tile128(int64_t m, int k, int n) {
+static bool quant_prefers_tile128(int64_t m, int k, int n, bool w_nmajor) {
   const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 128;
   double t128;
-  if (narrow <= 256) t128 = 5.0 + nkt * (0.30 + 0.125 * narrow / 256.0);
-  else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + 0.47 * wide / 256.0);
+  // ([K,N], int8: the transposed byte reads cost more than the 16-bit ones — 0.58-0.66 us per K-tile of a 128 x 128 tile
+  // against 0.30-0.43 for [N,K]; profiles/r5_quant_tile128_ab_kn.txt)
+  if (narrow <= 256) t128 = 5.0 + nkt * (w_nmajor ? 0.58 + 0.08 * narrow / 256.0 : 0.30 + 0.125 * narrow / 256.0);
+  else if (wide <= 256) t128 = 6.0 + nkt * (w_nmajor ? 0.90 + 0.25 * wide / 256.0 : 0.34 + 0.47 * wide / 256.0);
   else return false;
   const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), sk = quant_splitk(m, k, n);
   const double t256 = static_cast<double>(ceil_div(tiles * sk, 256)) * (static_cast<double>(nkt) / sk) * 1.06 + 10.0 +
@@ -522,9 +526,9 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
     return fp8 ? launch_quant_gemv<TO, true>(a, rs, cs, m, s) : launch_quant_gemv<TO, false>(a, rs, cs, m, s);
   if (quant_skinny_ok(m, a) && (gemm_skinny_mask() & SKINNY_UNIFORM))
     return fp8 ? launch_quant_skinny<TO, true>(a, rs, cs, m, slab_ws, s) : launch_quant_skinny<TO, false>(a, rs, cs, m, slab_ws, s);
-  if (quant_tile128_ok(m, a, sizeof(TO))) {
+  if (quant_tile128_ok(m, a, sizeof(TO), fp8)) {
     const int f = g128::forced_choice();
-    if (f < 0 ? quant_prefers_tile128(m, a.K, a.N) : f == 1) {
+    if (f < 0 ? quant_prefers_tile128(m, a.K, a.N, a.w_n == 1) : f == 1) {
       if (fp8) {
         g256::EpilogueDequant<TO, f32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f, true};
         return g128::launch<g256::PolF8>(a, epi, m, s);

@@ -7,12 +7,14 @@ from mojo_opset_amd import switches
 from mojo_opset_amd.backends.hip import lib as L
 from mojo_opset_amd.backends.hip.operators.gemm import HIPQuantGemm
 dev = torch.device("cuda", 0)
+KN = len(sys.argv) > 1 and sys.argv[1] == "KN"            # the operator's default (K, N) weight layout (int8 only on the 128-row tiles)
 shapes = ((4096, 4096), (7168, 4096), (7168, 1536), (4096, 6144), (18432, 7168), (2048, 7168), (1024, 8192), (8192, 8192))
 ms = (192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096)
-for qd in (torch.int8, torch.float8_e4m3fn):
+for qd in ((torch.int8,) if KN else (torch.int8, torch.float8_e4m3fn)):
     for k, n in shapes:
-        op = HIPQuantGemm(k, n, output_dtype=torch.bfloat16, trans_weight=True, quant_dtype=qd, weight_dtype=qd, device=dev)
-        op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=dev) if qd == torch.int8 else torch.randn(n, k, device=dev).to(qd))
+        op = HIPQuantGemm(k, n, output_dtype=torch.bfloat16, trans_weight=not KN, quant_dtype=qd, weight_dtype=qd, device=dev)
+        w_nk = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=dev) if qd == torch.int8 else torch.randn(n, k, device=dev).to(qd)
+        op.weight.copy_(w_nk.t() if KN else w_nk)
         op.weight_scale.fill_(0.01)
         row = {}
         for m in ms:

@@ -255,37 +255,43 @@ def test_quant_gemm_split_k_route_is_deterministic_and_exact(quant_dtype, monkey
 @pytest.mark.parametrize("odt", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("m,k,n", [(129, 128, 128), (300, 384, 520), (1024, 7168, 1536), (513, 1024, 4104), (2048, 512, 2304)])
 @pytest.mark.parametrize("shape", ["128", "256"])
-def test_quant_gemm_tile128_equals_the_256_tile_kernel_and_the_integer_formula(m, k, n, odt, quant_dtype, shape, monkeypatch):
+@pytest.mark.parametrize("trans_weight", [True, False])
+def test_quant_gemm_tile128_equals_the_256_tile_kernel_and_the_integer_formula(m, k, n, odt, quant_dtype, shape, trans_weight, monkeypatch):
     """Mid-size M with `[N,K]` weights (`trans_weight=True`): the 128-row-tile kernel (csrc/gemm_tile128_core.h; both tile
     widths forced in turn) against the unsplit 256 x 256 kernel — int32 accumulation is exact, and the fp8 products are summed by
     the same instruction in the same order, so the outputs must be the same bits; int8 also equals the integer formula exactly.
     Ragged M and N, one and odd K-tile counts."""
     torch.manual_seed(m + n)
-    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=odt, trans_weight=True, quant_dtype=quant_dtype, weight_dtype=quant_dtype, device=DEV)
+    if not trans_weight:
+        if quant_dtype != torch.int8:
+            pytest.skip("(K, N) weights on the 128-row tiles: int8 only (the reference's operator is int8 only; fp8 stays on the 256 x 256 kernel)")
+        n = (n + 15) // 16 * 16                                       # [K, N] rows are read in 16-byte pieces
+    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=odt, trans_weight=trans_weight, quant_dtype=quant_dtype, weight_dtype=quant_dtype, device=DEV)
     if quant_dtype == torch.int8:
-        op.weight.copy_(torch.randint(-127, 128, (n, k), dtype=torch.int8, device=DEV))
+        w_nk = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=DEV)
         x = torch.randint(-127, 128, (m, k), dtype=torch.int8, device=DEV)
     else:
-        op.weight.copy_(torch.randn(n, k, device=DEV).to(quant_dtype))
+        w_nk = torch.randn(n, k, device=DEV).to(quant_dtype)
         x = torch.randn(m, k, device=DEV).to(quant_dtype)
+    op.weight.copy_(w_nk if trans_weight else w_nk.t())               # (N, K) with trans_weight, else the operator's default (K, N)
     op.weight_scale.copy_(torch.rand(n, device=DEV) * 0.02)
     s_in = torch.rand(m, device=DEV)
     monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", shape)
     small = op(x, s_in)
-    assert last_launch() == f"gemm128:128x{shape}:NK", last_launch()
+    assert last_launch() == f"gemm128:128x{shape}:" + ("NK" if trans_weight else "KN"), last_launch()
     monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")
     monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
     large = op(x, s_in)
     assert last_launch().startswith("gemm256:") and ":splitk" not in last_launch(), last_launch()
     assert torch.equal(small, large)
     if quant_dtype == torch.int8:
-        exact = quant_gemm_formula(x.cpu(), op.weight.cpu().t(), s_in.cpu(), op.weight_scale.cpu(), odt)
+        exact = quant_gemm_formula(x.cpu(), w_nk.cpu().t(), s_in.cpu(), op.weight_scale.cpu(), odt)
         torch.testing.assert_close(to_cpu(small), exact, atol=0, rtol=0)
 
 
 def test_quant_gemm_tile128_default_choice():
-    """Taken by default where the time model prefers it (few 256 x 256 tiles, `[N,K]` weights, more than 128 rows); `[K,N]`
-    weights and chip-filling launches stay on the 256 x 256 kernel."""
+    """Taken by default where the time model prefers it (few 256 x 256 tiles, more than 128 rows, either weight layout);
+    chip-filling launches stay on the 256 x 256 kernel."""
     def form(m, k, n, trans):
         op = hip_cls("MojoQuantGemm")(k, n, output_dtype=torch.bfloat16, trans_weight=trans, device=DEV)
         op.weight.copy_(torch.randint(-127, 128, (n, k) if trans else (k, n), dtype=torch.int8, device=DEV))
@@ -294,5 +300,5 @@ def test_quant_gemm_tile128_default_choice():
         return last_launch()
     assert form(1024, 4096, 4096, True) == "gemm128:128x128:NK"
     assert form(2048, 4096, 4096, True) == "gemm128:128x256:NK"
-    assert form(1024, 4096, 4096, False).startswith("gemm256:")
+    assert form(1024, 4096, 4096, False) == "gemm128:128x128:KN"      # the operator's default (K, N) layout
     assert form(8192, 1024, 8192, True).startswith("gemm256:")
