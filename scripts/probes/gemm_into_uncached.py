@@ -10,7 +10,7 @@ from mojo_opset_amd.comm.peer import _DeviceBytes
 dev = torch.device("cuda", 0)
 lib = L.load()
 out = {}
-for m, k, n in ((4096, 3584, 8192), (2048, 3584, 8192), (4096, 1024, 8192), (1024, 3584, 8192)):
+for m, k, n in ((4096, 3584, 8192), (2048, 3584, 8192), (4096, 1024, 8192), (1024, 3584, 8192), (512, 3584, 8192), (512, 1024, 8192), (256, 3584, 8192)):   # (the last rows: the 128-row tiles of gemm_tile128_core.h, 8-byte stores)
     x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
     w = torch.randn(k, n, device=dev, dtype=torch.bfloat16) * 0.02
     nbytes = m * n * 2
@@ -28,6 +28,8 @@ for m, k, n in ((4096, 3584, 8192), (2048, 3584, 8192), (4096, 1024, 8192), (102
                 ref = dst.clone()
             assert torch.equal(dst, ref)
             t = _time(lambda: _ENGINE(x, w, None, True, out=dst), 20, 5)
+            form = L.last_launch()
             rec.setdefault(kind, []).append(round(t * 1e6, 1))
     out[f"{m}x{k}x{n}"] = {a: {"us": min(v), "tflops": round(2.0 * m * k * n / (min(v) * 1e-6) / 1e12)} for a, v in rec.items()}
+    out[f"{m}x{k}x{n}"]["form"] = form
     print(json.dumps({f"{m}x{k}x{n}": out[f"{m}x{k}x{n}"]}), flush=True)
