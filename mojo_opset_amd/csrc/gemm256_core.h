@@ -111,11 +111,15 @@ struct EpiloguePlain {       // C = round_T(acc) (+ bias after the rounding: the
 #pragma unroll
       for (int e = 0; e < 4; ++e) p.b[j][e] = bias[min(n_first + j * 16 + e, n_limit - 1)];
   }
-  __device__ __forceinline__ void store_pre(const Pre& p, int, int j, int m, int n, int n_limit, f32x4 acc) const {
-    typedef typename vec_of<T, 4>::type V4;
-    V4 o;
+  __device__ __forceinline__ typename vec_of<T, 4>::type cvt_pre(const Pre& p, int, int j, f32x4 acc) const {
+    typename vec_of<T, 4>::type o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = bias ? round_with_bias<T>(acc[e], p.b[j][e], bias_fused) : static_cast<T>(acc[e]);
+    return o;
+  }
+  __device__ __forceinline__ void store_pre(const Pre& p, int i, int j, int m, int n, int n_limit, f32x4 acc) const {
+    typedef typename vec_of<T, 4>::type V4;
+    const V4 o = cvt_pre(p, i, j, acc);
     T* dst = C + static_cast<int64_t>(m) * ldc + n;
     if (n + 4 <= n_limit) {
       *reinterpret_cast<V4*>(dst) = o;
@@ -219,8 +223,7 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
 #pragma unroll
       for (int e = 0; e < 4; ++e) p.cs[j][e] = static_cast<float>(col_scale[min(n_first + j * 16 + e, n_limit - 1)]);
   }
-  __device__ __forceinline__ void store_pre(const Pre& p, int i, int j, int m, int n, int n_limit, ACC acc) const {
-    TO* dst = C + static_cast<int64_t>(m) * ldc + n;
+  __device__ __forceinline__ typename vec_of<TO, 4>::type cvt_pre(const Pre& p, int i, int j, ACC acc) const {
     typename vec_of<TO, 4>::type o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -228,6 +231,11 @@ struct EpilogueDequant {     // C = round_TO( float(acc) * row_scale[m] * col_sc
       asm volatile("" : "+v"(v));                          // see store(): the fp32 product is a value of its own
       o[e] = elt<TO>::from_f(v);
     }
+    return o;
+  }
+  __device__ __forceinline__ void store_pre(const Pre& p, int i, int j, int m, int n, int n_limit, ACC acc) const {
+    TO* dst = C + static_cast<int64_t>(m) * ldc + n;
+    const typename vec_of<TO, 4>::type o = cvt_pre(p, i, j, acc);
     if (vec4 && n + 4 <= n_limit) {
       *reinterpret_cast<typename vec_of<TO, 4>::type*>(dst) = o;
     } else {

@@ -361,7 +361,12 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   // destination allocated until the reads have retired.  tests/test_isa_async_reads.py checks the compiled kernels for it.
   if constexpr (W_NMAJOR) { retire_w_tr(w0); retire_w_tr(w1); }
 
-  // ---- epilogue: a lane owns row m = ... + (lane & 15) and 4 consecutive columns of each 16 x 16 tile ----------------------
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------
+  // (Row-staged stores — the wave's 64 x 64 tile transposed through 8 KiB of the free ring and written as whole 128-byte rows,
+  // 8 instructions instead of 16 — were measured and NOT kept: 24.5 / 32.1 us against 24.1 / 32.0 on 128 x 128 tiles at K 4096,
+  // 12.7 against 12.2 at K 1024, 2 % better on the eight-wave shape: the extra barrier and the LDS round trip cost what the
+  // store pattern saves.  DESIGN Appendix A 29.)
+  // direct stores: a lane owns row m = ... + (lane & 15) and 4 consecutive columns of each 16 x 16 tile
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
