@@ -111,10 +111,13 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
 // MOJO_HIP_GEMM_SPLITK=<n> forces the split (1 = off).
 static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelled_us = nullptr) {
   if (modelled_us) *modelled_us = static_cast<double>(ceil_div(ceil_div(m, 256) * ceil_div(n, 256), 256)) * (k / 64) * 1.06;
-  if (m <= 128 || n % 4 != 0 || k % 64 != 0) return 1;
-  const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), nkt = k / 64;
+  // (m <= 128 too: decode-sized rows with [K,N] weights — `x @ w`, the GEMM + collective operators' trans_weight — have no
+  // weight-streaming kernel and ran ONE round of 16-32 workgroups over the whole K: 72 us at 32 x 4096 x 4096 against 14 in the
+  // vendor library, 137 us at K 8192 (profiles/r5_gemm_sweep_vs_lib.txt).  Slices of at least 4 K-tiles there.)
+  if (m < 1 || n % 4 != 0 || k % 64 != 0) return 1;
+  const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), nkt = k / 64, min_slice = m <= 128 ? 4 : 8;
   if (int64_t sk = MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0); sk > 0) {
-    if (sk > nkt / 8) sk = nkt / 8;
+    if (sk > nkt / min_slice) sk = nkt / min_slice;
     return sk < 1 ? 1 : static_cast<int>(sk);
   }
   // time of a split in us, from measurements on this chip: a workgroup's K-tile takes ~1.06 us (68 us for the 64 K-tiles of
@@ -126,7 +129,7 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
   };
   int64_t best = 1;
   double best_cost = cost(1) * 0.9;                     // a split has to gain 10 % before it is worth a second launch
-  for (int64_t sk = 2; sk <= 16 && sk <= nkt / 8; ++sk) {
+  for (int64_t sk = 2; sk <= (m <= 128 ? 32 : 16) && sk <= nkt / min_slice; ++sk) {
     const double c = cost(sk);
     if (c < best_cost * 0.999) { best = sk; best_cost = c; }
   }
@@ -150,6 +153,18 @@ static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n, bool w_n
   double t256 = 0;
   (void)gemm_dense_splitk256(m, k, n, &t256);
   return t128 < 1.2 * t256;
+}
+
+// 65..128 rows with [N,K] weights: the weight-streaming kernel's weak zone (its 128-row form reads the weights at ~3 TB/s: 38 us
+// at 96 x 4096 x 14336, 440 us for a 128-row lm_head 4096 x 128256, against 24 / 231 in the vendor library) — one row of 128-row
+// tiles where the model says so (a lone m-tile: T = ceil(n / 128) tiles of 128 x 128, or rounds of 128 x 256 tiles beyond the chip).
+static bool gemm_rows65_128_prefers_tile128(int64_t m, int64_t k, int64_t n) {
+  if (m <= 64 || m > 128) return false;
+  const int64_t narrow = ceil_div(n, 128), wide = ceil_div(n, 256), nkt = k / 64;
+  const double t128 = narrow <= 256 ? 5.0 + nkt * (0.30 + 0.125 * narrow / 256.0)
+                                    : 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
+  const double t_stream = static_cast<double>(k) * n * 2.0 / 3e6 + 6.0;
+  return t128 < 0.9 * t_stream;
 }
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
@@ -187,6 +202,8 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
   a.row_start = ws; a.tile_start = ws + 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   a.uniform_rows = static_cast<int>(m);
+  if (w_k_stride == 1 && m > 64 && m <= 128 && gemm_tile128_use(a, dtype, m, gemm_rows65_128_prefers_tile128(m, k, n)))
+    return launch_gemm_tile128(a, dtype, m, s);
   if (w_k_stride == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16)) {          // decode-sized, K-major weights: maybe split K
     const int sk = gemm_skinny_splitk(m, k, n, 1);
     if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {

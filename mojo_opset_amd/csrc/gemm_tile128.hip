@@ -12,10 +12,10 @@ bool gemm_tile128_ok(const GemmArgs& a, int dtype) {
          (!a.bias || aligned_to(a.bias, 2));
 }
 
-// Where the 128-row tiles are taken: more than 128 rows (the decode-sized kernels own those) and the caller's time model
+// Where the 128-row tiles are taken: more than 64 rows (the weight-streaming kernels own those) and the caller's time model
 // (gemm_api.hip, gemm_dense_prefers_tile128) says so; MOJO_HIP_GEMM_TILE128 = 1 / 0: wherever they apply / never.
 bool gemm_tile128_use(const GemmArgs& a, int dtype, int64_t m_total, bool model_prefers) {
-  if (!gemm_tile128_ok(a, dtype) || m_total <= 128) return false;
+  if (!gemm_tile128_ok(a, dtype) || m_total <= 64) return false;
   const int f = g128::forced_choice();
   return f < 0 ? model_prefers : f == 1;
 }

@@ -128,3 +128,40 @@ def test_tile128_row_maps_and_strided_operands(shape, layout):
     for b in range(blocks):
         mask[b * 3 * rc + 2 * rc: b * 3 * rc + 3 * rc] = False
     assert not out_full[mask.to(DEV)].any() and not out_full[:, n:].any()      # nothing written outside the mapped rows / N columns
+
+
+@pytest.mark.parametrize("m,k,n,want_form", [(96, 4096, 14336, "gemm128:128x128:NK"),      # one row of 112 tiles beats the 128-row weight stream
+                                             (128, 1024, 33024, "gemm128:128x256:NK"),     # 258 tiles of 128 x 128 -> 128 x 256 tiles
+                                             (100, 8192, 1024, "gemm_skinny"),             # 8 tiles over a long K: the weight stream with its K split
+                                             (64, 4096, 14336, "gemm_skinny")])            # <= 64 rows: never
+def test_rows_65_to_128_take_the_128_row_tiles_where_the_model_says_so(m, k, n, want_form):
+    """65..128 rows with `[N,K]` weights: one row of 128-row tiles where it beats the weight-streaming kernel's 128-row form
+    (gemm_api.hip, gemm_rows65_128_prefers_tile128); integer-exact either way."""
+    torch.manual_seed(m)
+    x = torch.randint(-4, 5, (m, k)).to(torch.bfloat16).to(DEV)
+    w = torch.randint(-4, 5, (n, k)).to(torch.bfloat16).to(DEV)
+    b = torch.randint(-8, 9, (n,)).to(torch.bfloat16).to(DEV)
+    got = dense_gemm(x, w, b, False)
+    assert last_launch().startswith(want_form), last_launch()
+    assert torch.equal(got, F.linear(x.float(), w.float(), b.float()).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 4096, 4096), (32, 8192, 1024), (64, 1024, 8192), (128, 14336, 4096), (100, 4096, 520)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_decode_sized_rows_with_kn_weights_split_k(m, k, n, bias):
+    """Decode-sized rows with `[K,N]` weights (`x @ w`: the GEMM + collective operators with trans_weight) have no weight-streaming
+    kernel; the 256 x 256 kernel now cuts K for them too (it ran one round of a few workgroups over the whole K: 3-11 x the
+    vendor library's time).  Small-integer data: split, unsplit (MOJO_HIP_GEMM_SPLITK=1) and the fp32 reference agree to the bit."""
+    torch.manual_seed(m + n)
+    x = torch.randint(-4, 5, (m, k)).to(torch.bfloat16).to(DEV)
+    w = torch.randint(-4, 5, (k, n)).to(torch.bfloat16).to(DEV)
+    b = torch.randint(-8, 9, (n,)).to(torch.bfloat16).to(DEV) if bias else None
+    want = (x.float() @ w.float()).to(torch.bfloat16)
+    want = want if b is None else (want.float() + b.float()).to(torch.bfloat16)
+    with switch_env(MOJO_HIP_GEMM_TILE128="0"):
+        got = dense_gemm(x, w, b, True)
+        assert ":splitk" in last_launch(), last_launch()
+        with switch_env(MOJO_HIP_GEMM_SPLITK="1"):
+            unsplit = dense_gemm(x, w, b, True)
+            assert last_launch().startswith("gemm256:") and ":splitk" not in last_launch(), last_launch()
+    assert torch.equal(got, want) and torch.equal(unsplit, want)
