@@ -501,7 +501,7 @@ static int quant_splitk(int64_t m, int k, int n) {
 static bool quant_tile128_ok(int64_t m, const GemmArgs& a, int out_elt_bytes, bool fp8) {
   const bool layout = (a.w_k == 1 && a.w_n % 16 == 0) ||                                      // [N,K] (trans_weight)
                       (!fp8 && a.w_n == 1 && a.w_k % 16 == 0 && a.N % 16 == 0 && a.N >= 16);    // [K,N], int8: transposed byte reads
-  return m > 128 && layout && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldc % 4 == 0 &&
+  return m > 64 && layout && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldc % 4 == 0 &&   // (<= 128 rows with [N,K] weights never get here: the weight-streaming kernel)
          aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 4 * out_elt_bytes);
 }
 static bool quant_prefers_tile128(int64_t m, int k, int n, bool w_nmajor) {
