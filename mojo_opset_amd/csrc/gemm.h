@@ -119,6 +119,8 @@ bool gemm_mfma256_ok(const GemmArgs& a, int dtype);
 
 // 128 x 128 tiles for one dense 16-bit product with [N,K] weights that under-fills the 256 x 256 kernel (gemm_tile128.hip)
 bool gemm_tile128_ok(const GemmArgs& a, int dtype);
+bool gemm_tile128_group_ok(const GemmArgs& a, int dtype);      // any number of groups (prefix arrays for 128-row tiles)
+int gemm_tile128_forced();                                       // MOJO_HIP_GEMM_TILE128: 0 never, 1 always, -1 the caller's model
 bool gemm_tile128_use(const GemmArgs& a, int dtype, int64_t m_total, bool model_prefers);   // MOJO_HIP_GEMM_TILE128: 1 / 0 override the model
 int launch_gemm_tile128(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);
 

@@ -1,6 +1,8 @@
 // C ABI of the grouped and dense GEMM entry points: argument checks, kernel choice, prefix launch (ragged groups only).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "gemm.h"
 
 namespace mojo {
@@ -52,16 +54,36 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + (num_groups + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!group_list) {
-    a.uniform_rows = static_cast<int>(m_total / num_groups);
-  } else {
-    const int bm = gemm_skinny_ragged_ok(a, dtype, m_total) ? 64 : (gemm_mfma256_ok(a, dtype) ? 256 : 64);   // the tile height run_gemm's choice walks
+  if (!group_list) a.uniform_rows = static_cast<int>(m_total / num_groups);
+  // 128-row tiles (gemm_tile128_core.h) for grouped products the 256 x 256 kernel under-fills or pads: few small experts
+  // (8 groups of 2048 x 1408: 48 tiles of 256 x 256, 45 us where the weights stream in 8), or 65-250 rows per group (a
+  // 256-row tile per group is mostly padding).  The row counts live on the device: the model works on the mean.
+  bool use128 = false;
+  if (num_groups > 1 && gemm_tile128_group_ok(a, dtype) &&
+      !(group_list ? gemm_skinny_ragged_ok(a, dtype, m_total) : gemm_skinny_ok(a, dtype))) {
+    const int f = gemm_tile128_forced();
+    if (f >= 0) {
+      use128 = f == 1;
+    } else {
+      const int64_t rows = std::max<int64_t>(1, m_total / num_groups), nkt = k / 64;
+      const int64_t t256 = num_groups * ceil_div(rows, 256) * ceil_div(n, 256);
+      const int64_t t128n = num_groups * ceil_div(rows, 128) * ceil_div(n, 128), t128w = num_groups * ceil_div(rows, 128) * ceil_div(n, 256);
+      // (constants fitted on scripts/probes/group_gemm_sweep.py, both kernels forced, 116 grouped products:
+      // profiles/r5_group_gemm_sweep.txt — within 0.9 % of always picking the faster one, 15 % ahead of the 256 x 256 kernel alone)
+      const double c256 = static_cast<double>(ceil_div(t256, 256)) * nkt * (t256 <= 128 ? 1.2 : 1.45);
+      const double c128 = t128n <= 256 ? 5.0 + nkt * (0.30 + 0.125 * t128n / 256.0) : 6.0 + nkt * 1.0 * std::max(1.0, t128w / 256.0);
+      use128 = c128 < c256;
+    }
+  }
+  if (group_list) {
+    const int bm = use128 ? 128 : gemm_skinny_ragged_ok(a, dtype, m_total) ? 64 : (gemm_mfma256_ok(a, dtype) ? 256 : 64);   // the tile height the chosen kernel walks
     GemmTail tail;
     const int64_t elt = dtype == MOJO_F32 ? 4 : 2;
     if (!c_map) { tail.C = out; tail.ld_bytes = ldc * elt; tail.row_bytes = n * elt; }
     int rc = launch_group_prefix(group_list, group_list_is_i64, a.G, bm, m_total, ws, ws + (num_groups + 1), s, tail);
     if (rc) return rc;
   }
+  if (use128) return launch_gemm_tile128(a, dtype, m_total, s);
   return run_gemm(a, dtype, m_total, s);
 }
 

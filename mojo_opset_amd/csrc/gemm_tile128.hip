@@ -3,14 +3,18 @@
 
 namespace mojo {
 
-// One dense product (G = 1), 16-bit, whole K-tiles, unsplit; [N,K] weights or [K,N] weights with N a multiple of 8.
-bool gemm_tile128_ok(const GemmArgs& a, int dtype) {
+// 16-bit products, whole K-tiles, unsplit; [N,K] weights or [K,N] weights with N a multiple of 8; any number of groups (ragged
+// groups: the caller builds the prefix arrays for 128-row tiles).
+bool gemm_tile128_group_ok(const GemmArgs& a, int dtype) {
   if (dtype != MOJO_BF16 && dtype != MOJO_F16) return false;
   const bool layout = (a.w_k == 1 && a.w_n % 8 == 0) || (a.w_n == 1 && a.w_k % 8 == 0 && a.N % 8 == 0 && a.N >= 8);
-  return a.G == 1 && a.uniform_rows > 0 && layout && a.K >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.ldc % 4 == 0 &&
+  return a.G >= 1 && layout && (a.G == 1 || a.w_group % 8 == 0) && a.K >= 64 && a.K % 64 == 0 && a.lda % 8 == 0 && a.ldc % 4 == 0 &&
          a.splitk == 1 && !a.glu && a.a_k_wrap == 0 && aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 8) &&
          (!a.bias || aligned_to(a.bias, 2));
 }
+// One dense product (G = 1).
+bool gemm_tile128_ok(const GemmArgs& a, int dtype) { return a.G == 1 && a.uniform_rows > 0 && gemm_tile128_group_ok(a, dtype); }
+int gemm_tile128_forced() { return g128::forced_choice(); }      // MOJO_HIP_GEMM_TILE128: 0 never, 1 always, -1 the caller's model
 
 // Where the 128-row tiles are taken: more than 64 rows (the weight-streaming kernels own those) and the caller's time model
 // (gemm_api.hip, gemm_dense_prefers_tile128) says so; MOJO_HIP_GEMM_TILE128 = 1 / 0: wherever they apply / never.
@@ -21,7 +25,7 @@ bool gemm_tile128_use(const GemmArgs& a, int dtype, int64_t m_total, bool model_
 }
 
 int launch_gemm_tile128(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s) {
-  MOJO_REQUIRE(gemm_tile128_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm(128-row tiles): preconditions not met");
+  MOJO_REQUIRE(gemm_tile128_group_ok(a, dtype), MOJO_EUNSUPPORTED, "gemm(128-row tiles): preconditions not met");
   if (dtype == MOJO_BF16) {
     g256::EpiloguePlain<bf16_t> epi{static_cast<bf16_t*>(a.C), a.ldc, static_cast<const bf16_t*>(a.bias), a.bias_fused != 0};
     return g128::launch<g256::PolBF16>(a, epi, m_total, s);

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   lds_char* smem = (lds_char*)smem_generic;
 
   const int n_tiles = (a.N + BN - 1) / BN;
-  const int m_tiles = (a.uniform_rows + BM - 1) / BM;
+  const int m_tiles = gemm_m_tiles(a, BM);           // (ragged groups: the prefix arrays were built for 128-row tiles)
   const int total = m_tiles * n_tiles;
   const int bid = blockIdx.x;
   if (bid >= total) return;
@@ -103,7 +103,10 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
       ni = full_panels * PANEL + (t - mi * rem);
     }
   }
-  const int m0 = mi * BM, m_end = a.uniform_rows, n0 = ni * BN;
+  int grp_i, m0, m_end;                              // group, first row and end row (exclusive) of this m-tile
+  gemm_locate_tile(a, mi, BM, grp_i, m0, m_end);
+  const int n0 = ni * BN;
+  const char* const W_g = static_cast<const char*>(a.W) + static_cast<int64_t>(grp_i) * a.w_group * EB;
   const int nkt = a.K / BK;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
       if constexpr (!W_NMAJOR) {
         int n = n0 + (WB * wave + (h >> 1)) * 16 + r;
         if (n >= a.N) n = a.N - 1;
-        srcW[h] = static_cast<const char*>(a.W) + static_cast<int64_t>(n) * a.w_n * EB + chunk * 16;
+        srcW[h] = W_g + static_cast<int64_t>(n) * a.w_n * EB + chunk * 16;
       }
     }
   }
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
       const int n = n0 + hh * 128 + (lane >> 4) * 16 + (lane & 1) * 8;
       const int n_a = n > a.N - 8 ? a.N - 8 : n;                   // partial n-tile: stay inside the row (those columns are never stored)
       const int n_b = n + 64 > a.N - 8 ? a.N - 8 : n + 64;
-      srcW[u] = static_cast<const char*>(a.W) + (static_cast<int64_t>(kb * 8 + rr) * a.w_k + n_a) * 2;
+      srcW[u] = W_g + (static_cast<int64_t>(kb * 8 + rr) * a.w_k + n_a) * 2;
       w2_off[u] = (n_b - n_a) * 2;
     }
   }
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
       const int nb = (lane >> 3) ^ ((kb >> 1) & 1);
       int n = n0 + hh * 128 + nb * 16;
       if (n > a.N - 16) n = a.N - 16;                              // partial n-tile: stay inside the row (those columns are never stored)
-      srcW[u] = static_cast<const char*>(a.W) + static_cast<int64_t>(kb * 8 + (lane & 7)) * a.w_k + n;
+      srcW[u] = W_g + static_cast<int64_t>(kb * 8 + (lane & 7)) * a.w_k + n;
     }
   }
   const int64_t w_step = W_NMAJOR ? static_cast<int64_t>(BK) * a.w_k * EB : KT_BYTES;
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
 template <typename P, typename Epi, int NWN, int S>
 inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
   constexpr int BN = NWN * 64, LDS = S * (TILE_A_BYTES + BN * KT_BYTES);
-  const int64_t tiles = ceil_div(m_total, BM) * ceil_div(a.N, BN);
+  const int64_t tiles = (a.uniform_rows > 0 ? static_cast<int64_t>(a.G) * ceil_div(a.uniform_rows, BM) : ceil_div(m_total, BM) + a.G) * ceil_div(a.N, BN);   // (ragged: an upper bound; surplus workgroups exit)
   MOJO_REQUIRE(tiles < (1LL << 31), MOJO_EUNSUPPORTED, "gemm(128-row tiles): grid too large");
   // [K,N] weights: 16-bit and int8.  (fp8: its MFMA is inline asm with the accumulator tied in place, the kernel then sits at
   // 256 registers with spills, and hipcc splits the live ranges of the transposed reads' destinations — copies them while
@@ -419,7 +422,7 @@ inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipS
 template <typename P, typename Epi>
 inline int launch(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
   const long long f = MOJO_SWITCH("MOJO_HIP_GEMM_TILE128", -1);
-  const bool wide = f == 256 || (f != 128 && ceil_div(m_total, BM) * ceil_div(a.N, 128) > g256::device_cu_count());
+  const bool wide = f == 256 || (f != 128 && (ceil_div(m_total, BM) + (a.uniform_rows > 0 ? 0 : a.G / 2)) * ceil_div(a.N, 128) > g256::device_cu_count());
   return wide ? launch_shape<P, Epi, 4, 3>(a, epi, m_total, s) : launch_shape<P, Epi, 2, 4>(a, epi, m_total, s);
 }
 

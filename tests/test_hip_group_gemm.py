@@ -217,6 +217,7 @@ def test_group_gemm_row_staged_epilogue_is_bit_identical_to_direct_stores(trans,
     w = (torch.randn(groups, n, k, generator=g) if trans else torch.randn(groups, k, n, generator=g)).to(dtype).to(DEV)
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
     op = hip_cls("MojoGroupGemm")(w, trans)
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")             # (these small shapes would otherwise take the 128-row tiles)
     staged = op(x, cnt)
     assert last_launch().startswith("gemm256:staged"), last_launch()
     monkeypatch.setenv("MOJO_HIP_GEMM_STAGE_ROWS", "0")          # (the fixture makes the library re-read its switches)
@@ -247,3 +248,44 @@ def test_group_gemm_four_wave_experiment_is_bit_identical(counts, k, n, monkeypa
     monkeypatch.setenv("MOJO_HIP_GEMM_W128", "1")
     four = op(x, cnt)
     assert torch.equal(shipped, four)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", ["128", "256"])
+@pytest.mark.parametrize("counts,k,n", [([300, 0, 17, 1000, 255, 1], 512, 768), ([128] * 8, 2048, 1408), ([65, 200, 0, 129, 90, 256, 1, 130], 1408, 2048),
+                                        ([513, 7], 448, 264 + 248), ([100] * 64, 256, 520)])
+def test_group_gemm_128_row_tiles_equal_the_256_tile_kernel_and_the_integers(trans, dtype, shape, counts, k, n, monkeypatch):
+    """Ragged groups on the 128-row tiles (gemm_tile128_core.h; both tile widths forced): prefix arrays for 128-row tiles, the
+    group's weight matrix per m-tile, rows past a group never stored.  Small-integer data: equal to the fp32 reference and to
+    the 256 x 256 kernel, element for element; empty groups, one-row groups, groups that end inside a tile."""
+    g = torch.Generator().manual_seed(5)
+    groups = len(counts)
+    x = torch.randint(-3, 4, (sum(counts), k), generator=g).to(dtype).to(DEV)
+    w = (torch.randint(-3, 4, (groups, n, k), generator=g) if trans else torch.randint(-3, 4, (groups, k, n), generator=g)).to(dtype).to(DEV)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    op = hip_cls("MojoGroupGemm")(w, trans)
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", shape)
+    small = op(x, cnt)
+    assert last_launch() == f"gemm128:128x{shape}:" + ("NK" if trans else "KN"), last_launch()
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")
+    monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", "0")              # (and not the ragged weight-streaming kernel)
+    large = op(x, cnt)
+    assert last_launch().startswith("gemm256:"), last_launch()
+    assert torch.equal(small, large)
+    want = torch_cls("MojoGroupGemm")(w.float().cpu(), trans)(x.float().cpu(), cnt.cpu()).to(dtype)
+    assert torch.equal(to_cpu(small)[: sum(counts)].float(), want.float())
+
+
+def test_group_gemm_128_row_tiles_default_choice():
+    """Taken by default where the time model (on the mean rows per group) prefers them: few small experts, groups of about a hundred rows;
+    not for Mixtral-sized groups, not where the ragged weight-streaming kernel applies."""
+    def form(counts, k, n, trans):
+        w = torch.randn((len(counts), n, k) if trans else (len(counts), k, n), dtype=torch.bfloat16, device=DEV)
+        x = torch.randn(sum(counts), k, dtype=torch.bfloat16, device=DEV)
+        hip_cls("MojoGroupGemm")(w, trans)(x, torch.tensor(counts, dtype=torch.int32, device=DEV))
+        return last_launch()
+    assert form([128] * 8, 2048, 1408, False).startswith("gemm128:")
+    assert form([100] * 64, 1408, 2048, True).startswith("gemm128:")
+    assert form([2048] * 8, 4096, 14336, False).startswith("gemm256:")
+    assert form([16] * 64, 2048, 1408, True).startswith("gemm_skinny:ragged")
