@@ -184,7 +184,9 @@ int mojo_hip_group_gemm(const void* input, const void* weight, void* out, const 
  *      GroupGemm -> SwiGLU -> GroupGemm): weight [G, 2*inter, K] (trans_weight) or [G, K, 2*inter], columns [gate | up];
  *      out [m_total, inter] = round(round(silu(round(gate))) * round(up)) — the roundings of the two-op golden path — so
  *      the [m_total, 2*inter] product never goes to HBM.  bf16 / fp16, inter % 128 == 0 and the 256x256 MFMA kernel's
- *      layout preconditions; MOJO_EUNSUPPORTED otherwise (callers fall back to group_gemm + swiglu_rows).               */
+ *      layout preconditions; MOJO_EUNSUPPORTED otherwise — and where the library's time model prefers the unfused route (the
+ *      product on 128-row tiles: few small experts, groups of about a hundred rows) — callers fall back to group_gemm +
+ *      swiglu_rows (same bits).                                                                                         */
 int mojo_hip_group_gemm_swiglu(const void* input, const void* weight, void* out, const void* group_list,
                                int group_list_is_i64, int64_t m_total, int64_t k, int64_t inter,
                                int64_t num_groups, int trans_weight, int dtype, void* workspace,

@@ -26,6 +26,18 @@ extern "C" int64_t mojo_hip_group_gemm_workspace_bytes(int64_t num_groups) {
   return (2 * (num_groups + 1)) * static_cast<int64_t>(sizeof(int32_t)) + 64;
 }
 
+// 128-row tiles or the 256 x 256 kernel for a grouped product?  The row counts live on the device: a model on the MEAN rows per
+// group (constants fitted on scripts/probes/group_gemm_sweep.py, both kernels forced, 116 grouped products:
+// profiles/r5_group_gemm_sweep.txt — within 0.9 % of always picking the faster one, 15 % ahead of the 256 x 256 kernel alone).
+static bool group_prefers_tile128(int64_t m_total, int64_t k, int64_t n, int64_t num_groups) {
+  const int64_t rows = std::max<int64_t>(1, m_total / num_groups), nkt = k / 64;
+  const int64_t t256 = num_groups * ceil_div(rows, 256) * ceil_div(n, 256);
+  const int64_t t128n = num_groups * ceil_div(rows, 128) * ceil_div(n, 128), t128w = num_groups * ceil_div(rows, 128) * ceil_div(n, 256);
+  const double c256 = static_cast<double>(ceil_div(t256, 256)) * nkt * (t256 <= 128 ? 1.2 : 1.45);
+  const double c128 = t128n <= 256 ? 5.0 + nkt * (0.30 + 0.125 * t128n / 256.0) : 6.0 + nkt * 1.0 * std::max(1.0, t128w / 256.0);
+  return c128 < c256;
+}
+
 extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight, void* out, const void* group_list,
                                            int group_list_is_i64, int64_t m_total, int64_t k, int64_t n,
                                            int64_t num_groups, int64_t lda, int64_t ldc, int64_t w_group_stride,
@@ -62,18 +74,7 @@ extern "C" int mojo_hip_group_gemm_strided(const void* input, const void* weight
   if (num_groups > 1 && gemm_tile128_group_ok(a, dtype) &&
       !(group_list ? gemm_skinny_ragged_ok(a, dtype, m_total) : gemm_skinny_ok(a, dtype))) {
     const int f = gemm_tile128_forced();
-    if (f >= 0) {
-      use128 = f == 1;
-    } else {
-      const int64_t rows = std::max<int64_t>(1, m_total / num_groups), nkt = k / 64;
-      const int64_t t256 = num_groups * ceil_div(rows, 256) * ceil_div(n, 256);
-      const int64_t t128n = num_groups * ceil_div(rows, 128) * ceil_div(n, 128), t128w = num_groups * ceil_div(rows, 128) * ceil_div(n, 256);
-      // (constants fitted on scripts/probes/group_gemm_sweep.py, both kernels forced, 116 grouped products:
-      // profiles/r5_group_gemm_sweep.txt — within 0.9 % of always picking the faster one, 15 % ahead of the 256 x 256 kernel alone)
-      const double c256 = static_cast<double>(ceil_div(t256, 256)) * nkt * (t256 <= 128 ? 1.2 : 1.45);
-      const double c128 = t128n <= 256 ? 5.0 + nkt * (0.30 + 0.125 * t128n / 256.0) : 6.0 + nkt * 1.0 * std::max(1.0, t128w / 256.0);
-      use128 = c128 < c256;
-    }
+    use128 = f >= 0 ? f == 1 : group_prefers_tile128(m_total, k, n, num_groups);
   }
   if (group_list) {
     const int bm = use128 ? 128 : gemm_skinny_ragged_ok(a, dtype, m_total) ? 64 : (gemm_mfma256_ok(a, dtype) ? 256 : 64);   // the tile height the chosen kernel walks
@@ -116,6 +117,17 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
   a.glu = 1;
   MOJO_REQUIRE(gemm_mfma256_glu_ok(a, dtype), MOJO_EUNSUPPORTED,
                "group_gemm_swiglu: needs the 256x256 MFMA kernel's layout and an intermediate size that is a multiple of 128");
+  {  // few small experts / groups of about a hundred rows: the product on the 128-row tiles + mojo_hip_swiglu_rows beats the fused
+     // 256 x 256 tiles (8 experts of 2048 x 2816: 38 us fused against ~20); the documented fallback of this entry point
+    GemmArgs p = a;
+    p.glu = 0;
+    const int f = gemm_tile128_forced();
+    const int64_t rows = std::max<int64_t>(1, m_total / num_groups);
+    const bool one_round = num_groups * ceil_div(rows, 128) * ceil_div(n, 128) <= 256;   // (beyond one round of 128 x 128 tiles the fused
+    if (gemm_tile128_group_ok(p, dtype) && !gemm_skinny_ragged_ok(p, dtype, m_total) &&   //  tiles win back what the product alone loses:
+        (f >= 0 ? f == 1 : (one_round && group_prefers_tile128(m_total, k, n, num_groups))))   //  8 x 300 rows of 2048 x 2816: 81 us fused, 101 not)
+      MOJO_REQUIRE(false, MOJO_EUNSUPPORTED, "group_gemm_swiglu: the unfused route (group_gemm on 128-row tiles + swiglu_rows) is faster for this shape");
+  }
   int32_t* ws = static_cast<int32_t*>(workspace);
   a.row_start = ws; a.tile_start = ws + (num_groups + 1);
   hipStream_t s = static_cast<hipStream_t>(stream);

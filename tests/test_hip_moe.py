@@ -215,6 +215,7 @@ def test_experts_fused_swiglu_epilogue_is_bit_identical_to_the_two_kernel_path(e
     cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
     act = torch.empty(x.shape[0], inter, dtype=dtype, device=DEV)
     monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", str(31 & ~2))     # (no ragged streaming form: a decode-sized case would otherwise take it)
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")             # (nor the 128-row tiles, for which the fused entry point defers to the two-kernel path)
     assert op._fused_up_swiglu(x, op.up_proj_weight.detach(), cnt, act, inter)
     fused = op(x, cnt)
     monkeypatch.setenv("MOJO_HIP_EXPERTS_FUSED", "0")
@@ -223,7 +224,10 @@ def test_experts_fused_swiglu_epilogue_is_bit_identical_to_the_two_kernel_path(e
     assert torch.equal(fused, plain)
     monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY")
     monkeypatch.delenv("MOJO_HIP_EXPERTS_FUSED")
-    assert torch.equal(op(x, cnt), fused)                        # whatever the library picks by itself: the same bits
+    monkeypatch.delenv("MOJO_HIP_GEMM_TILE128")
+    assert torch.equal(op(x, cnt), fused)                        # whatever the library picks by itself (128-row tiles included): the same bits
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "1")
+    assert torch.equal(op(x, cnt), fused)                        # ... and with the 128-row tiles forced
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -234,7 +238,7 @@ def test_experts_fused_swiglu_epilogue_is_bit_identical_to_the_two_kernel_path(e
 def test_experts_streaming_form_for_ragged_decode_groups_is_bit_identical(experts, hidden, inter, counts, dtype, monkeypatch):
     """At most 64 rows per expert on average (a decode step): both projections run the 64-row streaming grouped GEMM on
     ragged groups (gemm_skinny_kernel<.., RAGGED>) — empty groups, groups of more than 64 rows (several blocks), a group
-    that ends on a block boundary; same bits as the 256-row tile kernel, and against the oracle."""
+    that ends on a block boundary; same bits as the tile kernels (256 or 128 rows, whichever the library picks), and against the oracle."""
     torch.manual_seed(3)
     if counts is None:
         counts = torch.randint(0, 17, (experts,)).tolist()
@@ -253,7 +257,7 @@ def test_experts_streaming_form_for_ragged_decode_groups_is_bit_identical(expert
     monkeypatch.setenv("MOJO_HIP_GEMM_SKINNY", str(31 & ~2))     # every decode-sized form but the ragged one
     tiled = op(x, cnt)
     hist = launches_of(lambda: op(x, cnt))
-    assert "gemm_skinny:ragged" not in hist and ("gemm256:" in hist or "gemm_generic" in hist), hist   # the OTHER kernels really ran
+    assert "gemm_skinny:ragged" not in hist and ("gemm256:" in hist or "gemm128:" in hist or "gemm_generic" in hist), hist   # the OTHER kernels really ran
     assert torch.equal(streamed, tiled)
     monkeypatch.delenv("MOJO_HIP_GEMM_SKINNY")
     op.forward_diff_with(ref, x, cnt, mixed_tol=True, ref_device="cpu")
