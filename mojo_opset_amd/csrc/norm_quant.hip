@@ -61,18 +61,22 @@ __device__ __forceinline__ float round_quotient(float y, float scale, float inv_
   return r;
 }
 
-template <typename T, int VEC, int CACHE, bool NT = false /* stream_nt(): activations by-pass the caches */>
+// TPR = threads per row: 256 (a row per workgroup) or 64 (a row per WAVE, four rows per workgroup, no LDS and no barrier:
+// dynamic quant only — the row maximum is exact in any order, a sum of squares is not).  Many short rows on a workgroup each
+// cost ~2 ns of workgroup turnover per row (32 768 rows x 2048: 70 us for 200 MB; x 128: 54 us for 13 MB).
+template <typename T, int VEC, int CACHE, bool NT = false /* stream_nt(): activations by-pass the caches */, int TPR = 256>
 __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
   typedef typename vec_of<T, VEC>::type V;
   __shared__ float red[4];
   const int n_vec = a.dim / VEC;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x % TPR;
+  constexpr int RPB = 256 / TPR;                     // rows per workgroup at a time
   const T* hidden = static_cast<const T*>(a.hidden);
   const T* residual = static_cast<const T*>(a.residual);
   T* out_sum = static_cast<T*>(a.out_sum);
   unsigned char* out_q = static_cast<unsigned char*>(a.out_q);
 
-  for (int64_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
+  for (int64_t row = static_cast<int64_t>(blockIdx.x) * RPB + threadIdx.x / TPR; row < a.rows; row += static_cast<int64_t>(gridDim.x) * RPB) {
     const int64_t base = row * a.dim;
     // y of element (v, j); `from_cache` rows only ever take the first branch
     float y[CACHE][VEC];
@@ -96,11 +100,11 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     {
       V xr[CACHE];
 #pragma unroll
-      for (int c = 0; c < CACHE; ++c) xr[c] = NT ? load_vec_nt<T, VEC>(hidden + base + min(tid + c * 256, n_vec - 1) * VEC) : load_vec<T, VEC>(hidden + base + min(tid + c * 256, n_vec - 1) * VEC);
+      for (int c = 0; c < CACHE; ++c) xr[c] = NT ? load_vec_nt<T, VEC>(hidden + base + min(tid + c * TPR, n_vec - 1) * VEC) : load_vec<T, VEC>(hidden + base + min(tid + c * TPR, n_vec - 1) * VEC);
       if (residual) {
         V rr[CACHE];
 #pragma unroll
-        for (int c = 0; c < CACHE; ++c) rr[c] = NT ? load_vec_nt<T, VEC>(residual + base + min(tid + c * 256, n_vec - 1) * VEC) : load_vec<T, VEC>(residual + base + min(tid + c * 256, n_vec - 1) * VEC);
+        for (int c = 0; c < CACHE; ++c) rr[c] = NT ? load_vec_nt<T, VEC>(residual + base + min(tid + c * TPR, n_vec - 1) * VEC) : load_vec<T, VEC>(residual + base + min(tid + c * TPR, n_vec - 1) * VEC);
 #pragma unroll
         for (int c = 0; c < CACHE; ++c)
 #pragma unroll
@@ -110,11 +114,11 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
       if (out_sum) {
 #pragma unroll
         for (int c = 0; c < CACHE; ++c)
-          if (tid + c * 256 < n_vec) { if (NT) store_vec_nt<T, VEC>(out_sum + base + (tid + c * 256) * VEC, xr[c]); else store_vec<T, VEC>(out_sum + base + (tid + c * 256) * VEC, xr[c]); }
+          if (tid + c * TPR < n_vec) { if (NT) store_vec_nt<T, VEC>(out_sum + base + (tid + c * TPR) * VEC, xr[c]); else store_vec<T, VEC>(out_sum + base + (tid + c * TPR) * VEC, xr[c]); }
       }
 #pragma unroll
       for (int c = 0; c < CACHE; ++c) {
-        const bool live = tid + c * 256 < n_vec;
+        const bool live = tid + c * TPR < n_vec;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           y[c][j] = live ? elt<T>::to_f(vget<T, VEC>(xr[c], j)) : 0.f;           // clamped duplicates count as zeros
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
         }
       }
     }
-    for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
+    for (int v = tid + CACHE * TPR; v < n_vec; v += TPR) {
       float f[VEC];
       const V x = load_sum(v, f);
       if (out_sum) { if (NT) store_vec_nt<T, VEC>(out_sum + base + v * VEC, x); else store_vec<T, VEC>(out_sum + base + v * VEC, x); }
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     if (a.weight) {
       float w[CACHE][VEC];
 #pragma unroll
-      for (int c = 0; c < CACHE; ++c) load_f32(a.weight, min(tid + c * 256, n_vec - 1), w[c]);
+      for (int c = 0; c < CACHE; ++c) load_f32(a.weight, min(tid + c * TPR, n_vec - 1), w[c]);
 #pragma unroll
       for (int c = 0; c < CACHE; ++c)
 #pragma unroll
@@ -181,16 +185,16 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
       if (a.out_normed) {
 #pragma unroll
         for (int c = 0; c < CACHE; ++c)
-          if (tid + c * 256 < n_vec) {
+          if (tid + c * TPR < n_vec) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) a.out_normed[base + (tid + c * 256) * VEC + j] = y[c][j];
+            for (int j = 0; j < VEC; ++j) a.out_normed[base + (tid + c * TPR) * VEC + j] = y[c][j];
           }
       }
     }
     if (a.smooth) {
       float sm[CACHE][VEC];
 #pragma unroll
-      for (int c = 0; c < CACHE; ++c) load_f32(a.smooth, min(tid + c * 256, n_vec - 1), sm[c]);
+      for (int c = 0; c < CACHE; ++c) load_f32(a.smooth, min(tid + c * TPR, n_vec - 1), sm[c]);
 #pragma unroll
       for (int c = 0; c < CACHE; ++c)
 #pragma unroll
@@ -198,22 +202,27 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < CACHE; ++c) {
-      if (tid + c * 256 < n_vec) {
+      if (tid + c * TPR < n_vec) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(y[c][j]));
       }
     }
-    for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
+    for (int v = tid + CACHE * TPR; v < n_vec; v += TPR) {
       float f[VEC];
       load_sum(v, f);
       finish(v, f);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) amax = fmaxf(amax, fabsf(f[j]));
     }
-    amax = block_max256(amax, red);
+    if constexpr (TPR == 256) {
+      amax = block_max256(amax, red);
+    } else {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    }
     float scale = __fdiv_rn(fmaxf(amax, 1e-12f), a.q_max);
     if (a.tiny_scale_is_one && scale < 1e-6f) scale = 1.0f;
-    if (threadIdx.x == 0) a.out_scale[row] = scale;
+    if (tid == 0) a.out_scale[row] = scale;
     const float inv_scale = __fdiv_rn(1.0f, scale);
     // ---- pass 3: quantise ------------------------------------------------------------------------------------------
     auto emit = [&](int v, const float (&f)[VEC]) {
@@ -256,10 +265,10 @@ __global__ __launch_bounds__(256) void norm_quant_kernel(NormQuantArgs a) {
     };
 #pragma unroll
     for (int c = 0; c < CACHE; ++c) {
-      const int v = threadIdx.x + c * 256;
+      const int v = tid + c * TPR;
       if (v < n_vec) emit(v, y[c]);
     }
-    for (int v = threadIdx.x + CACHE * 256; v < n_vec; v += 256) {
+    for (int v = tid + CACHE * TPR; v < n_vec; v += TPR) {
       float f[VEC];
       load_sum(v, f);
       // (the stored normed tensor was written in pass 2; write it again is harmless but wasteful: skip it)
@@ -284,6 +293,16 @@ static int launch_norm_quant(const NormQuantArgs& a, hipStream_t s) {
                     (!a.weight || aligned_to(a.weight, 16)) && (!a.smooth || aligned_to(a.smooth, 16));
   int64_t blocks = a.rows > 256 * 32 ? 256 * 32 : a.rows;
   const long long moved = a.rows * static_cast<long long>(a.dim) * (static_cast<long long>(sizeof(T)) * (1 + (a.residual ? 1 : 0) + (a.out_sum ? 1 : 0)) + 1);
+  // a row per wave: dynamic quant (no normalisation: no sum of squares) of many rows that fit one wave's registers
+  if (wide && !a.weight && a.dim / WIDE <= 4 * 64 && a.rows >= 2048) {
+    blocks = ceil_div(a.rows, 4);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (stream_nt(moved)) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4, true, 64>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4, false, 64>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
+    MOJO_CHECK_LAUNCH("norm_quant");
+    note_launch("norm_quant:row_per_wave");
+    return MOJO_OK;
+  }
   if (wide && stream_nt(moved)) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4, true>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
   else if (wide) hipLaunchKernelGGL((norm_quant_kernel<T, WIDE, 4>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((norm_quant_kernel<T, 1, 8>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, a);
