@@ -860,6 +860,40 @@ def bench_dense_mid_m(device):
             rec = _mfma(t, 2.0 * m * k * n)
             rec.update({"kernel_form": form, "hipblaslt_same_box_us": t_lib * 1e6, "time_vs_hipblaslt": t / t_lib})
             out[f"dense_{m}x{k}x{n}_{layout}"] = rec
+    # the fall-offs the round-5 sweep against the vendor library found (scripts/probes/gemm_sweep_vs_lib.py): decode-sized rows with
+    # [K,N] weights (`x @ w`: the GEMM + collective operators' trans_weight), 65-128 rows (a 128-row lm_head), a bias on a
+    # chip-filling product
+    for m, k, n, layout, bias in ((32, 4096, 4096, "KN", False), (64, 8192, 1024, "KN", False), (128, 4096, 128256, "NK", False),
+                                  (96, 4096, 14336, "NK", False), (8192, 4096, 6144, "NK", True)):
+        name = f"dense_{m}x{k}x{n}_{layout}" + ("_bias" if bias else "")
+        if not _want(name):
+            continue
+        x = torch.randn(m, k, device=device, dtype=dt)
+        w = torch.randn(n, k, device=device, dtype=dt) * 0.02
+        w = w if layout == "NK" else w.t().contiguous()
+        b = torch.randn(n, device=device, dtype=dt) if bias else None
+        trans = layout == "KN"
+        reps = 10 if m * k * n < 2 ** 36 else 3
+        t = _time_graph(lambda: dense_gemm(x, w, b, trans), reps=reps)
+        form = _L.last_launch()
+        if trans:
+            t_lib = _time_graph((lambda: x @ w) if b is None else (lambda: torch.addmm(b, x, w)), reps=reps)
+        else:
+            t_lib = _time_graph(lambda: torch.nn.functional.linear(x, w, b), reps=reps)
+        rec = _mfma(t, 2.0 * m * k * n)
+        rec.update({"kernel_form": form, "hipblaslt_same_box_us": t_lib * 1e6, "time_vs_hipblaslt": t / t_lib})
+        out[name] = rec
+        del x, w
+    # few small experts (8 x 2048 -> 1408, 128 rows each): the grouped product on the 128-row tiles
+    if _want("group_8x128_2048x1408_KN"):
+        gw = torch.randn(8, 2048, 1408, device=device, dtype=dt) * 0.02
+        gx = torch.randn(8 * 128, 2048, device=device, dtype=dt)
+        gl = torch.full((8,), 128, dtype=torch.int32, device=device)
+        gop = hip("MojoGroupGemm")(gw, False)
+        t = _time_graph(lambda: gop(gx, gl), reps=10)
+        rec = _mfma(t, 2.0 * 1024 * 2048 * 1408)
+        rec["kernel_form"] = _L.last_launch()
+        out["group_8x128_2048x1408_KN"] = rec
     for qd, tag in ((torch.int8, "int8"), (torch.float8_e4m3fn, "fp8_e4m3")):
         for m, k, n in ((512, 4096, 4096), (1024, 4096, 4096), (1024, 7168, 4096), (2048, 7168, 1536)):
             if not _want(f"quant_{tag}_{m}x{k}x{n}_NK"):
