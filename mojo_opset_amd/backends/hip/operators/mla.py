@@ -204,13 +204,16 @@ def _prefill_decompressed(op, query, ckv_cache, kpe_cache, cu_q_lens, block_tabl
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if groups > 1 else None
     identity = None
+    no_tail = L.ints4(0, 0, 0, 1)                            # an (identity) output row map: the GEMM entry point then leaves the rows past
+    #                                                          the slice's key count alone (nobody reads them; zeroing them cost 223 ms
+    #                                                          for a 920 MB tail before round 5, and would still be a wasted GB of writes)
 
     def decompress(g, on):
         # kv[t, g*cols_g + j] = sum_k ckv[t, k] * kv_b_proj[g*cols_g + j, k]: one group whose row count is the slice's
         # device-side number of keys, so rows past it are never computed
         L.check(lib.mojo_hip_group_gemm_strided(
             L.ptr(ckv_flat), L.c_void_p(proj.data_ptr() + g * cols_g * r * es), L.c_void_p(kv.data_ptr() + g * cols_g * es),
-            L.ptr(count), 0, cap, r, cols_g, 1, r, kv_cols, 0, 1, r, identity, identity, L.dtype_code(dt),
+            L.ptr(count), 0, cap, r, cols_g, 1, r, kv_cols, 0, 1, r, identity, no_tail, L.dtype_code(dt),
             L.ptr(wss[g]), wss[g].numel(), L.c_void_p(on.cuda_stream)), "hip mla decompression")
 
     for b0 in range(0, batch, seqs_per_slice):

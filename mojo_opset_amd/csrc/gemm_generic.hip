@@ -7,9 +7,48 @@ namespace mojo {
 
 // One 256-thread block: exclusive prefix sums of the per-group row counts (row_start) and of the per-group
 // tile counts (tile_start).  Counts are clamped so that no row beyond m_total is ever addressed.
+// Rows behind the last group (sum(counts) < m_total) belong to no product: the golden does not return them
+// (core/operators/gemm.py:111-117 concatenates the groups), the caller's [m_total, N] buffer reads as zeros there.  The GEMM
+// launch never touches these rows, so no ordering issue.  Workgroups 1 .. gridDim.x - 1 do this: each sums the counts itself and
+// zeroes its share of the tail, 16 bytes per lane where the row allows.  (Until round 5 the ONE prefix workgroup zeroed the tail
+// two bytes at a time — "normally there are none" — and a padded buffer cost milliseconds: the second slice of an MLA prefill
+// batch, 920 MB of tail, 223 ms.)
+template <typename IdxT>
+__device__ void zero_group_tail(const IdxT* counts, int G, long long m_total, GemmTail tail) {
+  __shared__ long long part[256];
+  long long sum = 0;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const long long c = static_cast<long long>(counts[g]);
+    sum += c > 0 ? c : 0;
+  }
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  const long long e = part[0] > m_total ? m_total : part[0];
+  if (e >= m_total) return;
+  char* base = static_cast<char*>(tail.C);
+  const long long workers = static_cast<long long>(gridDim.x - 1) * 256, me = static_cast<long long>(blockIdx.x - 1) * 256 + threadIdx.x;
+  const bool wide = (reinterpret_cast<uintptr_t>(base) & 15) == 0 && tail.ld_bytes % 16 == 0;
+  const long long vec_per_row = wide ? tail.row_bytes / 16 : 0, rest = (tail.row_bytes - vec_per_row * 16) / 2;
+  const long long per_row = vec_per_row + rest;
+  for (long long i = me; i < (m_total - e) * per_row; i += workers) {
+    const long long r = e + i / per_row, c = i % per_row;
+    char* row = base + r * tail.ld_bytes;
+    if (c < vec_per_row) *reinterpret_cast<i32x4*>(row + c * 16) = i32x4{0, 0, 0, 0};
+    else *reinterpret_cast<uint16_t*>(row + vec_per_row * 16 + (c - vec_per_row) * 2) = 0;
+  }
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void prefix_kernel(const IdxT* counts, int G, int bm, long long m_total,
                                                      int32_t* row_start, int32_t* tile_start, GemmTail tail) {
+  if (blockIdx.x > 0) {                              // (only launched with a tail to look after)
+    zero_group_tail(counts, G, m_total, tail);
+    return;
+  }
   __shared__ long long s_rows[256];
   __shared__ long long s_tiles[256];
   __shared__ long long carry[2];
@@ -62,25 +101,23 @@ __global__ __launch_bounds__(256) void prefix_kernel(const IdxT* counts, int G, 
     row_start[G] = static_cast<int32_t>(e);
     tile_start[G] = static_cast<int32_t>(carry[1]);
   }
-  // Rows behind the last group (sum(counts) < m_total) belong to no product: the golden does not return them
-  // (core/operators/gemm.py:111-117 concatenates the groups), the caller's [m_total, N] buffer reads as zeros there.
-  // Normally there are none and this loop does not run; the GEMM launch never touches these rows, so no ordering issue.
-  if (tail.C && e < m_total) {
-    const long long halves = tail.row_bytes >> 1;
-    for (long long i = tid; i < (m_total - e) * halves; i += 256) {
-      const long long r = e + i / halves, c = i % halves;
-      *reinterpret_cast<uint16_t*>(static_cast<char*>(tail.C) + r * tail.ld_bytes + c * 2) = 0;
-    }
-  }
 }
 
 int launch_group_prefix(const void* counts, int counts_are_i64, int G, int bm, int64_t m_total, int32_t* row_start,
                         int32_t* tile_start, hipStream_t s, GemmTail tail) {
+  // workgroup 0: the prefix arrays; the others: the tail's zeros, one per 256 KiB of the whole buffer (they exit at once when
+  // the counts add up to m_total)
+  int64_t zero_blocks = 0;
+  if (tail.C) {
+    zero_blocks = ceil_div(m_total * tail.row_bytes, 256 << 10);
+    zero_blocks = zero_blocks < 1 ? 1 : zero_blocks > 1024 ? 1024 : zero_blocks;
+  }
+  const dim3 grid(static_cast<unsigned>(1 + zero_blocks));
   if (counts_are_i64)
-    hipLaunchKernelGGL(prefix_kernel<int64_t>, dim3(1), dim3(256), 0, s, static_cast<const int64_t*>(counts), G, bm,
+    hipLaunchKernelGGL(prefix_kernel<int64_t>, grid, dim3(256), 0, s, static_cast<const int64_t*>(counts), G, bm,
                        static_cast<long long>(m_total), row_start, tile_start, tail);
   else
-    hipLaunchKernelGGL(prefix_kernel<int32_t>, dim3(1), dim3(256), 0, s, static_cast<const int32_t*>(counts), G, bm,
+    hipLaunchKernelGGL(prefix_kernel<int32_t>, grid, dim3(256), 0, s, static_cast<const int32_t*>(counts), G, bm,
                        static_cast<long long>(m_total), row_start, tile_start, tail);
   MOJO_CHECK_LAUNCH("group_prefix");
   return MOJO_OK;
