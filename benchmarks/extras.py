@@ -310,6 +310,20 @@ def bench_prefill(device):
         flops = sum(4.0 * hq * d * (a * b - a * a / 2.0) for a, b in zip(q_lens, kv))
         t = _time(lambda: op(q, k, v, cu_q, table, cu_total_seq_lens=cu_kv, max_q_len=max(q_lens), max_total_seq_len=max(kv)))
         out[name] = _mfma(t, flops)
+        if len(set(q_lens)) == 1 and not any(cached):
+            # calibration: torch's own scaled_dot_product_attention on the same box (the flash kernel of the PyTorch-ROCm wheel,
+            # contiguous [B, H, S, D] tensors, enable_gqa) — what a user gets without this backend
+            try:
+                import torch.nn.functional as F
+                b_, s_ = len(q_lens), q_lens[0]
+                qs = torch.randn(b_, hq, s_, d, device=device, dtype=torch.bfloat16)
+                ks = torch.randn(b_, hkv, s_, d, device=device, dtype=torch.bfloat16)
+                vs = torch.randn(b_, hkv, s_, d, device=device, dtype=torch.bfloat16)
+                t_lib = _time(lambda: F.scaled_dot_product_attention(qs, ks, vs, is_causal=True, enable_gqa=True), 5, 2)
+                out[name].update({"torch_sdpa_same_box_us": t_lib * 1e6, "time_vs_torch_sdpa": t / t_lib})
+                del qs, ks, vs
+            except Exception as e:   # an SDPA build without this path must not cost the record
+                out[name]["torch_sdpa_same_box_us"] = repr(e)[:80]
     return out
 
 
