@@ -200,6 +200,19 @@ def bench_quant_gemm(device):
             if m <= 128:                                   # decode-sized M: the weight stream is the roofline
                 tg = _time_graph(lambda: op(x, s))
                 res = {"us_eager": t * 1e6, **_hbm(tg, k * n + m * k + m * n * 2)}
+            if m >= 1024:
+                # calibration: the vendor library's 8-bit product on the same box in the same run — torch._int_mm (int32 out, NO
+                # dequantising epilogue) / torch._scaled_mm (fp8, unit scales, bf16 out), both hipBLASLt
+                try:
+                    wl = op.weight
+                    if qd == torch.int8:
+                        t_lib = _time_graph(lambda: torch._int_mm(x, wl.t()), reps=3, replays=3)
+                    else:
+                        one = torch.ones((), device=device)
+                        t_lib = _time_graph(lambda: torch._scaled_mm(x, wl.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16), reps=3, replays=3)
+                    res.update({"hipblaslt_same_box_us": t_lib * 1e6, "time_vs_hipblaslt": t / t_lib})
+                except Exception as e:
+                    res["hipblaslt_same_box_us"] = repr(e)[:80]
             out[f"{qname}_{m}x{k}x{n}_NK"] = res
             del op, x
             torch.cuda.empty_cache()
