@@ -9,6 +9,10 @@
 
 #include "gemm.h"
 
+#ifndef GEMM256_LINE_PIECES       // K-major LDS-DMA pieces: 1 = 8 whole rows of 128 bytes (gemm_tile128_core.h's image), 0 = 16 rows x 64 bytes
+#define GEMM256_LINE_PIECES 1
+#endif
+
 namespace mojo {
 namespace g256 {
 
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
   const char* srcW[2];
   int64_t w_step = 0;                                 // byte advance per K-tile
   int w2_off[2] = {64, 64};                           // byte offset of the wave's second glds
+  int a2_off[2] = {64, 64};                           // the same for A (whole-line pieces: eight rows further down)
   auto locate = [&](int bid_) {
     int tile;
     if (a.tile_order == 1) {
@@ -363,6 +368,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     // K-major half-tile h: wave w fills row-block w (16 rows) with two glds (64-byte k-blocks 0,1).
     //   lane l -> row l/4, 16-byte chunk (l%4) ^ (2 if row >= 8)           [st_16x32 on the source side]
     const char* W = static_cast<const char*>(a.W) + static_cast<int64_t>(g) * a.w_group * EB;
+#if GEMM256_LINE_PIECES
+    // (round 5) K-major row-block of 16 rows x 128 bytes, filled in two pieces of 8 WHOLE rows: lane l -> row l / 8 (+ 8), LDS slot
+    // l % 8 of that row, which holds the row's 16-byte chunk (l % 8) ^ (row / 2 % 8) — half-line requests cost the fill rate 15 %
+    // in gemm_tile128_core.h, where this image comes from
+    {
+      const int rr = lane >> 3, pslot = lane & 7;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t off[2];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const int r = pc * 8 + rr;
+          int m = m0 + h * 128 + wave * 16 + r;
+          if (m >= m_end) m = m_end - 1;               // rows past the group: re-read a valid row, never stored
+          off[pc] = (static_cast<int64_t>(map_row(m, a.a_rc, a.a_ml, a.a_off, a.a_mul)) * a.lda) * EB + (pslot ^ ((r >> 1) & 7)) * 16;
+        }
+        srcA[h] = A + off[0] + static_cast<int64_t>(a.a_k_wrap ? kt0 % a.a_k_wrap : kt0) * KT_BYTES;
+        a2_off[h] = static_cast<int>(off[1] - off[0]);
+      }
+    }
+    if constexpr (!W_NMAJOR) {
+      const int rr = lane >> 3, pslot = lane & 7;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int64_t off[2];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+          const int r = pc * 8 + rr;
+          int n = n0 + h * hoff + wave * 16 + r;
+          if (n >= a.N) n = a.N - 1;
+          off[pc] = (static_cast<int64_t>(n) * a.w_n) * EB + (pslot ^ ((r >> 1) & 7)) * 16;
+        }
+        srcW[h] = W + off[0];
+        w2_off[h] = static_cast<int>(off[1] - off[0]);
+      }
+      w_step = KT_BYTES;
+    } else if constexpr (EB == 2) {
+#else
     {
       const int row = lane >> 2;
       const int chunk = (lane & 3) ^ ((row & 8) ? 2 : 0);
@@ -384,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
       }
       w_step = KT_BYTES;
     } else if constexpr (EB == 2) {
+#endif
       // [k/8][n/16][8 k][16 n] image (256-byte blocks): wave w fills k-block w with two glds (n-blocks 0-3,
       // 4-7); lane l -> n-block l/16, stored row (l%16)/2, columns (l%2)*8..+8; odd k-blocks hold rows 4-7 first
       const int rr = ((lane & 15) >> 1) ^ ((wave & 1) ? 4 : 0);
@@ -426,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
     if (which < 2) {
       const char* p = srcA[which] + static_cast<int64_t>(kt) * KT_BYTES;
       glds16(p, dst);
-      glds16(p + 64, dst + 1024);
+      glds16(p + a2_off[which], dst + 1024);
     } else {
       const int h = which - 2;
       const char* p = srcW[h] + static_cast<int64_t>(kt) * w_step;
@@ -437,21 +481,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a, Epi epi) {
 
   // ---- fragment read offsets ------------------------------------------------------------------------------
   // K-major: sub-tile (rb, ks) at (rb*2+ks)*1024; lane reads row l&15, chunk (l>>4) ^ (2 if row >= 8)
+#if GEMM256_LINE_PIECES
+  // lane reads row l & 15, chunk ks * 4 + (l >> 4), stored in slot chunk ^ (row / 2 % 8): conflict-free in each of ds_read_b128's
+  // four 16-lane groups
+  const int kmaj_lane = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) * 16);
+  const int kmaj_lane1 = (lane & 15) * 128 + (((4 + (lane >> 4)) ^ (((lane & 15) >> 1) & 7)) * 16);
+#else
   const int kmaj_lane = (lane & 15) * 64 + (((lane >> 4) ^ ((lane & 8) ? 2 : 0)) * 16);
+  const int kmaj_lane1 = kmaj_lane + 1024;
+#endif
   const int grp = lane >> 4;
 
   typedef const __attribute__((address_space(3))) frag16* lds_frag_ptr;
   auto read_a = [&](frag32 (&fa)[4], int h, int buf) {
-    const lds_char* base = smem + buf * KTILE_BYTES + h * HALF_BYTES + (wm * 4) * 2048 + kmaj_lane;
+    const lds_char* base = smem + buf * KTILE_BYTES + h * HALF_BYTES + (wm * 4) * 2048;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      fa[i] = join(*reinterpret_cast<lds_frag_ptr>(base + i * 2048), *reinterpret_cast<lds_frag_ptr>(base + i * 2048 + 1024));
+      fa[i] = join(*reinterpret_cast<lds_frag_ptr>(base + i * 2048 + kmaj_lane), *reinterpret_cast<lds_frag_ptr>(base + i * 2048 + kmaj_lane1));
   };
   auto read_w = [&](frag32 (&fw)[2], int h, int buf) {              // K-major W ([N,K])
-    const lds_char* base = smem + buf * KTILE_BYTES + (2 + h) * HALF_BYTES + (wn * 2) * 2048 + kmaj_lane;
+    const lds_char* base = smem + buf * KTILE_BYTES + (2 + h) * HALF_BYTES + (wn * 2) * 2048;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      fw[j] = join(*reinterpret_cast<lds_frag_ptr>(base + j * 2048), *reinterpret_cast<lds_frag_ptr>(base + j * 2048 + 1024));
+      fw[j] = join(*reinterpret_cast<lds_frag_ptr>(base + j * 2048 + kmaj_lane), *reinterpret_cast<lds_frag_ptr>(base + j * 2048 + kmaj_lane1));
   };
   // N-major W ([K,N]): transposed reads.  hipcc drains vmcnt(0) in front of the ds_read_tr builtins (it
   // cannot prove the read independent of the LDS-DMA writes in flight), which serialises the pipeline;
