@@ -171,6 +171,42 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
   return static_cast<int>(best);
 }
 
+// The 128 x 128 tiles' own K split (few tiles over a long K: a chunk of 65-1024 rows against a 1024-8192-wide projection, where
+// even 128 x 128 tiles leave most CUs idle and one tile walks 64-224 K-tiles: M 256 x 8192 x 1024 took 32 us on the 256 kernel's
+// split and 45 unsplit here, 17.5 with 6 slices; hipBLASLt 16.9).  Slices of at least 4 K-tiles, tiles x slices within one per CU.
+// Time model on profiles/r5_gemm_tile128_splitk_ab.txt (every split of 58 shapes): the unsplit kernel's K-tile times, 1 us more
+// of fixed cost, 0.26 us per MB of fp32 slab (written and read once) and 0.44 us per slice; a split has to model 5 % under the
+// unsplit launch, and no form runs under the operands' one pass over HBM at ~5 TB/s; the choice is within 1.1 % (geometric mean, 12 % at worst) of the best measured split.  Returns the split
+// (1 = none) and its modelled time.
+// MOJO_HIP_GEMM_SPLITK=<n> forces it (with MOJO_HIP_GEMM_TILE128 > 0).
+static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, double* modelled_us) {
+  const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 64;
+  auto cost = [&](int64_t sk) {
+    const double busy = static_cast<double>(tiles * sk) / 256.0, kn = w_nmajor ? 0.05 : 0.0;
+    const double kts = static_cast<double>(ceil_div(nkt, sk));
+    double loop = kts * (0.30 + kn + 0.125 * busy);
+    const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) * 2.0 / 5e6;      // operands once at ~5 TB/s
+    if (loop < hbm) loop = hbm;
+    const double gemm = (sk == 1 ? 5.0 : 6.0) + loop;
+    return sk == 1 ? gemm : gemm + 0.26 * static_cast<double>(sk * m * n) * 4.0 / 1e6 + 0.44 * sk;
+  };
+  *modelled_us = cost(1);
+  if (tiles > 256 || n % 4 != 0) { *modelled_us = 1e30; return 1; }
+  if (int64_t sk = MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0); sk > 0) {
+    if (sk > nkt) sk = nkt;
+    *modelled_us = cost(sk);
+    return static_cast<int>(sk);
+  }
+  int64_t best = 1;
+  double best_cost = cost(1) * 0.95;
+  for (int64_t sk = 2; sk <= 16 && tiles * sk <= 256 && sk <= nkt / 4; ++sk) {
+    const double c = cost(sk);
+    if (c < best_cost * 0.999) { best = sk; best_cost = c; }
+  }
+  if (best > 1) *modelled_us = best_cost;
+  return static_cast<int>(best);
+}
+
 // 128-row tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  Modelled times from measurements on this chip
 // (profiles/r5_gemm_tile128_ab.txt, r5_gemm_tile128_ab_kn.txt: 80 shapes per weight layout): up to 256 tiles of 128 x 128, one
 // workgroup per CU, a K-tile takes 0.30 us on an otherwise idle chip and 0.425 us with every CU busy (clock, L2), plus ~5 us of
@@ -178,33 +214,52 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
 // CUs, plus ~6 us; [K,N] weights (transposed fragment reads) 0.05 / 0.04 us more.  The 256 kernel's model runs ~15-20 % under its
 // measured times on split launches, hence the factor.  On the measured grids the rule is within 0.2 % (geometric mean) of always
 // picking the faster form, and 15 % ([N,K]) / 12.5 % ([K,N]) ahead of the 256 kernel alone.
-static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n, bool w_nmajor) {
+static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n, bool w_nmajor, int* splitk128) {
   const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 64;
   double t128;
-  if (narrow <= 256) t128 = 5.0 + nkt * (0.30 + (w_nmajor ? 0.05 : 0.0) + 0.125 * narrow / 256.0);
+  *splitk128 = 1;
+  if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, w_nmajor, &t128);
   else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + (w_nmajor ? 0.04 : 0.0) + 0.47 * wide / 256.0);
   else return false;
   double t256 = 0;
   (void)gemm_dense_splitk256(m, k, n, &t256);
-  return t128 < 1.2 * t256;
+  // (at most 128 rows — [K,N] weights, which have no weight-streaming kernel: the 256 kernel's split measures ~2 x its model there,
+  // 27.6 us at 100 x 8192 x 1024 against 15.9 on 128-row tiles in 8 slices; profiles/r5_gemm_tile128_splitk_ab_kn.txt)
+  return t128 < (m <= 128 ? 2.0 : 1.2) * t256;
 }
 
 // 65..128 rows with [N,K] weights: the weight-streaming kernel's weak zone (its 128-row form reads the weights at ~3 TB/s: 38 us
 // at 96 x 4096 x 14336, 440 us for a 128-row lm_head 4096 x 128256, against 24 / 231 in the vendor library) — one row of 128-row
 // tiles where the model says so (a lone m-tile: T = ceil(n / 128) tiles of 128 x 128, or rounds of 128 x 256 tiles beyond the chip).
-static bool gemm_rows65_128_prefers_tile128(int64_t m, int64_t k, int64_t n) {
+// The stream's own time, fitted at 100 rows on nine weight shapes of 8-134 MB (profiles/r5_gemm_tile128_splitk_ab.txt, the
+// TILE128=0 leg): 10.4 us + 0.224 us per MB + 0.08 us per 1024 of K; weights beyond the 256 MB of last-level cache stream at ~3 TB/s.
+static bool gemm_rows65_128_prefers_tile128(int64_t m, int64_t k, int64_t n, int* splitk128) {
+  *splitk128 = 1;
   if (m <= 64 || m > 128) return false;
   const int64_t narrow = ceil_div(n, 128), wide = ceil_div(n, 256), nkt = k / 64;
-  const double t128 = narrow <= 256 ? 5.0 + nkt * (0.30 + 0.125 * narrow / 256.0)
-                                    : 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
-  const double t_stream = static_cast<double>(k) * n * 2.0 / 3e6 + 6.0;
-  return t128 < 0.9 * t_stream;
+  double t128;
+  if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, false, &t128);
+  else t128 = 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
+  const double mb = static_cast<double>(k) * n * 2.0 / 1e6;
+  const double t_stream = mb <= 200.0 ? 10.4 + 0.224 * mb + 0.08 * k / 1024.0 : 6.0 + mb / 3.0;
+  return t128 < t_stream;
+}
+
+// (for the fused callers outside this file that must take mojo_hip_gemm's route: qkv_fused.hip)
+bool mojo::gemm_rows65_128_takes_tile128(const GemmArgs& a, int dtype, int64_t m, int64_t k, int64_t n, int* splitk128) {
+  *splitk128 = 1;
+  if (!(a.w_k == 1 && m > 64 && m <= 128 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && k % 64 == 0)) return false;
+  const bool prefers = gemm_rows65_128_prefers_tile128(m, k, n, splitk128);
+  return gemm_tile128_use(a, dtype, m, prefers);
 }
 
 extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n) {
   int sk = gemm_skinny_splitk(m, k, n, 1);
   const int sk256 = gemm_dense_splitk256(m, k, n);
   if (sk256 > sk) sk = sk256;
+  double t;
+  const int sk128 = m > 64 && k % 64 == 0 ? gemm_tile128_splitk(m, k, n, false, &t) : 1;   // (the same split for either weight layout)
+  if (sk128 > sk) sk = sk128;
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
 }
 
@@ -236,8 +291,15 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
   a.row_start = ws; a.tile_start = ws + 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   a.uniform_rows = static_cast<int>(m);
-  if (w_k_stride == 1 && m > 64 && m <= 128 && gemm_tile128_use(a, dtype, m, gemm_rows65_128_prefers_tile128(m, k, n)))
+  auto take_split128 = [&](int sk128) {                  // the 128-row tiles' own K split, if the workspace holds its slabs
+    if (sk128 > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk128) * m * n * 4 && aligned_to(workspace, 16)) {
+      a.splitk = sk128; a.slab = static_cast<char*>(workspace) + 64; a.slab_rows = static_cast<int>(m);
+    }
+  };
+  if (int sk128 = 1; gemm_rows65_128_takes_tile128(a, dtype, m, k, n, &sk128)) {
+    take_split128(sk128);
     return launch_gemm_tile128(a, dtype, m, s);
+  }
   if (w_k_stride == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16)) {          // decode-sized, K-major weights: maybe split K
     const int sk = gemm_skinny_splitk(m, k, n, 1);
     if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {
@@ -245,8 +307,14 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
       if (!gemm_skinny_ok(a, dtype)) { a.splitk = 1; a.slab = nullptr; }
     }
   }
-  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && gemm_tile128_use(a, dtype, m, gemm_dense_prefers_tile128(m, k, n, w_n_stride == 1)))
-    return launch_gemm_tile128(a, dtype, m, s);
+  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && (dtype == MOJO_BF16 || dtype == MOJO_F16) && k % 64 == 0) {
+    int sk128 = 1;
+    const bool prefers = gemm_dense_prefers_tile128(m, k, n, w_n_stride == 1, &sk128);
+    if (gemm_tile128_use(a, dtype, m, prefers)) {
+      take_split128(sk128);
+      return launch_gemm_tile128(a, dtype, m, s);      // (split: + launch_gemm_splitk_finalize)
+    }
+  }
   if (a.splitk == 1 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && !gemm_skinny_ok(a, dtype) && gemm_mfma256_ok(a, dtype)) {
     const int sk = gemm_dense_splitk256(m, k, n);       // few output tiles: cut K, sum the slices in a second launch
     if (sk > 1 && workspace_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4 && aligned_to(workspace, 16)) {
@@ -335,23 +403,53 @@ extern "C" int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* wei
   char* ws2 = prod + m * n * 2;
   ws2 += (16 - (reinterpret_cast<uintptr_t>(ws2) & 15)) & 15;
   const int64_t ws2_bytes = workspace_bytes - (ws2 - static_cast<char*>(workspace));
-  if (w_k_stride == 1) {                                                // decode-sized split: slabs straight into the norm
+  // A split product's slabs go straight into the norm (the finalize launch IS the norm).  The plan below is mojo_hip_gemm's own,
+  // step for step, so the fused form and the separate calls add the same slices in the same order (same bits).
+  GemmArgs a;
+  a.A = input; a.W = weight; a.C = gemm_out; a.bias = bias;
+  a.bias_fused = (bias && w_k_stride == 1) ? 1 : 0;                      // [N,K]: F.linear semantics, as mojo_hip_gemm
+  a.lda = lda; a.ldc = n; a.w_group = 0; a.w_k = w_k_stride; a.w_n = w_n_stride;
+  a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
+  a.row_start = nullptr; a.tile_start = nullptr;
+  a.uniform_rows = static_cast<int>(m);
+  auto slabs = [&](int sk) {
+    if (sk <= 1 || ws2_bytes < 64 + static_cast<int64_t>(sk) * m * n * 4) return false;
+    a.splitk = sk; a.slab = ws2 + 64; a.slab_rows = static_cast<int>(m); a.defer_finalize = 1;
+    return true;
+  };
+  auto unsplit = [&]() { a.splitk = 1; a.slab = nullptr; a.defer_finalize = 0; };
+  auto tiles128_into_norm = [&](int sk128) -> int {     // 1 = launched, 0 = not this way, < 0 = error code
+    if (!slabs(sk128)) return 0;
+    if (!gemm_tile128_group_ok(a, dtype) || !gemm_splitk_resnorm_ok(a, dtype, residual, norm_weight, normed_out, sum_out)) { unsplit(); return 0; }
+    int rc = launch_gemm_tile128(a, dtype, m, s);
+    if (!rc) rc = launch_gemm_splitk_resnorm(a, dtype, m, residual, norm_weight, normed_out, sum_out, eps, s);
+    return rc ? rc : 1;
+  };
+  bool planned = false;                                  // true: mojo_hip_gemm takes a route that is not fused here
+  if (int sk128 = 1; gemm_rows65_128_takes_tile128(a, dtype, m, k, n, &sk128)) {   // 65..128 rows: 128-row tiles where the model says so
+    const int r = tiles128_into_norm(sk128);
+    if (r) return r < 0 ? r : MOJO_OK;
+    planned = true;
+  }
+  if (!planned && w_k_stride == 1) {                                     // decode-sized split of the weight-streaming kernel
     const int sk = gemm_skinny_splitk(m, k, n, 1);
-    if (sk > 1 && ws2_bytes >= 64 + static_cast<int64_t>(sk) * m * n * 4) {
-      GemmArgs a;
-      a.A = input; a.W = weight; a.C = gemm_out; a.bias = bias;
-      a.bias_fused = bias ? 1 : 0;                                       // (w_k == 1 here: F.linear semantics, as mojo_hip_gemm)
-      a.lda = lda; a.ldc = n; a.w_group = 0; a.w_k = 1; a.w_n = w_n_stride;
-      a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
-      a.row_start = nullptr; a.tile_start = nullptr;
-      a.uniform_rows = static_cast<int>(m);
-      a.splitk = sk; a.slab = ws2 + 64; a.slab_rows = static_cast<int>(m);
-      a.defer_finalize = 1;
-      if (gemm_skinny_ok(a, dtype) && gemm_splitk_resnorm_ok(a, dtype, residual, norm_weight, normed_out, sum_out)) {
-        const int rc = launch_gemm_skinny(a, dtype, s);
-        if (rc) return rc;
-        return launch_gemm_splitk_resnorm(a, dtype, m, residual, norm_weight, normed_out, sum_out, eps, s);
+    if (slabs(sk)) {
+      if (gemm_skinny_ok(a, dtype)) {
+        if (gemm_splitk_resnorm_ok(a, dtype, residual, norm_weight, normed_out, sum_out)) {
+          const int rc = launch_gemm_skinny(a, dtype, s);
+          if (rc) return rc;
+          return launch_gemm_splitk_resnorm(a, dtype, m, residual, norm_weight, normed_out, sum_out, eps, s);
+        }
+        planned = true;
       }
+    }
+    unsplit();
+  }
+  if (!planned && !gemm_skinny_ok(a, dtype) && k % 64 == 0) {            // 128-row tiles with their own split (a prefill chunk's o_proj / down_proj)
+    int sk128 = 1;
+    if (gemm_tile128_use(a, dtype, m, gemm_dense_prefers_tile128(m, k, n, w_n_stride == 1, &sk128))) {
+      const int r = tiles128_into_norm(sk128);
+      if (r) return r < 0 ? r : MOJO_OK;
     }
   }
   void* p = gemm_out ? gemm_out : static_cast<void*>(prod);

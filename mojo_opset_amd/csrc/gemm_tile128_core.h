@@ -81,7 +81,8 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
 
   const int n_tiles = (a.N + BN - 1) / BN;
   const int m_tiles = gemm_m_tiles(a, BM);           // (ragged groups: the prefix arrays were built for 128-row tiles)
-  const int total = m_tiles * n_tiles;
+  const int tiles_mn = m_tiles * n_tiles;
+  const int total = tiles_mn * a.splitk;             // split-K (dense products only): slice-major, so an XCD's run shares A and W
   const int bid = blockIdx.x;
   if (bid >= total) return;
   int tile;
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
     const int q = total >> 3, r = total & 7, x = bid & 7, i = bid >> 3;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
+  const int kslice = tile / tiles_mn;                // 0 when splitk == 1
+  tile -= kslice * tiles_mn;
   int mi, ni;
   {  // panel-major: panels of PANEL n-tiles, inside a panel m-tile by m-tile
     const int full_panels = n_tiles / PANEL, rem = n_tiles - full_panels * PANEL;
@@ -107,7 +110,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   gemm_locate_tile(a, mi, BM, grp_i, m0, m_end);
   const int n0 = ni * BN;
   const char* const W_g = static_cast<const char*>(a.W) + static_cast<int64_t>(grp_i) * a.w_group * EB;
-  const int nkt = a.K / BK;
+  const int nkt_all = a.K / BK;
+  const int kt0 = static_cast<int>(static_cast<int64_t>(nkt_all) * kslice / a.splitk);
+  const int nkt = static_cast<int>(static_cast<int64_t>(nkt_all) * (kslice + 1) / a.splitk) - kt0;   // K-tiles of this slice (>= 1: the launcher's check)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
@@ -168,8 +173,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
     }
   }
   const int64_t w_step = W_NMAJOR ? static_cast<int64_t>(BK) * a.w_k * EB : KT_BYTES;
-  auto stage_piece = [&](int kt, int slot, int p) {  // LDS-DMA request p of the wave's PIECES for K-tile kt (p is a constant after unrolling)
+  auto stage_piece = [&](int kt, int slot, int p) {  // LDS-DMA request p of the wave's PIECES for K-tile kt of the slice (p is a constant after unrolling)
     lds_char* dst = smem + slot * STAGE_BYTES;
+    kt += kt0;
     if (p < 2 * AB) {
       glds16(srcA[p] + static_cast<int64_t>(kt) * KT_BYTES, dst + (AB * wave) * 2048 + p * 1024);
     } else if constexpr (!W_NMAJOR) {
@@ -370,6 +376,22 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   // 12.7 against 12.2 at K 1024, 2 % better on the eight-wave shape: the extra barrier and the LDS round trip cost what the
   // store pattern saves.  DESIGN Appendix A 29.)
   // direct stores: a lane owns row m = ... + (lane & 15) and 4 consecutive columns of each 16 x 16 tile
+  if constexpr (std::is_same<acc_t, f32x4>::value) {
+    if (a.splitk > 1) {                                // raw accumulators of this K slice -> slab[kslice][m][n] (launch_gemm_splitk_finalize sums them)
+      f32x4* slab = static_cast<f32x4*>(a.slab);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= m_end) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int n = n0 + wn * (WN * 16) + j * 16 + (lane >> 4) * 4;
+          if (n + 4 <= a.N) slab[((static_cast<int64_t>(kslice) * a.slab_rows + m) * a.N + n) / 4] = acc[i][j];
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -390,7 +412,9 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
 template <typename P, typename Epi, int NWN, int S>
 inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
   constexpr int BN = NWN * 64, LDS = S * (TILE_A_BYTES + BN * KT_BYTES);
-  const int64_t tiles = (a.uniform_rows > 0 ? static_cast<int64_t>(a.G) * ceil_div(a.uniform_rows, BM) : ceil_div(m_total, BM) + a.G) * ceil_div(a.N, BN);   // (ragged: an upper bound; surplus workgroups exit)
+  const int64_t tiles = (a.uniform_rows > 0 ? static_cast<int64_t>(a.G) * ceil_div(a.uniform_rows, BM) : ceil_div(m_total, BM) + a.G) * ceil_div(a.N, BN) * a.splitk;   // (ragged: an upper bound; surplus workgroups exit)
+  MOJO_REQUIRE(a.splitk == 1 || (std::is_same<typename P::acc_t, f32x4>::value && a.G == 1 && a.uniform_rows > 0 && a.slab && a.N % 4 == 0 && a.K / (KT_BYTES / P::EB) >= a.splitk),
+               MOJO_EUNSUPPORTED, "gemm(128-row tiles): split-K preconditions not met");
   MOJO_REQUIRE(tiles < (1LL << 31), MOJO_EUNSUPPORTED, "gemm(128-row tiles): grid too large");
   // [K,N] weights: 16-bit and int8.  (fp8: its MFMA is inline asm with the accumulator tied in place, the kernel then sits at
   // 256 registers with spills, and hipcc splits the live ranges of the transposed reads' destinations — copies them while
@@ -402,7 +426,7 @@ inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipS
       if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(tiles)), dim3(128 * NWN), LDS, s, a, epi);
       MOJO_CHECK_LAUNCH("gemm(128-row tiles)");
-      note_launch("gemm128:%dx%d:KN", BM, BN);
+      note_launch("gemm128:%dx%d:KN%s", BM, BN, a.splitk > 1 ? ":splitk" : "");
       return MOJO_OK;
     }
   }
@@ -412,7 +436,7 @@ inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipS
   if (first_call_on_device(attr_set)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   hipLaunchKernelGGL(fn, dim3(static_cast<unsigned>(tiles)), dim3(128 * NWN), LDS, s, a, epi);
   MOJO_CHECK_LAUNCH("gemm(128-row tiles)");
-  note_launch("gemm128:%dx%d:NK", BM, BN);
+  note_launch("gemm128:%dx%d:NK%s", BM, BN, a.splitk > 1 ? ":splitk" : "");
   return MOJO_OK;
 }
 
@@ -431,7 +455,7 @@ inline int forced_choice() {
   const long long f = MOJO_SWITCH("MOJO_HIP_GEMM_TILE128", -1);
   if (f == 0) return 0;
   if (f > 0) return 1;                                              // 1; 128 / 256 also force the tile shape
-  if (MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0) > 1) return 0;         // a forced split is a split of the 256 kernel
+  if (MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0) > 1) return 0;         // a forced split alone is a split of the 256 kernel
   return -1;
 }
 

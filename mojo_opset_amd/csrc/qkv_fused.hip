@@ -168,18 +168,32 @@ extern "C" int mojo_hip_qkv_rope_store(const void* input, const void* weight, co
   f.c_blk = cache_block_stride * 2; f.c_head = cache_head_stride * 2; f.c_tok = cache_token_stride * 2;
   f.num_blocks = num_blocks; f.page = block_size; f.max_pages = max_blocks_per_seq; f.table_stride = block_table_stride;
   f.table = block_table; f.ctx_lens = context_kv_lens;
-  bool slabs = false;
-  const int sk = gemm_skinny_splitk(batch, k, n, 1);
+  bool slabs = false, planned = false;
+  GemmArgs a;
+  a.A = input; a.W = weight; a.bias = nullptr;
+  a.lda = lda; a.ldc = n; a.w_group = 0; a.w_k = 1; a.w_n = w_n_stride;
+  a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
+  a.row_start = nullptr; a.tile_start = nullptr;
+  a.uniform_rows = static_cast<int>(batch);
+  a.C = prod;                                              // (never written when the finalize is deferred; the alignment checks want a pointer)
+  // mojo_hip_gemm's own route, step for step (same slices, same bits as the separate calls): 65..128 rows may take 128-row
+  // tiles with their own K split; their slabs feed this kernel like the weight stream's.
+  if (int sk128 = 1; gemm_rows65_128_takes_tile128(a, dtype, batch, k, n, &sk128)) {
+    planned = true;
+    if (sk128 > 1 && ws2_bytes >= 64 + static_cast<int64_t>(sk128) * batch * n * 4) {
+      a.splitk = sk128; a.slab = ws2 + 64; a.slab_rows = static_cast<int>(batch); a.defer_finalize = 1;
+      if (gemm_tile128_group_ok(a, dtype)) {
+        const int rc = launch_gemm_tile128(a, dtype, batch, s);
+        if (rc) return rc;
+        f.slab = static_cast<const float*>(a.slab); f.sk = sk128; f.bias = bias;
+        slabs = true;
+      }
+    }
+  }
+  const int sk = planned ? 1 : gemm_skinny_splitk(batch, k, n, 1);
   if (sk > 1 && ws2_bytes >= 64 + static_cast<int64_t>(sk) * batch * n * 4) {
-    GemmArgs a;
-    a.A = input; a.W = weight; a.C = nullptr; a.bias = nullptr;
-    a.lda = lda; a.ldc = n; a.w_group = 0; a.w_k = 1; a.w_n = w_n_stride;
-    a.K = static_cast<int>(k); a.N = static_cast<int>(n); a.G = 1;
-    a.row_start = nullptr; a.tile_start = nullptr;
-    a.uniform_rows = static_cast<int>(batch);
     a.splitk = sk; a.slab = ws2 + 64; a.slab_rows = static_cast<int>(batch);
     a.defer_finalize = 1;
-    a.C = prod;                                            // (never written: the finalize is deferred; the alignment checks want a pointer)
     if (gemm_skinny_ok(a, dtype)) {
       const int rc = launch_gemm_skinny(a, dtype, s);
       if (rc) return rc;

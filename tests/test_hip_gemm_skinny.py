@@ -218,7 +218,9 @@ def test_gemm_swiglu_integer_data_is_exact():
 @pytest.mark.parametrize("m,k,n,bias,resid", [(64, 4096, 4096, False, True), (64, 14336, 4096, False, True), (1, 2048, 512, True, True),
                                               (33, 8192, 8192, True, True), (64, 4096, 2048, False, False), (16, 1024, 16384, False, True),
                                               (7, 256, 192, True, True),          # no K split: the two-launch route
-                                              (200, 512, 1024, False, True)])     # 256-row tile kernel, then the norm
+                                              (200, 512, 1024, False, True),      # 128-row tiles, unsplit, then the norm
+                                              (100, 4096, 4096, True, True),      # 128-row tiles with their own K split: slabs into the norm
+                                              (256, 8192, 1024, False, True), (512, 4096, 4096, True, False)])
 def test_gemm_residual_rmsnorm_fused_equals_the_separate_calls_and_the_oracle(dtype, m, k, n, bias, resid):
     from hip_utils import hip_cls, torch_cls
     from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm_residual_rmsnorm
@@ -231,7 +233,11 @@ def test_gemm_residual_rmsnorm_fused_equals_the_separate_calls_and_the_oracle(dt
     eps = 1e-5
     dev = lambda t: None if t is None else t.to(DEV)
     normed, summed = dense_gemm_residual_rmsnorm(dev(x), dev(w), dev(b), dev(r), dev(nw), eps)
+    if k >= 4096 and m >= 100:
+        assert L.last_launch() == "gemm_skinny:splitk->resnorm"                # (the norm that sums the slabs; the product before it:)
     a = dense_gemm(dev(x), dev(w), dev(b), False)
+    if k >= 4096 and m >= 100:
+        assert L.last_launch() == "gemm128:128x128:NK:splitk", L.last_launch()
     if resid:
         op = hip_cls("MojoResidualAddRMSNorm")(n, eps, "pre", dtype=dtype, device=DEV)
         op.weight.data.copy_(nw)

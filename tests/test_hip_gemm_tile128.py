@@ -44,7 +44,7 @@ def test_tile128_integer_data_is_exact(dtype, m, k, n, bias, shape, layout):
         w = w.t().contiguous()                                      # [K, N]: `x @ w` is rounded, then `+ b` is (two operators)
         want = (x.float() @ w.float()).to(dtype)
         want = want if b is None else (want.float() + b.float()).to(dtype)
-    with switch_env(MOJO_HIP_GEMM_TILE128=shape):                   # 1: the launcher's own choice of shape; 128 / 256: forced
+    with switch_env(MOJO_HIP_GEMM_TILE128=shape, MOJO_HIP_GEMM_SPLITK="1"):   # 1: the launcher's own choice of shape; 128 / 256: forced
         got = dense_gemm(x, w, b, layout == "KN")
         form = last_launch()
     wide = shape == "256" or (shape == "1" and ((m + 127) // 128) * ((n + 127) // 128) > 256)
@@ -66,7 +66,7 @@ def test_tile128_gives_the_bits_of_the_unsplit_256_tile_kernel(dtype, m, k, n, b
     trans = layout == "KN"
     if trans:
         w = w.t().contiguous()
-    with switch_env(MOJO_HIP_GEMM_TILE128=shape):
+    with switch_env(MOJO_HIP_GEMM_TILE128=shape, MOJO_HIP_GEMM_SPLITK="1"):
         small = dense_gemm(x, w, b, trans)
         assert last_launch() == f"gemm128:128x{shape}:{layout}", last_launch()
         again = dense_gemm(x, w, b, trans)
@@ -98,7 +98,10 @@ def test_tile128_default_choice_and_switch():
     assert form(2048, 4096, 4096) == "gemm128:128x256:NK"             # 512 tiles of 128 x 128 -> 256 of 128 x 256
     assert form(8192, 1024, 8192).startswith("gemm256:")              # 1024 tiles of 256 x 256
     assert form(1024, 4096, 4096, trans=True) == "gemm128:128x128:KN"
-    assert form(128, 4096, 4096).startswith("gemm_skinny")
+    assert form(128, 4096, 4096) == "gemm128:128x128:NK:splitk"      # 32 tiles over 64 K-tiles: the tiles' own K split
+    assert form(256, 8192, 1024) == "gemm128:128x128:NK:splitk"
+    assert form(128, 4096, 1024).startswith("gemm_skinny")            # 8 MB of weights: the weight stream
+    assert form(64, 4096, 4096).startswith("gemm_skinny")
     with switch_env(MOJO_HIP_GEMM_TILE128="0"):
         assert form(1024, 4096, 4096).startswith("gemm256:")
 
@@ -117,7 +120,7 @@ def test_tile128_row_maps_and_strided_operands(shape, layout):
     a_map, c_map = (rc, 2 * rc, rc), (rc, 3 * rc, 2 * rc)            # second sub-chunk of 2 -> third sub-chunk of 3
     eng = HipGemmEngine()
     wk = w.t().contiguous() if layout == "KN" else w
-    with switch_env(MOJO_HIP_GEMM_TILE128=shape):
+    with switch_env(MOJO_HIP_GEMM_TILE128=shape, MOJO_HIP_GEMM_SPLITK="1"):
         eng(a_full[:, :k], wk, None, layout == "KN", out=out_full[:, :n], rows=blocks * rc, a_map=a_map, c_map=c_map)
         assert last_launch() == f"gemm128:128x{shape}:{layout}", last_launch()
     a_rows = torch.cat([a_full[b * 2 * rc + rc: b * 2 * rc + 2 * rc, :k] for b in range(blocks)])
@@ -133,6 +136,7 @@ def test_tile128_row_maps_and_strided_operands(shape, layout):
 @pytest.mark.parametrize("m,k,n,want_form", [(96, 4096, 14336, "gemm128:128x128:NK"),      # one row of 112 tiles beats the 128-row weight stream
                                              (128, 1024, 33024, "gemm128:128x256:NK"),     # 258 tiles of 128 x 128 -> 128 x 256 tiles
                                              (100, 8192, 1024, "gemm_skinny"),             # 8 tiles over a long K: the weight stream with its K split
+                                             (100, 14336, 4096, "gemm128:128x128:NK:splitk"),  # 32 tiles over 224 K-tiles: cut into slices
                                              (64, 4096, 14336, "gemm_skinny")])            # <= 64 rows: never
 def test_rows_65_to_128_take_the_128_row_tiles_where_the_model_says_so(m, k, n, want_form):
     """65..128 rows with `[N,K]` weights: one row of 128-row tiles where it beats the weight-streaming kernel's 128-row form
@@ -165,3 +169,60 @@ def test_decode_sized_rows_with_kn_weights_split_k(m, k, n, bias):
             unsplit = dense_gemm(x, w, b, True)
             assert last_launch().startswith("gemm256:") and ":splitk" not in last_launch(), last_launch()
     assert torch.equal(got, want) and torch.equal(unsplit, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n,bias,sk", [
+    (256, 8192, 1024, True, 0),           # the model's own split (16 tiles over 128 K-tiles)
+    (200, 4096, 4096, False, 0),
+    (512, 7168, 2048, True, 0),
+    (129, 192, 132, True, 3),             # one K-tile per slice, ragged M and N (N % 128 = 4)
+    (300, 1024, 520, True, 5),            # 16 K-tiles in 5 uneven slices
+    (1000, 512, 4096, False, 2),
+])
+@pytest.mark.parametrize("layout", ["NK", "KN"])
+def test_tile128_split_k_integer_data_is_exact(dtype, m, k, n, bias, sk, layout):
+    """Few 128 x 128 tiles over a long K: K is cut, the slices' fp32 accumulators go to slabs and the finalize launch sums them in
+    slice order, rounds and adds the bias as the unsplit epilogue does.  Small-integer data: exact whatever the split."""
+    torch.manual_seed(m + n)
+    if layout == "KN":
+        n = (n + 7) // 8 * 8
+    x = torch.randint(-4, 5, (m, k)).to(dtype).to(DEV)
+    w = torch.randint(-4, 5, (n, k)).to(dtype).to(DEV)
+    b = torch.randint(-8, 9, (n,)).to(dtype).to(DEV) if bias else None
+    if layout == "NK":
+        want = F.linear(x.float(), w.float(), None if b is None else b.float()).to(dtype)
+    else:
+        w = w.t().contiguous()
+        want = (x.float() @ w.float()).to(dtype)
+        want = want if b is None else (want.float() + b.float()).to(dtype)
+    env = dict(MOJO_HIP_GEMM_TILE128="1", MOJO_HIP_GEMM_SPLITK=str(sk)) if sk else {}
+    with switch_env(**env):
+        got = dense_gemm(x, w, b, layout == "KN")
+        assert last_launch() == f"gemm128:128x128:{layout}:splitk", last_launch()
+    assert torch.equal(got, want)
+
+
+def test_tile128_split_k_row_maps_and_random_data():
+    """Split + row maps on both sides (the slabs are indexed by logical row; the finalize applies the C map), and random data
+    within one unit in the last place of the fp32 reference."""
+    torch.manual_seed(9)
+    dtype = torch.bfloat16
+    k, n, rc, blocks = 2048, 640, 96, 3
+    a_full = torch.randn(blocks * 2 * rc, k + 64, device=DEV).to(dtype)
+    w = (torch.randn(n, k, device=DEV) * 0.05).to(dtype)
+    b = torch.randn(n, device=DEV).to(dtype)
+    out_full = torch.zeros(blocks * 3 * rc, n + 8, dtype=dtype, device=DEV)
+    a_map, c_map = (rc, 2 * rc, rc), (rc, 3 * rc, 2 * rc)
+    eng = HipGemmEngine()
+    with switch_env(MOJO_HIP_GEMM_TILE128="1", MOJO_HIP_GEMM_SPLITK="4"):
+        eng(a_full[:, :k], w, b, False, out=out_full[:, :n], rows=blocks * rc, a_map=a_map, c_map=c_map)
+        assert last_launch() == "gemm128:128x128:NK:splitk", last_launch()
+    a_rows = torch.cat([a_full[i * 2 * rc + rc: i * 2 * rc + 2 * rc, :k] for i in range(blocks)])
+    want = F.linear(a_rows.float(), w.float(), b.float()).to(dtype)
+    got = torch.cat([out_full[i * 3 * rc + 2 * rc: i * 3 * rc + 3 * rc, :n] for i in range(blocks)])
+    assert max_ulp_bf16ish(to_cpu(got), to_cpu(want), atol=2e-2) <= 1
+    mask = torch.ones(out_full.shape[0], dtype=torch.bool)
+    for i in range(blocks):
+        mask[i * 3 * rc + 2 * rc: i * 3 * rc + 3 * rc] = False
+    assert not out_full[mask.to(DEV)].any() and not out_full[:, n:].any()
