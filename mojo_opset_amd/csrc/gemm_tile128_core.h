@@ -376,21 +376,19 @@ __global__ __launch_bounds__(128 * NWN, 2) void gemm128_kernel(GemmArgs a, Epi e
   // 12.7 against 12.2 at K 1024, 2 % better on the eight-wave shape: the extra barrier and the LDS round trip cost what the
   // store pattern saves.  DESIGN Appendix A 29.)
   // direct stores: a lane owns row m = ... + (lane & 15) and 4 consecutive columns of each 16 x 16 tile
-  if constexpr (std::is_same<acc_t, f32x4>::value) {
-    if (a.splitk > 1) {                                // raw accumulators of this K slice -> slab[kslice][m][n] (launch_gemm_splitk_finalize sums them)
-      f32x4* slab = static_cast<f32x4*>(a.slab);
+  if (a.splitk > 1) {                                  // raw accumulators (fp32 / int32) of this K slice -> slab[kslice][m][n]: the caller's
+    acc_t* slab = static_cast<acc_t*>(a.slab);         // finalize launch sums the slices in index order (and dequantises)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= m_end) continue;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      if (m >= m_end) continue;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int n = n0 + wn * (WN * 16) + j * 16 + (lane >> 4) * 4;
-          if (n + 4 <= a.N) slab[((static_cast<int64_t>(kslice) * a.slab_rows + m) * a.N + n) / 4] = acc[i][j];
-        }
+      for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wn * (WN * 16) + j * 16 + (lane >> 4) * 4;
+        if (n + 4 <= a.N) slab[((static_cast<int64_t>(kslice) * a.slab_rows + m) * a.N + n) / 4] = acc[i][j];
       }
-      return;
     }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -413,7 +411,7 @@ template <typename P, typename Epi, int NWN, int S>
 inline int launch_shape(const GemmArgs& a, const Epi& epi, int64_t m_total, hipStream_t s) {
   constexpr int BN = NWN * 64, LDS = S * (TILE_A_BYTES + BN * KT_BYTES);
   const int64_t tiles = (a.uniform_rows > 0 ? static_cast<int64_t>(a.G) * ceil_div(a.uniform_rows, BM) : ceil_div(m_total, BM) + a.G) * ceil_div(a.N, BN) * a.splitk;   // (ragged: an upper bound; surplus workgroups exit)
-  MOJO_REQUIRE(a.splitk == 1 || (std::is_same<typename P::acc_t, f32x4>::value && a.G == 1 && a.uniform_rows > 0 && a.slab && a.N % 4 == 0 && a.K / (KT_BYTES / P::EB) >= a.splitk),
+  MOJO_REQUIRE(a.splitk == 1 || (a.G == 1 && a.uniform_rows > 0 && a.slab && a.N % 4 == 0 && a.K / (KT_BYTES / P::EB) >= a.splitk),
                MOJO_EUNSUPPORTED, "gemm(128-row tiles): split-K preconditions not met");
   MOJO_REQUIRE(tiles < (1LL << 31), MOJO_EUNSUPPORTED, "gemm(128-row tiles): grid too large");
   // [K,N] weights: 16-bit and int8.  (fp8: its MFMA is inline asm with the accumulator tied in place, the kernel then sits at

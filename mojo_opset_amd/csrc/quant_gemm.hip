@@ -54,6 +54,26 @@ __global__ __launch_bounds__(256) void quant_finalize_kernel(const ACC* __restri
                                                              const float* __restrict__ rs, const bf16_t* __restrict__ cs,
                                                              TO* __restrict__ C) {
   const int64_t total = M * N;
+  if (N % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & (4 * sizeof(TO) - 1)) == 0) {      // 16 bytes of every slab per lane
+    typedef typename vec_of<ACC, 4>::type A4;
+    typedef typename vec_of<TO, 4>::type O4;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total / 4; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+      A4 acc = {0, 0, 0, 0};
+      for (int sidx = 0; sidx < splitk; ++sidx) acc += reinterpret_cast<const A4*>(slab + static_cast<int64_t>(sidx) * total)[i];
+      const int64_t m = (i * 4) / N;
+      const int n = static_cast<int>(i * 4 - m * N);
+      const float r = rs[m];
+      O4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = __fmul_rn(__fmul_rn(static_cast<float>(acc[e]), r), static_cast<float>(cs[n + e]));
+        asm volatile("" : "+v"(v));
+        o[e] = elt<TO>::from_f(v);
+      }
+      reinterpret_cast<O4*>(C)[i] = o;
+    }
+    return;
+  }
   for (int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total;
        idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
     ACC acc = 0;
@@ -501,15 +521,44 @@ static int quant_splitk(int64_t m, int k, int n) {
 static bool quant_tile128_ok(int64_t m, const GemmArgs& a, int out_elt_bytes, bool fp8) {
   const bool layout = (a.w_k == 1 && a.w_n % 16 == 0) ||                                      // [N,K] (trans_weight)
                       (!fp8 && a.w_n == 1 && a.w_k % 16 == 0 && a.N % 16 == 0 && a.N >= 16);    // [K,N], int8: transposed byte reads
-  return m > 64 && layout && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldc % 4 == 0 &&   // (<= 128 rows with [N,K] weights never get here: the weight-streaming kernel)
+  return (m > 64 || a.w_n == 1) && layout && a.K >= 128 && a.K % 128 == 0 && a.lda % 16 == 0 && a.ldc % 4 == 0 &&   // (<= 128 rows with [N,K] weights never get here: the weight-streaming kernel)
          aligned_to(a.A, 16) && aligned_to(a.W, 16) && aligned_to(a.C, 4 * out_elt_bytes);
 }
-static bool quant_prefers_tile128(int64_t m, int k, int n, bool w_nmajor) {
+// The 128 x 128 tiles' own K split (gemm_api.hip, gemm_tile128_splitk: the same model — a K-tile is 128 bytes of K in both
+// element sizes — with the [K,N] byte reads' K-tile time): few tiles over a long K, M 256 x 8192 x 1024 = 16 tiles over 64 K-tiles.
+// The slices' int32 / fp32 accumulators go to slabs; quant_finalize_kernel sums them in slice order and applies the scales.
+static int quant_tile128_splitk(int64_t m, int k, int n, bool w_nmajor, double* modelled_us) {
+  const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 128;
+  auto cost = [&](int64_t sk) {
+    const double busy = static_cast<double>(tiles * sk) / 256.0;
+    double loop = static_cast<double>(ceil_div(nkt, sk)) * (w_nmajor ? 0.58 + 0.08 * busy : 0.30 + 0.125 * busy);
+    const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) / 5e6;
+    if (loop < hbm) loop = hbm;
+    return sk == 1 ? 5.0 + loop : 6.0 + loop + 0.26 * static_cast<double>(sk * m * n) * 4.0 / 1e6 + 0.44 * sk;
+  };
+  *modelled_us = cost(1);
+  if (tiles > 256 || n % 4 != 0) { *modelled_us = 1e30; return 1; }
+  if (int64_t sk = MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0); sk > 0) {
+    if (sk > nkt) sk = nkt;
+    *modelled_us = cost(sk);
+    return static_cast<int>(sk);
+  }
+  int64_t best = 1;
+  double best_cost = cost(1) * 0.95;
+  for (int64_t sk = 2; sk <= 16 && tiles * sk <= 256 && sk <= nkt / 4; ++sk) {
+    const double c = cost(sk);
+    if (c < best_cost * 0.999) { best = sk; best_cost = c; }
+  }
+  if (best > 1) *modelled_us = best_cost;
+  return static_cast<int>(best);
+}
+static bool quant_prefers_tile128(int64_t m, int k, int n, bool w_nmajor, int* splitk128) {
   const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 128;
   double t128;
+  *splitk128 = 1;
   // ([K,N], int8: the transposed byte reads cost more than the 16-bit ones — 0.58-0.66 us per K-tile of a 128 x 128 tile
   // against 0.30-0.43 for [N,K]; profiles/r5_quant_tile128_ab_kn.txt)
-  if (narrow <= 256) t128 = 5.0 + nkt * (w_nmajor ? 0.58 + 0.08 * narrow / 256.0 : 0.30 + 0.125 * narrow / 256.0);
+  if (narrow <= 256) *splitk128 = quant_tile128_splitk(m, k, n, w_nmajor, &t128);
   else if (wide <= 256) t128 = 6.0 + nkt * (w_nmajor ? 0.90 + 0.25 * wide / 256.0 : 0.34 + 0.47 * wide / 256.0);
   else return false;
   const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), sk = quant_splitk(m, k, n);
@@ -528,13 +577,29 @@ static int run_quant(GemmArgs a, const float* rs, const bf16_t* cs, int64_t m, i
     return fp8 ? launch_quant_skinny<TO, true>(a, rs, cs, m, slab_ws, s) : launch_quant_skinny<TO, false>(a, rs, cs, m, slab_ws, s);
   if (quant_tile128_ok(m, a, sizeof(TO), fp8)) {
     const int f = g128::forced_choice();
-    if (f < 0 ? quant_prefers_tile128(m, a.K, a.N, a.w_n == 1) : f == 1) {
+    int sk128 = 1;
+    const bool prefers = quant_prefers_tile128(m, a.K, a.N, a.w_n == 1, &sk128);
+    if (f < 0 ? prefers : f == 1) {
+      if (sk128 > 1 && a.ldc == a.N) {                 // (the finalize writes a dense [M, N]; mojo_hip_quant_gemm_workspace_bytes covers the slabs)
+        a.splitk = sk128; a.slab = slab_ws; a.slab_rows = static_cast<int>(m);
+      }
+      int rc;
       if (fp8) {
         g256::EpilogueDequant<TO, f32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f, true};
-        return g128::launch<g256::PolF8>(a, epi, m, s);
+        rc = g128::launch<g256::PolF8>(a, epi, m, s);
+      } else {
+        g256::EpilogueDequant<TO, i32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f, true};
+        rc = g128::launch<g256::PolI8>(a, epi, m, s);
       }
-      g256::EpilogueDequant<TO, i32x4> epi{static_cast<TO*>(a.C), a.ldc, rs, cs, 0.f, true};
-      return g128::launch<g256::PolI8>(a, epi, m, s);
+      if (rc || a.splitk == 1) return rc;
+      int64_t blocks = ceil_div(m * a.N, 256);
+      if (blocks > 256 * 8) blocks = 256 * 8;
+      if (fp8)
+        hipLaunchKernelGGL((quant_finalize_kernel<TO, float>), dim3(blocks), dim3(256), 0, s, static_cast<const float*>(slab_ws), a.splitk, m, a.N, rs, cs, static_cast<TO*>(a.C));
+      else
+        hipLaunchKernelGGL((quant_finalize_kernel<TO, int>), dim3(blocks), dim3(256), 0, s, static_cast<const int*>(slab_ws), a.splitk, m, a.N, rs, cs, static_cast<TO*>(a.C));
+      MOJO_CHECK_LAUNCH("quant_gemm(finalize)");
+      return MOJO_OK;
     }
   }
   if (g256::gemm256_layout_ok(a, 1)) {
@@ -593,6 +658,13 @@ extern "C" int64_t mojo_hip_quant_gemm_workspace_bytes(int64_t m, int64_t k, int
   if (m <= 128 && k > 0 && k % 256 == 0 && n % 64 == 0) {
     const int s2 = quant_skinny_splitk(static_cast<int>(k), static_cast<int>(n), m);
     if (s2 > sk) sk = s2;
+  }
+  if (k > 0 && k % 128 == 0) {                          // the 128-row tiles' own split, either weight layout
+    double t;
+    for (int kn = 0; kn < 2; ++kn) {
+      const int s3 = quant_tile128_splitk(m, static_cast<int>(k), static_cast<int>(n), kn != 0, &t);
+      if (s3 > sk) sk = s3;
+    }
   }
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
 }

@@ -277,16 +277,60 @@ def test_quant_gemm_tile128_equals_the_256_tile_kernel_and_the_integer_formula(m
     op.weight_scale.copy_(torch.rand(n, device=DEV) * 0.02)
     s_in = torch.rand(m, device=DEV)
     monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", shape)
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
     small = op(x, s_in)
     assert last_launch() == f"gemm128:128x{shape}:" + ("NK" if trans_weight else "KN"), last_launch()
     monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "0")
-    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
     large = op(x, s_in)
     assert last_launch().startswith("gemm256:") and ":splitk" not in last_launch(), last_launch()
     assert torch.equal(small, large)
     if quant_dtype == torch.int8:
         exact = quant_gemm_formula(x.cpu(), w_nk.cpu().t(), s_in.cpu(), op.weight_scale.cpu(), odt)
         torch.testing.assert_close(to_cpu(small), exact, atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("quant_dtype", [torch.int8, torch.float8_e4m3fn])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("m,k,n,sk", [(256, 8192, 1024, 0), (200, 4096, 4096, 0),      # the model's own split
+                                      (129, 384, 132, 3), (300, 2048, 520, 5), (32, 4096, 1024, 4)])   # forced: one K-tile per slice, uneven slices, decode rows ([K,N] only)
+@pytest.mark.parametrize("trans_weight", [True, False])
+def test_quant_gemm_tile128_split_k(m, k, n, sk, odt, quant_dtype, trans_weight, monkeypatch):
+    """Few 128 x 128 tiles over a long K: the tiles' own K split — int32 / fp32 slabs, summed in slice order and dequantised by
+    quant_finalize_kernel.  int8: int32 sums are exact, so the result equals the integer formula and the unsplit kernel to the
+    bit; fp8: the fp32 slices are added in another order than the unsplit K loop — within the operator's fp8 bound."""
+    torch.manual_seed(m + n)
+    if not trans_weight:
+        if quant_dtype != torch.int8:
+            pytest.skip("(K, N) weights on the 128-row tiles: int8 only")
+        n = (n + 15) // 16 * 16
+    elif m <= 64:
+        pytest.skip("[N,K] weights and at most 64 rows: the weight-streaming kernel")
+    op = hip_cls("MojoQuantGemm")(k, n, output_dtype=odt, trans_weight=trans_weight, quant_dtype=quant_dtype, weight_dtype=quant_dtype, device=DEV)
+    if quant_dtype == torch.int8:
+        w_nk = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=DEV)
+        x = torch.randint(-127, 128, (m, k), dtype=torch.int8, device=DEV)
+    else:
+        w_nk = torch.randn(n, k, device=DEV).to(quant_dtype)
+        x = torch.randn(m, k, device=DEV).to(quant_dtype)
+    op.weight.copy_(w_nk if trans_weight else w_nk.t())
+    op.weight_scale.copy_(torch.rand(n, device=DEV) * 0.02)
+    s_in = torch.rand(m, device=DEV)
+    if sk:
+        monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "1")
+        monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", str(sk))
+    split = op(x, s_in)
+    assert last_launch() == "gemm128:128x128:" + ("NK" if trans_weight else "KN") + ":splitk", last_launch()
+    assert torch.equal(split, op(x, s_in))
+    monkeypatch.setenv("MOJO_HIP_GEMM_TILE128", "1")
+    monkeypatch.setenv("MOJO_HIP_GEMM_SPLITK", "1")
+    whole = op(x, s_in)
+    assert last_launch() == "gemm128:128x128:" + ("NK" if trans_weight else "KN"), last_launch()
+    if quant_dtype == torch.int8:
+        assert torch.equal(split, whole)
+        exact = quant_gemm_formula(x.cpu(), w_nk.cpu().t(), s_in.cpu(), op.weight_scale.cpu(), odt)
+        torch.testing.assert_close(to_cpu(split), exact, atol=0, rtol=0)
+    else:
+        torch.testing.assert_close(to_cpu(split).float(), to_cpu(whole).float(), atol=2e-2 * k ** 0.5 * 0.02, rtol=2 ** -7)
 
 
 def test_quant_gemm_tile128_default_choice():
