@@ -105,7 +105,7 @@ bool gemm_mfma256_glu_ok(const GemmArgs& a, int dtype);
 bool gemm_skinny_ok(const GemmArgs& a, int dtype);
 int gemm_skinny_splitk(int64_t m, int64_t k, int64_t n, int64_t groups);
 int launch_gemm_skinny(const GemmArgs& a, int dtype, hipStream_t s);
-bool gemm_rows65_128_takes_tile128(const GemmArgs& a, int dtype, int64_t m, int64_t k, int64_t n, int* splitk128);   // gemm_api.hip: mojo_hip_gemm's route for 65..128 rows of [N,K] weights
+bool gemm_rows128_takes_tile128(const GemmArgs& a, int dtype, int64_t m, int64_t k, int64_t n, int* splitk128);   // gemm_api.hip: mojo_hip_gemm's route for at most 128 rows of [N,K] weights
 int launch_gemm_splitk_finalize(const GemmArgs& a, int dtype, int64_t m_total, hipStream_t s);   // C = round(sum of the fp32 K-slice slabs) (+ bias)
 bool gemm_skinny_glu_ok(const GemmArgs& a, int dtype);                            // dense, <= 64 rows, W = [gate | up] rows: SwiGLU in the epilogue
 int launch_gemm_skinny_glu(const GemmArgs& a, int dtype, hipStream_t s);

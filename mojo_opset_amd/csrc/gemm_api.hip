@@ -143,8 +143,16 @@ extern "C" int mojo_hip_group_gemm_swiglu(const void* input, const void* weight,
 // same 68 us (K = 4096) from 129 to 2048 rows, 2-4 x the vendor library's time.  K is cut so that ~256 workgroups run; the
 // slices go to fp32 slabs and launch_gemm_splitk_finalize sums them in slice order (deterministic).
 // MOJO_HIP_GEMM_SPLITK=<n> forces the split (1 = off).
+// `modelled_us`: the chosen launch's time with COLD weights — every call another weight, as a model's layers are; the one-weight
+// graphs of the first A/Bs re-read up to 256 MB from the last-level cache, which flatters the kernels with little in flight per CU.
+// Fitted on profiles/r5_gemm_cold_weights_ab.txt (94 launches of this kernel, 6 % rms): 12.3 us + K-tiles per slice x (0.60 per
+// round + 0.77 x share of busy CUs) + 0.14 us per MB of slab + 7.1 us for the second launch of a split.
 static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelled_us = nullptr) {
-  if (modelled_us) *modelled_us = static_cast<double>(ceil_div(ceil_div(m, 256) * ceil_div(n, 256), 256)) * (k / 64) * 1.06;
+  auto cold = [&](int64_t sk) {
+    const double tiles_sk = static_cast<double>(ceil_div(m, 256) * ceil_div(n, 256) * sk), kts = static_cast<double>(k / 64) / sk;
+    return 12.3 + std::ceil(tiles_sk / 256.0) * kts * 0.60 + tiles_sk / 256.0 * kts * 0.77 + (sk > 1 ? 0.14 * sk * m * n * 4.0 / 1e6 + 7.1 : 0.0);
+  };
+  if (modelled_us) *modelled_us = cold(1);
   // (m <= 128 too: decode-sized rows with [K,N] weights — `x @ w`, the GEMM + collective operators' trans_weight — have no
   // weight-streaming kernel and ran ONE round of 16-32 workgroups over the whole K: 72 us at 32 x 4096 x 4096 against 14 in the
   // vendor library, 137 us at K 8192 (profiles/r5_gemm_sweep_vs_lib.txt).  Slices of at least 4 K-tiles there.)
@@ -152,7 +160,9 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
   const int64_t tiles = ceil_div(m, 256) * ceil_div(n, 256), nkt = k / 64, min_slice = m <= 128 ? 4 : 8;
   if (int64_t sk = MOJO_SWITCH("MOJO_HIP_GEMM_SPLITK", 0); sk > 0) {
     if (sk > nkt / min_slice) sk = nkt / min_slice;
-    return sk < 1 ? 1 : static_cast<int>(sk);
+    if (sk < 1) sk = 1;
+    if (modelled_us) *modelled_us = cold(sk);
+    return static_cast<int>(sk);
   }
   // time of a split in us, from measurements on this chip: a workgroup's K-tile takes ~1.06 us (68 us for the 64 K-tiles of
   // K = 4096), one workgroup per CU, so rounds(tiles * sk) x K-tiles per slice; the slabs are written and read once each at
@@ -167,28 +177,29 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
     const double c = cost(sk);
     if (c < best_cost * 0.999) { best = sk; best_cost = c; }
   }
-  if (modelled_us) *modelled_us = cost(best);
+  if (modelled_us) *modelled_us = cold(best);
   return static_cast<int>(best);
 }
 
 // The 128 x 128 tiles' own K split (few tiles over a long K: a chunk of 65-1024 rows against a 1024-8192-wide projection, where
 // even 128 x 128 tiles leave most CUs idle and one tile walks 64-224 K-tiles: M 256 x 8192 x 1024 took 32 us on the 256 kernel's
 // split and 45 unsplit here, 17.5 with 6 slices; hipBLASLt 16.9).  Slices of at least 4 K-tiles, tiles x slices within one per CU.
-// Time model on profiles/r5_gemm_tile128_splitk_ab.txt (every split of 58 shapes): the unsplit kernel's K-tile times, 1 us more
-// of fixed cost, 0.26 us per MB of fp32 slab (written and read once) and 0.44 us per slice; a split has to model 5 % under the
-// unsplit launch, and no form runs under the operands' one pass over HBM at ~5 TB/s; the choice is within 1.1 % (geometric mean, 12 % at worst) of the best measured split.  Returns the split
+// Time model for COLD weights (profiles/r5_gemm_cold_weights_ab.txt: every split of 168 shapes, each call of the graph on another
+// copy of the weight; the first, one-weight A/B — r5_gemm_tile128_splitk_ab.txt — had the weights in the last-level cache): with
+// three K-tiles of 32 KiB in flight a workgroup is bound by the memory LATENCY, 0.50-0.58 us per K-tile whatever the number of busy
+// CUs (0.30-0.43 from the cache), so spreading the K-tiles over more CUs pays more than it did warm: unsplit 6.75 us + K-tiles x
+// (0.50 + 0.075 x share of busy CUs); split 5.6 us + K-tiles per slice x 0.55 + 0.55 us per MB of slab + 0.32 us per slice; and no
+// form runs under the operands' one pass over HBM at the ~4.8 TB/s these 128-byte row pieces reach.  Returns the split
 // (1 = none) and its modelled time.
-// MOJO_HIP_GEMM_SPLITK=<n> forces it (with MOJO_HIP_GEMM_TILE128 > 0).
 static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, double* modelled_us) {
   const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 64;
   auto cost = [&](int64_t sk) {
     const double busy = static_cast<double>(tiles * sk) / 256.0, kn = w_nmajor ? 0.05 : 0.0;
     const double kts = static_cast<double>(ceil_div(nkt, sk));
-    double loop = kts * (0.30 + kn + 0.125 * busy);
-    const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) * 2.0 / 5e6;      // operands once at ~5 TB/s
+    double loop = kts * (sk == 1 ? 0.50 + kn + 0.075 * busy : 0.55 + kn);
+    const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) * 2.0 / 4.8e6;
     if (loop < hbm) loop = hbm;
-    const double gemm = (sk == 1 ? 5.0 : 6.0) + loop;
-    return sk == 1 ? gemm : gemm + 0.26 * static_cast<double>(sk * m * n) * 4.0 / 1e6 + 0.44 * sk;
+    return sk == 1 ? 6.75 + loop : 5.6 + loop + 0.55 * static_cast<double>(sk * m * n) * 4.0 / 1e6 + 0.32 * sk;
   };
   *modelled_us = cost(1);
   if (tiles > 256 || n % 4 != 0) { *modelled_us = 1e30; return 1; }
@@ -198,7 +209,7 @@ static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, d
     return static_cast<int>(sk);
   }
   int64_t best = 1;
-  double best_cost = cost(1) * 0.95;
+  double best_cost = cost(1);
   for (int64_t sk = 2; sk <= 16 && tiles * sk <= 256 && sk <= nkt / 4; ++sk) {
     const double c = cost(sk);
     if (c < best_cost * 0.999) { best = sk; best_cost = c; }
@@ -207,49 +218,53 @@ static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, d
   return static_cast<int>(best);
 }
 
-// 128-row tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  Modelled times from measurements on this chip
-// (profiles/r5_gemm_tile128_ab.txt, r5_gemm_tile128_ab_kn.txt: 80 shapes per weight layout): up to 256 tiles of 128 x 128, one
-// workgroup per CU, a K-tile takes 0.30 us on an otherwise idle chip and 0.425 us with every CU busy (clock, L2), plus ~5 us of
-// launch, prologue and epilogue; beyond, up to 256 tiles of 128 x 256 (eight waves), 0.34 us + 0.47 us x the share of busy
-// CUs, plus ~6 us; [K,N] weights (transposed fragment reads) 0.05 / 0.04 us more.  The 256 kernel's model runs ~15-20 % under its
-// measured times on split launches, hence the factor.  On the measured grids the rule is within 0.2 % (geometric mean) of always
-// picking the faster form, and 15 % ([N,K]) / 12.5 % ([K,N]) ahead of the 256 kernel alone.
+// 128-row tiles (gemm_tile128.hip) or the 256 x 256 kernel with its best split?  The smaller of the two modelled times, both for
+// COLD weights (profiles/r5_gemm_cold_weights_ab.txt, 168 shapes x every form; see gemm_tile128_splitk and gemm_dense_splitk256):
+// up to 256 tiles of 128 x 128 with their own K split; beyond, up to 256 tiles of 128 x 256 (eight waves): 12 us + K-tiles x
+// (0.72 + 0.12 x share of busy CUs); [K,N] weights (transposed fragment reads) 0.05 us more per K-tile.  On the cold grid the rule is
+// within 1.6 % (geometric mean) of always picking the fastest measured form and level with hipBLASLt (1.00 x its time over the
+// grid, rows 8 to 4096); the warm-fitted rule it replaces was 3.6 % off the best and picked 128-row tiles for long-K products the
+// 256 kernel runs 20-25 % faster cold (M 1024 x 14336 x 4096: 136 against 108 us).  On the warm grid the cold rule gives up 0.9 %.
 static bool gemm_dense_prefers_tile128(int64_t m, int64_t k, int64_t n, bool w_nmajor, int* splitk128) {
   const int64_t narrow = ceil_div(m, 128) * ceil_div(n, 128), wide = ceil_div(m, 128) * ceil_div(n, 256), nkt = k / 64;
   double t128;
   *splitk128 = 1;
   if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, w_nmajor, &t128);
-  else if (wide <= 256) t128 = 6.0 + nkt * (0.34 + (w_nmajor ? 0.04 : 0.0) + 0.47 * wide / 256.0);
+  else if (wide <= 256) t128 = 12.0 + nkt * (0.72 + (w_nmajor ? 0.05 : 0.0) + 0.12 * wide / 256.0);
   else return false;
   double t256 = 0;
   (void)gemm_dense_splitk256(m, k, n, &t256);
-  // (at most 128 rows — [K,N] weights, which have no weight-streaming kernel: the 256 kernel's split measures ~2 x its model there,
-  // 27.6 us at 100 x 8192 x 1024 against 15.9 on 128-row tiles in 8 slices; profiles/r5_gemm_tile128_splitk_ab_kn.txt)
-  return t128 < (m <= 128 ? 2.0 : 1.2) * t256;
+  // (at most 128 rows — [K,N] weights, which have no weight-streaming kernel: the 256 kernel's split is slices of at least 4 K-tiles
+  // on 16-32 workgroups, 27.6 us at 100 x 8192 x 1024 against 15.9 on 128-row tiles in 8 slices; profiles/r5_gemm_tile128_splitk_ab_kn.txt)
+  return t128 < t256;
 }
 
-// 65..128 rows with [N,K] weights: the weight-streaming kernel's weak zone (its 128-row form reads the weights at ~3 TB/s: 38 us
-// at 96 x 4096 x 14336, 440 us for a 128-row lm_head 4096 x 128256, against 24 / 231 in the vendor library) — one row of 128-row
-// tiles where the model says so (a lone m-tile: T = ceil(n / 128) tiles of 128 x 128, or rounds of 128 x 256 tiles beyond the chip).
-// The stream's own time, fitted at 100 rows on nine weight shapes of 8-134 MB (profiles/r5_gemm_tile128_splitk_ab.txt, the
-// TILE128=0 leg): 10.4 us + 0.224 us per MB + 0.08 us per 1024 of K; weights beyond the 256 MB of last-level cache stream at ~3 TB/s.
-static bool gemm_rows65_128_prefers_tile128(int64_t m, int64_t k, int64_t n, int* splitk128) {
+// At most 128 rows with [N,K] weights — the weight-streaming kernels' range — against one row of 128-row tiles (a lone m-tile:
+// ceil(n / 128) tiles of 128 x 128 with their own K split, or rounds of 128 x 256 tiles beyond the chip).  65..128 rows are the
+// stream's weak zone (its 128-row form reads the weights at ~3.5 TB/s: 88 us for 128 x 4096 x 28672 against 58 on the tiles, 440 us
+// for a 128-row lm_head 4096 x 128256 against 231 in the vendor library); up to 64 rows the stream wins on cold weights almost
+// everywhere.  Both sides modelled for COLD weights (profiles/r5_gemm_cold_weights_ab.txt; the stream, 65 launches, 9 % rms): up to 64
+// rows (7.4 + 0.05 m) us + (0.144 + 0.00044 m) us per MB of weights; 65..128 rows (3.9 + 0.05 m) us + (0.264 + 0.00044 m) us per MB.
+static bool gemm_rows128_prefers_tile128(int64_t m, int64_t k, int64_t n, int* splitk128) {
   *splitk128 = 1;
-  if (m <= 64 || m > 128) return false;
+  if (m > 128) return false;
   const int64_t narrow = ceil_div(n, 128), wide = ceil_div(n, 256), nkt = k / 64;
   double t128;
   if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, false, &t128);
   else t128 = 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
   const double mb = static_cast<double>(k) * n * 2.0 / 1e6;
-  const double t_stream = mb <= 200.0 ? 10.4 + 0.224 * mb + 0.08 * k / 1024.0 : 6.0 + mb / 3.0;
+  double t_stream;
+  if (m <= 64) t_stream = 0.9 * (7.4 + 0.05 * m + (0.144 + 0.00044 * m) * mb);   // (decode rows: the tiles have to model 10 % under the stream,
+  else t_stream = 3.9 + 0.05 * m + (0.264 + 0.00044 * m) * mb;                    //  whose fused decode forms — GLU, norm, RoPE + store — share its bits)
+  if (m <= 64 && mb < 32.0) return false;               // (small weights at decode rows: outside the fitted range; the stream)
   return t128 < t_stream;
 }
 
 // (for the fused callers outside this file that must take mojo_hip_gemm's route: qkv_fused.hip)
-bool mojo::gemm_rows65_128_takes_tile128(const GemmArgs& a, int dtype, int64_t m, int64_t k, int64_t n, int* splitk128) {
+bool mojo::gemm_rows128_takes_tile128(const GemmArgs& a, int dtype, int64_t m, int64_t k, int64_t n, int* splitk128) {
   *splitk128 = 1;
-  if (!(a.w_k == 1 && m > 64 && m <= 128 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && k % 64 == 0)) return false;
-  const bool prefers = gemm_rows65_128_prefers_tile128(m, k, n, splitk128);
+  if (!(a.w_k == 1 && m <= 128 && (dtype == MOJO_BF16 || dtype == MOJO_F16) && k % 64 == 0)) return false;
+  const bool prefers = gemm_rows128_prefers_tile128(m, k, n, splitk128);
   return gemm_tile128_use(a, dtype, m, prefers);
 }
 
@@ -258,7 +273,7 @@ extern "C" int64_t mojo_hip_gemm_workspace_bytes(int64_t m, int64_t k, int64_t n
   const int sk256 = gemm_dense_splitk256(m, k, n);
   if (sk256 > sk) sk = sk256;
   double t;
-  const int sk128 = m > 64 && k % 64 == 0 ? gemm_tile128_splitk(m, k, n, false, &t) : 1;   // (the same split for either weight layout)
+  const int sk128 = k % 64 == 0 ? gemm_tile128_splitk(m, k, n, false, &t) : 1;   // (the same split for either weight layout)
   if (sk128 > sk) sk = sk128;
   return 64 + (sk > 1 ? static_cast<int64_t>(sk) * m * n * 4 : 0);
 }
@@ -296,7 +311,7 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
       a.splitk = sk128; a.slab = static_cast<char*>(workspace) + 64; a.slab_rows = static_cast<int>(m);
     }
   };
-  if (int sk128 = 1; gemm_rows65_128_takes_tile128(a, dtype, m, k, n, &sk128)) {
+  if (int sk128 = 1; gemm_rows128_takes_tile128(a, dtype, m, k, n, &sk128)) {
     take_split128(sk128);
     return launch_gemm_tile128(a, dtype, m, s);
   }
@@ -307,7 +322,8 @@ extern "C" int mojo_hip_gemm_rowmap(const void* input, const void* weight, const
       if (!gemm_skinny_ok(a, dtype)) { a.splitk = 1; a.slab = nullptr; }
     }
   }
-  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && (dtype == MOJO_BF16 || dtype == MOJO_F16) && k % 64 == 0) {
+  // (up to 64 rows of [N,K] weights the weight stream cannot take — N % 64: the 256 kernel, whose unsplit bits the fused decode forms share)
+  if (a.splitk == 1 && !gemm_skinny_ok(a, dtype) && (dtype == MOJO_BF16 || dtype == MOJO_F16) && k % 64 == 0 && (m > 64 || w_k_stride != 1)) {
     int sk128 = 1;
     const bool prefers = gemm_dense_prefers_tile128(m, k, n, w_n_stride == 1, &sk128);
     if (gemm_tile128_use(a, dtype, m, prefers)) {
@@ -426,7 +442,7 @@ extern "C" int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* wei
     return rc ? rc : 1;
   };
   bool planned = false;                                  // true: mojo_hip_gemm takes a route that is not fused here
-  if (int sk128 = 1; gemm_rows65_128_takes_tile128(a, dtype, m, k, n, &sk128)) {   // 65..128 rows: 128-row tiles where the model says so
+  if (int sk128 = 1; gemm_rows128_takes_tile128(a, dtype, m, k, n, &sk128)) {   // at most 128 rows: 128-row tiles where the model says so
     const int r = tiles128_into_norm(sk128);
     if (r) return r < 0 ? r : MOJO_OK;
     planned = true;
@@ -445,7 +461,7 @@ extern "C" int mojo_hip_gemm_residual_rmsnorm(const void* input, const void* wei
     }
     unsplit();
   }
-  if (!planned && !gemm_skinny_ok(a, dtype) && k % 64 == 0) {            // 128-row tiles with their own split (a prefill chunk's o_proj / down_proj)
+  if (!planned && !gemm_skinny_ok(a, dtype) && k % 64 == 0 && (m > 64 || w_k_stride != 1)) {   // 128-row tiles with their own split (a prefill chunk's o_proj / down_proj)
     int sk128 = 1;
     if (gemm_tile128_use(a, dtype, m, gemm_dense_prefers_tile128(m, k, n, w_n_stride == 1, &sk128))) {
       const int r = tiles128_into_norm(sk128);

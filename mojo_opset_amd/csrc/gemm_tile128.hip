@@ -16,10 +16,10 @@ bool gemm_tile128_group_ok(const GemmArgs& a, int dtype) {
 bool gemm_tile128_ok(const GemmArgs& a, int dtype) { return a.G == 1 && a.uniform_rows > 0 && gemm_tile128_group_ok(a, dtype); }
 int gemm_tile128_forced() { return g128::forced_choice(); }      // MOJO_HIP_GEMM_TILE128: 0 never, 1 always, -1 the caller's model
 
-// Where the 128-row tiles are taken: more than 64 rows for [N,K] weights (the weight-streaming kernels own those) and the caller's time model
-// (gemm_api.hip, gemm_dense_prefers_tile128) says so; MOJO_HIP_GEMM_TILE128 = 1 / 0: wherever they apply / never.
+// Where the 128-row tiles are taken: where the caller's time model (gemm_api.hip: gemm_dense_prefers_tile128, and
+// gemm_rows128_prefers_tile128 against the weight-streaming kernels) says so; MOJO_HIP_GEMM_TILE128 = 1 / 0: wherever they apply / never.
 bool gemm_tile128_use(const GemmArgs& a, int dtype, int64_t m_total, bool model_prefers) {
-  if (!gemm_tile128_ok(a, dtype) || (m_total <= 64 && a.w_k == 1)) return false;
+  if (!gemm_tile128_ok(a, dtype)) return false;
   const int f = g128::forced_choice();
   return f < 0 ? model_prefers : f == 1;
 }

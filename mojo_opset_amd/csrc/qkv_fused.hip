@@ -176,9 +176,9 @@ extern "C" int mojo_hip_qkv_rope_store(const void* input, const void* weight, co
   a.row_start = nullptr; a.tile_start = nullptr;
   a.uniform_rows = static_cast<int>(batch);
   a.C = prod;                                              // (never written when the finalize is deferred; the alignment checks want a pointer)
-  // mojo_hip_gemm's own route, step for step (same slices, same bits as the separate calls): 65..128 rows may take 128-row
+  // mojo_hip_gemm's own route, step for step (same slices, same bits as the separate calls): at most 128 rows may take 128-row
   // tiles with their own K split; their slabs feed this kernel like the weight stream's.
-  if (int sk128 = 1; gemm_rows65_128_takes_tile128(a, dtype, batch, k, n, &sk128)) {
+  if (int sk128 = 1; gemm_rows128_takes_tile128(a, dtype, batch, k, n, &sk128)) {
     planned = true;
     if (sk128 > 1 && ws2_bytes >= 64 + static_cast<int64_t>(sk128) * batch * n * 4) {
       a.splitk = sk128; a.slab = ws2 + 64; a.slab_rows = static_cast<int>(batch); a.defer_finalize = 1;

@@ -532,7 +532,7 @@ static int quant_tile128_splitk(int64_t m, int k, int n, bool w_nmajor, double* 
   auto cost = [&](int64_t sk) {
     const double busy = static_cast<double>(tiles * sk) / 256.0;
     double loop = static_cast<double>(ceil_div(nkt, sk)) * (w_nmajor ? 0.58 + 0.08 * busy : 0.30 + 0.125 * busy);
-    const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) / 5e6;
+    const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) / 6.5e6;
     if (loop < hbm) loop = hbm;
     return sk == 1 ? 5.0 + loop : 6.0 + loop + 0.26 * static_cast<double>(sk * m * n) * 4.0 / 1e6 + 0.44 * sk;
   };

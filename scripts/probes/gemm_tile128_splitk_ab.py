@@ -10,8 +10,10 @@ from mojo_opset_amd.backends.hip import lib as L
 from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm
 dev = torch.device("cuda", 0)
 shapes = ((4096, 4096), (8192, 1024), (7168, 2048), (14336, 4096), (5120, 5120), (4096, 1024), (2048, 7168), (4096, 14336), (8192, 8192))
+if len(sys.argv) > 2 and sys.argv[2] == "small":
+    shapes += ((8192, 28672), (28672, 8192), (4096, 28672))
 TRANS = len(sys.argv) > 1 and sys.argv[1] == "KN"
-ms = (8, 32, 64) if len(sys.argv) > 2 and sys.argv[2] == "small" else (100, 160, 256, 384, 512, 768, 1024)   # (small: [K,N] only)
+ms = (8, 32, 64) if len(sys.argv) > 2 and sys.argv[2] == "small" else (100, 160, 256, 384, 512, 768, 1024)
 splits = (2, 3, 4, 6, 8, 12, 16)
 
 

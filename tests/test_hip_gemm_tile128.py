@@ -101,7 +101,7 @@ def test_tile128_default_choice_and_switch():
     assert form(128, 4096, 4096) == "gemm128:128x128:NK:splitk"      # 32 tiles over 64 K-tiles: the tiles' own K split
     assert form(256, 8192, 1024) == "gemm128:128x128:NK:splitk"
     assert form(128, 4096, 1024).startswith("gemm_skinny")            # 8 MB of weights: the weight stream
-    assert form(64, 4096, 4096).startswith("gemm_skinny")
+    assert form(64, 4096, 4096).startswith("gemm_skinny")            # up to 64 rows: the weight stream (cold weights)
     with switch_env(MOJO_HIP_GEMM_TILE128="0"):
         assert form(1024, 4096, 4096).startswith("gemm256:")
 
@@ -133,14 +133,15 @@ def test_tile128_row_maps_and_strided_operands(shape, layout):
     assert not out_full[mask.to(DEV)].any() and not out_full[:, n:].any()      # nothing written outside the mapped rows / N columns
 
 
-@pytest.mark.parametrize("m,k,n,want_form", [(96, 4096, 14336, "gemm128:128x128:NK"),      # one row of 112 tiles beats the 128-row weight stream
+@pytest.mark.parametrize("m,k,n,want_form", [(96, 4096, 14336, "gemm128:128x128:NK:splitk"),  # one row of 112 tiles (x 2 slices) beats the 128-row weight stream
+                                             (128, 4096, 28672, "gemm128:128x128:NK"),     # 224 tiles, unsplit
                                              (128, 1024, 33024, "gemm128:128x256:NK"),     # 258 tiles of 128 x 128 -> 128 x 256 tiles
                                              (100, 8192, 1024, "gemm_skinny"),             # 8 tiles over a long K: the weight stream with its K split
                                              (100, 14336, 4096, "gemm128:128x128:NK:splitk"),  # 32 tiles over 224 K-tiles: cut into slices
-                                             (64, 4096, 14336, "gemm_skinny")])            # <= 64 rows: never
-def test_rows_65_to_128_take_the_128_row_tiles_where_the_model_says_so(m, k, n, want_form):
-    """65..128 rows with `[N,K]` weights: one row of 128-row tiles where it beats the weight-streaming kernel's 128-row form
-    (gemm_api.hip, gemm_rows65_128_prefers_tile128); integer-exact either way."""
+                                             (64, 4096, 14336, "gemm_skinny")])            # up to 64 rows: the weight stream
+def test_rows_up_to_128_take_the_128_row_tiles_where_the_model_says_so(m, k, n, want_form):
+    """At most 128 rows with `[N,K]` weights: one row of 128-row tiles where it beats the weight-streaming kernel
+    (gemm_api.hip, gemm_rows128_prefers_tile128); integer-exact either way."""
     torch.manual_seed(m)
     x = torch.randint(-4, 5, (m, k)).to(torch.bfloat16).to(DEV)
     w = torch.randint(-4, 5, (n, k)).to(torch.bfloat16).to(DEV)
