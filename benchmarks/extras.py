@@ -911,6 +911,32 @@ def bench_dense_mid_m(device):
         rec.update({"kernel_form": form, "hipblaslt_same_box_us": t_lib * 1e6, "time_vs_hipblaslt": t / t_lib})
         out[name] = rec
         del x, w
+    # COLD weights: every call of the graph on another copy of the weight (copies x bytes >= 768 MB, three times the last-level
+    # cache) — what a model's layers see; the one-weight rows above re-read the weight from the cache.  gemm_api.hip's kernel
+    # choice is fitted on this regime (scripts/probes/gemm_cold_weights_ab.py).
+    for m, k, n in ((256, 8192, 1024), (256, 4096, 4096), (512, 4096, 4096), (1024, 4096, 4096), (1024, 14336, 4096), (128, 14336, 4096)):
+        name = f"dense_{m}x{k}x{n}_NK_cold_weights"
+        if not _want(name):
+            continue
+        copies = max(2, -(-768 * 2 ** 20 // (k * n * 2)))
+        ws = [torch.randn(n, k, device=device, dtype=dt) * 0.02 for _ in range(copies)]
+        x = torch.randn(m, k, device=device, dtype=dt)
+        turn = [0, 0]
+
+        def ours():
+            turn[0] += 1
+            return dense_gemm(x, ws[turn[0] % copies], None, False)
+
+        def lib():
+            turn[1] += 1
+            return torch.nn.functional.linear(x, ws[turn[1] % copies])
+        t = _time_graph(ours, reps=max(10, copies))
+        form = _L.last_launch()
+        t_lib = _time_graph(lib, reps=max(10, copies))
+        rec = _mfma(t, 2.0 * m * k * n)
+        rec.update({"kernel_form": form, "weight_copies": copies, "hipblaslt_same_box_us": t_lib * 1e6, "time_vs_hipblaslt": t / t_lib})
+        out[name] = rec
+        del ws, x
     # few small experts (8 x 2048 -> 1408, 128 rows each): the grouped product on the 128-row tiles
     if _want("group_8x128_2048x1408_KN"):
         gw = torch.randn(8, 2048, 1408, device=device, dtype=dt) * 0.02
