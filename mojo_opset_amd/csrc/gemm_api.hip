@@ -186,8 +186,9 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
 // split and 45 unsplit here, 17.5 with 6 slices; hipBLASLt 16.9).  Slices of at least 4 K-tiles, tiles x slices within one per CU.
 // Time model for COLD weights (profiles/r5_gemm_cold_weights_ab.txt: every split of 168 shapes, each call of the graph on another
 // copy of the weight; the first, one-weight A/B — r5_gemm_tile128_splitk_ab.txt — had the weights in the last-level cache): with
-// three K-tiles of 32 KiB in flight a workgroup is bound by the memory LATENCY, 0.50-0.58 us per K-tile whatever the number of busy
-// CUs (0.30-0.43 from the cache), so spreading the K-tiles over more CUs pays more than it did warm: unsplit 6.75 us + K-tiles x
+// cold operands a workgroup fills at ~58 GB/s instead of ~90: 0.50-0.58 us per K-tile whatever the number of busy CUs (0.30-0.43
+// from the cache; a per-CU ceiling of the miss path — a fifth ring stage and a prefetch wave were measured and change nothing,
+// DESIGN Appendix A 30-31), so spreading the K-tiles over more CUs pays more than it did warm: unsplit 6.75 us + K-tiles x
 // (0.50 + 0.075 x share of busy CUs); split 5.6 us + K-tiles per slice x 0.55 + 0.55 us per MB of slab + 0.32 us per slice; and no
 // form runs under the operands' one pass over HBM at the ~4.8 TB/s these 128-byte row pieces reach.  Returns the split
 // (1 = none) and its modelled time.
