@@ -192,11 +192,19 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
 // (0.50 + 0.075 x share of busy CUs); split 5.6 us + K-tiles per slice x 0.55 + 0.55 us per MB of slab + 0.32 us per slice; and no
 // form runs under the operands' one pass over HBM at the ~4.8 TB/s these 128-byte row pieces reach.  Returns the split
 // (1 = none) and its modelled time.
-static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, double* modelled_us) {
+// `one_shot`: the constants of the first, one-weight A/B (profiles/r5_gemm_tile128_splitk_ab.txt) instead — used for 33..64 rows,
+// see gemm_rows128_prefers_tile128.
+static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, double* modelled_us, bool one_shot = false) {
   const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 64;
   auto cost = [&](int64_t sk) {
     const double busy = static_cast<double>(tiles * sk) / 256.0, kn = w_nmajor ? 0.05 : 0.0;
     const double kts = static_cast<double>(ceil_div(nkt, sk));
+    if (one_shot) {
+      double loop = kts * (0.30 + kn + 0.125 * busy);
+      const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) * 2.0 / 6.5e6;
+      if (loop < hbm) loop = hbm;
+      return sk == 1 ? (5.0 + loop) / 0.95 : 6.0 + loop + 0.26 * static_cast<double>(sk * m * n) * 4.0 / 1e6 + 0.44 * sk;   // (a split has to model 5 % under)
+    }
     double loop = kts * (sk == 1 ? 0.50 + kn + 0.075 * busy : 0.55 + kn);
     const double hbm = (static_cast<double>(k) * n + static_cast<double>(m) * k) * 2.0 / 4.8e6;
     if (loop < hbm) loop = hbm;
@@ -251,13 +259,22 @@ static bool gemm_rows128_prefers_tile128(int64_t m, int64_t k, int64_t n, int* s
   if (m > 128) return false;
   const int64_t narrow = ceil_div(n, 128), wide = ceil_div(n, 256), nkt = k / 64;
   double t128;
-  if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, false, &t128);
-  else t128 = 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
   const double mb = static_cast<double>(k) * n * 2.0 / 1e6;
+  // 33..64 rows: a 10-30 us launch between other kernels is neither of the two A/B regimes.  Measured where it runs — the Llama-3-8B
+  // decode layer at B 64, six alternating repetitions (scripts/probes/decode_layer_tile128_ab.py, profiles/r5_decode_layer_tile128_ab.txt):
+  // QKV / o / down projections on the tiles with their K split 290.7 -> 279.4 us for the fused layer (medians; 288-296 against
+  // 279-285), 306.9 -> 299.3 us for the layer written against the reference's operators — where the back-to-back cold graphs put the
+  // stream ahead (its launches overlap head and tail there) and the one-weight graphs had put the tiles ahead by 7 us.  So this range
+  // takes the one-weight models of both sides (r5_gemm_tile128_splitk_ab_nk_small.txt); weights under 32 MB stay with the stream.
+  const bool one_shot = m > 32 && m <= 64;
+  if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, false, &t128, one_shot);
+  else t128 = 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
   double t_stream;
-  if (m <= 64) t_stream = 0.9 * (7.4 + 0.05 * m + (0.144 + 0.00044 * m) * mb);   // (decode rows: the tiles have to model 10 % under the stream,
-  else t_stream = 3.9 + 0.05 * m + (0.264 + 0.00044 * m) * mb;                    //  whose fused decode forms — GLU, norm, RoPE + store — share its bits)
+  if (one_shot) t_stream = 6.5 + 0.07 * m + (0.16 + 0.0003 * m) * mb;
+  else if (m <= 64) t_stream = 0.9 * (7.4 + 0.05 * m + (0.144 + 0.00044 * m) * mb);   // (decode rows: the tiles have to model 10 % under the stream,
+  else t_stream = 3.9 + 0.05 * m + (0.264 + 0.00044 * m) * mb;                         //  whose fused decode forms — GLU, norm, RoPE + store — share its bits)
   if (m <= 64 && mb < 32.0) return false;               // (small weights at decode rows: outside the fitted range; the stream)
+  if (one_shot && *splitk128 == 1) return false;        // (unsplit tiles over a wide N lost in the layer: 64 x 4096 x 28672, +15 us)
   return t128 < t_stream;
 }
 

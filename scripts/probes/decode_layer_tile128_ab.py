@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from benchmarks import extras
 from mojo_opset_amd import switches
 dev = torch.device("cuda", 0)
-for rep in range(2):
+for rep in range(4):
     for val in (None, "1"):
         os.environ.pop("MOJO_HIP_GEMM_TILE128", None)
         if val:
