@@ -738,13 +738,13 @@ def bench_moe(device):
     return out
 
 
-def bench_decode_layer(device):
+def bench_decode_layer(device, bsz=64):
     """One whole Llama-3-8B decoder layer at decode (B = 64, ctx = 4096, bf16) as ONE captured graph of the operators of this
     package: residual-add RMSNorm -> QKV projection -> RoPE -> paged KV store -> paged decode attention -> output projection ->
     residual-add RMSNorm -> gate|up projection -> SwiGLU -> down projection.  Reported next to the sum of its memory traffic:
     what the per-operator numbers add up to once launch gaps and host work are out of the way."""
     from mojo_opset_amd.backends.hip.operators.gemm import dense_gemm as _ENGINE
-    hq, hkv, d, page, bsz, ctx, hidden, inter = 32, 8, 128, 16, 64, 4096, 4096, 14336
+    hq, hkv, d, page, ctx, hidden, inter = 32, 8, 128, 16, 4096, 4096, 14336
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(20260716)
     lens = [ctx] * bsz
@@ -862,7 +862,8 @@ def bench_decode_layer(device):
     api.update({"tokens_per_s_one_layer": bsz / t_api,
                 "note": "graph replay; the layer written only against the reference's operator API: MojoResidualAddRMSNorm, MojoGemm (QKV, o), "
                         "MojoApplyRoPE, MojoStorePagedKVCache, MojoPagedDecodeGQA, MojoSwiGLUMLP (gate|up + SwiGLU in one launch, then down)"})
-    return {"llama3_8b_layer_B64_ctx4096": res, "llama3_8b_layer_B64_ctx4096_fused": fused, "llama3_8b_layer_B64_ctx4096_mojo_api": api}
+    tag = f"llama3_8b_layer_B{bsz}_ctx4096"
+    return {tag: res, tag + "_fused": fused, tag + "_mojo_api": api}
 
 
 def bench_dense_mid_m(device):

@@ -192,7 +192,7 @@ static int gemm_dense_splitk256(int64_t m, int64_t k, int64_t n, double* modelle
 // (0.50 + 0.075 x share of busy CUs); split 5.6 us + K-tiles per slice x 0.55 + 0.55 us per MB of slab + 0.32 us per slice; and no
 // form runs under the operands' one pass over HBM at the ~4.8 TB/s these 128-byte row pieces reach.  Returns the split
 // (1 = none) and its modelled time.
-// `one_shot`: the constants of the first, one-weight A/B (profiles/r5_gemm_tile128_splitk_ab.txt) instead — used for 33..64 rows,
+// `one_shot`: the constants of the first, one-weight A/B (profiles/r5_gemm_tile128_splitk_ab.txt) instead — used for 16..64 rows,
 // see gemm_rows128_prefers_tile128.
 static int gemm_tile128_splitk(int64_t m, int64_t k, int64_t n, bool w_nmajor, double* modelled_us, bool one_shot = false) {
   const int64_t tiles = ceil_div(m, 128) * ceil_div(n, 128), nkt = k / 64;
@@ -260,13 +260,13 @@ static bool gemm_rows128_prefers_tile128(int64_t m, int64_t k, int64_t n, int* s
   const int64_t narrow = ceil_div(n, 128), wide = ceil_div(n, 256), nkt = k / 64;
   double t128;
   const double mb = static_cast<double>(k) * n * 2.0 / 1e6;
-  // 33..64 rows: a 10-30 us launch between other kernels is neither of the two A/B regimes.  Measured where it runs — the Llama-3-8B
+  // 16..64 rows: a 10-30 us launch between other kernels is neither of the two A/B regimes.  Measured where it runs — the Llama-3-8B
   // decode layer at B 64, six alternating repetitions (scripts/probes/decode_layer_tile128_ab.py, profiles/r5_decode_layer_tile128_ab.txt):
   // QKV / o / down projections on the tiles with their K split 290.7 -> 279.4 us for the fused layer (medians; 288-296 against
   // 279-285), 306.9 -> 299.3 us for the layer written against the reference's operators — where the back-to-back cold graphs put the
   // stream ahead (its launches overlap head and tail there) and the one-weight graphs had put the tiles ahead by 7 us.  So this range
   // takes the one-weight models of both sides (r5_gemm_tile128_splitk_ab_nk_small.txt); weights under 32 MB stay with the stream.
-  const bool one_shot = m > 32 && m <= 64;
+  const bool one_shot = m >= 16 && m <= 64;              // (B 32 / 16: 195.8 -> 190.6 / 154.2 -> 150.1 us fused with the tiles forced; B 8 and 1: level)
   if (narrow <= 256) *splitk128 = gemm_tile128_splitk(m, k, n, false, &t128, one_shot);
   else t128 = 6.0 + nkt * 0.81 * (wide <= 256 ? 1.0 : wide / 256.0);
   double t_stream;

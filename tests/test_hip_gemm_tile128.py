@@ -101,8 +101,8 @@ def test_tile128_default_choice_and_switch():
     assert form(128, 4096, 4096) == "gemm128:128x128:NK:splitk"      # 32 tiles over 64 K-tiles: the tiles' own K split
     assert form(256, 8192, 1024) == "gemm128:128x128:NK:splitk"
     assert form(128, 4096, 1024).startswith("gemm_skinny")            # 8 MB of weights: the weight stream
-    assert form(64, 4096, 4096) == "gemm128:128x128:NK:splitk"       # 33..64 rows: the tiles with their split where the one-shot model says so
-    assert form(32, 4096, 4096).startswith("gemm_skinny")            # up to 32 rows: the weight stream
+    assert form(64, 4096, 4096) == "gemm128:128x128:NK:splitk"       # 16..64 rows: the tiles with their split where the one-shot model says so
+    assert form(8, 4096, 4096).startswith("gemm_skinny")             # under 16 rows: the weight stream
     with switch_env(MOJO_HIP_GEMM_TILE128="0"):
         assert form(1024, 4096, 4096).startswith("gemm256:")
 
@@ -141,7 +141,7 @@ def test_tile128_row_maps_and_strided_operands(shape, layout):
                                              (100, 14336, 4096, "gemm128:128x128:NK:splitk"),  # 32 tiles over 224 K-tiles: cut into slices
                                              (64, 14336, 4096, "gemm128:128x128:NK:splitk"),   # a decode batch's down projection
                                              (64, 4096, 28672, "gemm_skinny"),             # 224 tiles would run unsplit: the weight stream
-                                             (32, 4096, 14336, "gemm_skinny")])            # up to 32 rows: the weight stream
+                                             (8, 4096, 14336, "gemm_skinny")])             # under 16 rows: the weight stream
 def test_rows_up_to_128_take_the_128_row_tiles_where_the_model_says_so(m, k, n, want_form):
     """At most 128 rows with `[N,K]` weights: one row of 128-row tiles where it beats the weight-streaming kernel
     (gemm_api.hip, gemm_rows128_prefers_tile128); integer-exact either way."""
