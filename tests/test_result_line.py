@@ -98,3 +98,28 @@ def test_bench_last_line_parses_on_the_gpu_box():
     assert rec["steps"] == 5 and rec["warmup"] == 2 and rec["n_gpus"] == 1
     assert rec["value"] > 0 and 0 < rec["roofline"]["frac"] < 1
     assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.parametrize("world,full", [(1, False), (2, False), (8, False), (8, True)])
+def test_multi_rank_runs_skip_the_single_gpu_extras(monkeypatch, world, full):
+    """bench.py at N > 1 measures the second headline (GroupGemm: the line's `roofline_group_gemm`) and the GEMM + collective
+    cases only; the single-GPU cases are on the N = 1 record.  MOJO_BENCH_FULL_EXTRAS=1 repeats them on every rank."""
+    import torch
+
+    from benchmarks import extras
+
+    ran = []
+    for name in [n for n in dir(extras) if n.startswith("bench_")]:
+        monkeypatch.setattr(extras, name, (lambda n: lambda *a, **k: ran.append(n) or {"stub": n})(name))
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    monkeypatch.setenv("MOJO_BENCH_COMM_INPROC", "1")
+    if full:
+        monkeypatch.setenv("MOJO_BENCH_FULL_EXTRAS", "1")
+    else:
+        monkeypatch.delenv("MOJO_BENCH_FULL_EXTRAS", raising=False)
+    out = extras.run_extras("cpu", world, 0)
+    assert out["MojoGroupGemm_bf16"] == {"stub": "bench_group_gemm"} and out["compute_comm_bf16"] == {"stub": "bench_compute_comm"}
+    if world == 1 or full:
+        assert "MojoPagedDecodeMLA_bf16" in out and "decode_layer_bf16" in out and len(ran) >= 14
+    else:
+        assert ran == ["bench_group_gemm", "bench_compute_comm"] and "note" in out
