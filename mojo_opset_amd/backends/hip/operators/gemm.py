@@ -131,8 +131,9 @@ def qkv_rope_store(x: torch.Tensor, weight_qkv: torch.Tensor, bias, cos: torch.T
 
 class HIPGemm(MojoGemm):
     """`MojoGemm` (core/operators/gemm.py:12-56) on `mojo_hip_gemm`: ``F.linear(input, weight, bias)``.  Decode-sized inputs take
-    the weight-stream kernels with split-K (csrc/gemm_skinny.hip), larger ones the 256 x 256 tile kernel; the product is rounded
-    to the storage type and the bias added after the rounding, as torch's 16-bit ``F.linear`` does on the CPU."""
+    the weight-stream kernels with split-K (csrc/gemm_skinny.hip), mid-size ones the 128-row tiles (csrc/gemm_tile128.hip), larger ones the 256 x 256 tile kernel; the bias joins the fp32
+    accumulator and the sum is rounded ONCE to the storage type, as the golden's ``F.linear(x, w, b)`` does (fixtures:
+    tests/golden, `tests/test_hip_dense.py`)."""
 
     supported_platforms_list = _ROCM
 
